@@ -1,0 +1,198 @@
+"""ctypes mirror of include/coflux.h (the C ABI of libcoflux).
+
+Field order and types must match the header exactly; tests/test_abi.py checks sizeof against
+the value the library reports and that every declared symbol is exported.
+"""
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+COMM_ID_BYTES = 128
+
+# enums (values from include/coflux.h)
+SIMILARITY_LOGARITHMIC, SIMILARITY_COARE_LOGARITHMIC = 0, 1
+STABILITY_EDSON2013, STABILITY_SHEBA, STABILITY_LARGE_YEAGER = 0, 1, 2
+ROUGHNESS_CONSTANT, ROUGHNESS_CHARNOCK, ROUGHNESS_WIND_CHARNOCK = 0, 1, 2
+SCALAR_ROUGHNESS_CONSTANT, SCALAR_ROUGHNESS_REYNOLDS = 0, 1
+VISCOSITY_CONSTANT, VISCOSITY_TEMPERATURE_DEPENDENT = 0, 1
+STOP_CONVERGENCE, STOP_FIXED = 0, 1
+VELOCITY_RELATIVE, VELOCITY_WIND = 0, 1
+MASK_NONE, MASK_U8, MASK_BOTTOM_HEIGHT = 0, 1, 2
+ALBEDO_CONSTANT, ALBEDO_LATITUDE_DEPENDENT = 0, 1
+STAGE_INTERPOLATE, STAGE_AO_FLUXES, STAGE_NET_FLUXES, STAGE_UPDATE_STATE = 0, 1, 2, 3
+
+JRA55_VARIABLES = ("tas", "huss", "psl", "uas", "vas", "rlds", "rsds", "prra", "prsn")
+JRA55_NVARS = len(JRA55_VARIABLES)
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class Grid(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("hx", C.c_int32), ("hy", C.c_int32),
+                ("ring", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Roughness(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("viscosity_kind", C.c_int32),
+                ("constant_length", C.c_double), ("maximum_length", C.c_double),
+                ("charnock", C.c_double), ("laminar", C.c_double),
+                ("wind_a1", C.c_double), ("wind_a2", C.c_double), ("wind_umax", C.c_double),
+                ("reynolds_A", C.c_double), ("reynolds_b", C.c_double),
+                ("viscosity", C.c_double * 4)]
+
+
+class Thermodynamics(C.Structure):
+    _fields_ = [("gas_constant", C.c_double), ("dry_air_molar_mass", C.c_double),
+                ("water_molar_mass", C.c_double), ("kappa_d", C.c_double),
+                ("cp_v", C.c_double), ("cp_l", C.c_double), ("cp_i", C.c_double),
+                ("LH_v0", C.c_double), ("LH_s0", C.c_double),
+                ("T_0", C.c_double), ("T_triple", C.c_double), ("p_triple", C.c_double),
+                ("T_freeze", C.c_double), ("T_icenuc", C.c_double), ("pow_icenuc", C.c_double)]
+
+
+class Seawater(C.Structure):
+    _fields_ = [("water_molar_mass", C.c_double),
+                ("constituent_molar_mass", C.c_double * 4),
+                ("constituent_mass_fraction", C.c_double * 4)]
+
+
+class FluxParams(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("abi_version", C.c_int32),
+                ("similarity_form", C.c_int32), ("stability_functions", C.c_int32),
+                ("stop_kind", C.c_int32), ("maxiter", C.c_int32),
+                ("velocity_difference", C.c_int32), ("mask_kind", C.c_int32),
+                ("tolerance", C.c_double), ("von_karman", C.c_double),
+                ("gustiness_parameter", C.c_double), ("minimum_gustiness", C.c_double),
+                ("similarity_profile_floor", C.c_double),
+                ("momentum_roughness", Roughness), ("temperature_roughness", Roughness),
+                ("water_vapor_roughness", Roughness),
+                ("reference_height", C.c_double), ("boundary_layer_height", C.c_double),
+                ("gravitational_acceleration", C.c_double),
+                ("thermo", Thermodynamics), ("seawater", Seawater),
+                ("ocean_reference_density", C.c_double), ("ocean_heat_capacity", C.c_double),
+                ("ocean_freshwater_density", C.c_double),
+                ("ocean_temperature_offset", C.c_double), ("ocean_minimum_salinity", C.c_double),
+                ("ocean_surface_z", C.c_double),
+                ("ocean_albedo_kind", C.c_int32), ("penetrating_shortwave", C.c_int32),
+                ("ocean_albedo", C.c_double), ("ocean_albedo_diffuse", C.c_double),
+                ("ocean_albedo_direct", C.c_double), ("ocean_emissivity", C.c_double),
+                ("stefan_boltzmann", C.c_double)]
+
+
+class OceanSurface(C.Structure):
+    _fields_ = [("T", C.c_void_p), ("S", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p),
+                ("mask", C.c_void_p)]
+
+
+class ExchangeFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")]
+
+
+class InterfaceFluxes(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum",
+                 "temperature", "friction_velocity", "temperature_scale", "humidity_scale",
+                 "iterations")]
+
+
+class SeaIceFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")]
+
+
+class NetOceanFluxes(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("u", "v", "T", "S", "shortwave_surface_flux", "upwelling_longwave",
+                 "downwelling_longwave", "downwelling_shortwave")]
+
+
+class AtmosSource(C.Structure):
+    _fields_ = [("data", C.c_void_p * JRA55_NVARS),
+                ("ns_x", C.c_int32), ("ns_y", C.c_int32), ("n_levels", C.c_int32),
+                ("level1", C.c_int32), ("level2", C.c_int32),
+                ("time_fraction", C.c_double)]
+
+
+class InterpWeights(C.Structure):
+    _fields_ = [("separable", C.c_int32), ("reserved", C.c_int32),
+                ("fi", C.c_void_p), ("fj", C.c_void_p),
+                ("cos_rot", C.c_void_p), ("sin_rot", C.c_void_p), ("latitude", C.c_void_p)]
+
+
+# Every symbol include/coflux.h declares (tests check they are all exported).
+EXPORTED_SYMBOLS = (
+    "cf_version", "cf_default_flux_params", "cf_create", "cf_destroy", "cf_last_error",
+    "cf_set_flux_params", "cf_set_stream", "cf_sync",
+    "cf_device_alloc", "cf_device_free", "cf_h2d", "cf_d2h",
+    "cf_interpolate_atmosphere_state", "cf_compute_atmosphere_ocean_fluxes",
+    "cf_compute_net_ocean_fluxes", "cf_update_state",
+    "cf_time_stage", "cf_time_copy",
+    "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
+)
+
+PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(PACKAGE_DIR), "csrc", "libcoflux.so")
+
+
+class CofluxLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libcoflux.so.  There is NO CPU fallback: a missing library is a hard error."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise CofluxLibraryMissing(
+            f"{p} not found: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). The HIP library is the only compute path.")
+    lib = C.CDLL(p)
+    vp = C.c_void_p
+    lib.cf_version.restype = C.c_int
+    lib.cf_default_flux_params.argtypes = [C.POINTER(FluxParams)]
+    lib.cf_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Grid), C.POINTER(FluxParams)]
+    lib.cf_destroy.argtypes = [vp]
+    lib.cf_last_error.argtypes = [vp]
+    lib.cf_last_error.restype = C.c_char_p
+    lib.cf_set_flux_params.argtypes = [vp, C.POINTER(FluxParams)]
+    lib.cf_set_stream.argtypes = [vp, vp]
+    lib.cf_sync.argtypes = [vp]
+    lib.cf_device_alloc.argtypes = [vp, C.c_size_t]
+    lib.cf_device_alloc.restype = vp
+    lib.cf_device_free.argtypes = [vp, vp]
+    lib.cf_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.cf_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.cf_interpolate_atmosphere_state.argtypes = [
+        vp, C.POINTER(AtmosSource), C.POINTER(InterpWeights), C.POINTER(ExchangeFields)]
+    lib.cf_compute_atmosphere_ocean_fluxes.argtypes = [
+        vp, C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes)]
+    lib.cf_compute_net_ocean_fluxes.argtypes = [
+        vp, C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes),
+        C.POINTER(SeaIceFields), C.POINTER(InterpWeights), C.POINTER(NetOceanFluxes)]
+    lib.cf_update_state.argtypes = [
+        vp, C.POINTER(AtmosSource), C.POINTER(InterpWeights), C.POINTER(OceanSurface),
+        C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes), C.POINTER(SeaIceFields),
+        C.POINTER(NetOceanFluxes)]
+    lib.cf_time_stage.argtypes = [
+        vp, C.c_int, C.c_int, C.POINTER(AtmosSource), C.POINTER(InterpWeights),
+        C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes),
+        C.POINTER(SeaIceFields), C.POINTER(NetOceanFluxes), C.POINTER(C.c_double)]
+    lib.cf_time_copy.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    lib.cf_comm_unique_id.argtypes = [vp]
+    lib.cf_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.cf_comm_destroy.argtypes = [vp]
+    lib.cf_halo_exchange_rows.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("cf_last_error", "cf_device_alloc"):
+            fn.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib

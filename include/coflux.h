@@ -1,0 +1,374 @@
+/*
+ * coflux.h — C ABI of libcoflux: the MI355X-native surface-flux hot path of
+ * ClimaOcean's OceanSeaIceModel (update_state! of the coupled model).
+ *
+ * Every entry point replaces one Julia function that the reference reaches through
+ * multiple dispatch (there is no FFI in the reference; the seam is described in
+ * SURVEY.md §8b).  All `path:line` citations are relative to the reference tree
+ * (CliMA/ClimaOcean.jl v0.10.0).  The arithmetic itself lives in the un-vendored
+ * NumericalEarth.jl package (Project.toml:21,31-32), so each entry cites the in-tree
+ * call/config site that pins its signature and parameters.
+ *
+ * Conventions
+ *  - plain C types only; no torch / HIP types in signatures (a stream is a `void*`
+ *    holding a hipStream_t; NULL = the context's own stream).
+ *  - every pointer named `d_*` or living inside a `cf_*_fields` struct is a DEVICE pointer.
+ *  - ocean-grid 2-D arrays are column-major with halos, `i` fastest (Oceananigans
+ *    `parent(field)` layout, omip_simulation.jl:184, KPP/kpp_surface_forcing.jl:49):
+ *        element (i, j), 0-based interior index, lives at
+ *        ptr[(j + hy) * (nx + 2*hx) + (i + hx)].
+ *    For 3-D ocean fields pass the pointer to the k = Nz level slab.
+ *  - all entry points return 0 on success, <0 on error; cf_last_error() explains.
+ *    Nothing throws across the ABI.
+ *  - a context is single-threaded; different contexts may be used from different threads.
+ *    One context per GPU (one MPI rank / one process per GPU, launch.sh:229-232).
+ */
+#ifndef COFLUX_H
+#define COFLUX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_ABI_VERSION 1
+
+/* status codes */
+#define CF_OK 0
+#define CF_ERR_INVALID (-1)   /* bad argument / inconsistent config */
+#define CF_ERR_HIP (-2)       /* HIP runtime error (message has file:line) */
+#define CF_ERR_NODEVICE (-3)  /* no usable gfx950 device */
+#define CF_ERR_COMM (-4)      /* RCCL error */
+
+typedef struct cf_ctx cf_ctx;
+
+/* ------------------------------------------------------------------------------------------
+ * Grid / launch description.
+ * Reference: LatitudeLongitudeGrid(arch; size=(1440,560,10), halo=(7,7,7)) README.md:56-61;
+ * flux kernels are launched on 0:Nx+1 × 0:Ny+1 (one halo ring) in the reference
+ * [UPSTREAM-RECALL interface_kernel_parameters] ⇒ ring = 1; ring = 0 computes the interior only.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cf_grid {
+    int32_t nx, ny;      /* interior surface cells (local slab when sharded)            */
+    int32_t hx, hy;      /* halo widths of every ocean-grid array handed to the library */
+    int32_t ring;        /* 0 or 1: extra ring of cells the kernels also compute        */
+    int32_t reserved;
+} cf_grid;
+
+/* ------------------------------------------------------------------------------------------
+ * Flux formulation parameter block.
+ * Mirrors SimilarityTheoryFluxes(FT; similarity_form, minimum_gustiness, gustiness_parameter,
+ * stability_functions, momentum_roughness_length, temperature_roughness_length,
+ * water_vapor_roughness_length) — omip_simulation.jl:42-49 (":corrected"), :63-69 (sea ice),
+ * :106-113 (":ncar" sea ice), and the defaults used at README.md:75 / omip_simulation.jl:128-132
+ * (":default" = Edson/COARE with constant Charnock 0.02, omip_simulation.jl:263).
+ * ---------------------------------------------------------------------------------------- */
+
+/* similarity_form */
+#define CF_SIMILARITY_LOGARITHMIC 0        /* log(h/l) - psi(h/L) + psi(l/L)                */
+#define CF_SIMILARITY_COARE_LOGARITHMIC 1  /* COARELogarithmicSimilarityProfile(): no psi(l/L), omip_simulation.jl:36,43 */
+
+/* stability_functions */
+#define CF_STABILITY_EDSON2013 0     /* default atmosphere–ocean (docs/climaocean.bib:1-10)            */
+#define CF_STABILITY_SHEBA 1         /* atmosphere_sea_ice_stability_functions, omip_simulation.jl:56,64 */
+#define CF_STABILITY_LARGE_YEAGER 2  /* large_yeager_stability_functions, omip_simulation.jl:96,107      */
+
+/* momentum roughness */
+#define CF_ROUGHNESS_CONSTANT 0        /* FT(5e-4), omip_simulation.jl:67                          */
+#define CF_ROUGHNESS_CHARNOCK 1        /* MomentumRoughnessLength, constant Charnock (0.02)        */
+#define CF_ROUGHNESS_WIND_CHARNOCK 2   /* WindDependentWaveFormulation, Edson 2013 eq. 13, :35,46 */
+
+/* scalar roughness */
+#define CF_SCALAR_ROUGHNESS_CONSTANT 0  /* FT(5e-5), omip_simulation.jl:68-69 */
+#define CF_SCALAR_ROUGHNESS_REYNOLDS 1  /* ScalarRoughnessLength(FT; air_kinematic_viscosity), :48-49 */
+
+/* air viscosity */
+#define CF_VISCOSITY_CONSTANT 0
+#define CF_VISCOSITY_TEMPERATURE_DEPENDENT 1 /* TemperatureDependentAirViscosity(FT), :41 */
+
+/* solver stop criteria */
+#define CF_STOP_CONVERGENCE 0  /* default: |Δu★|+|Δθ★|+|Δq★| < tolerance or iteration ≥ maxiter */
+#define CF_STOP_FIXED 1        /* FixedIterations(5), omip_simulation.jl:22,89                  */
+
+/* velocity difference */
+#define CF_VELOCITY_RELATIVE 0 /* RelativeVelocity(): Δu = u_atm − u_ocean, omip_simulation.jl:135 */
+#define CF_VELOCITY_WIND 1     /* WindVelocity():     Δu = u_atm,           omip_simulation.jl:136 */
+
+/* wet mask encoding */
+#define CF_MASK_NONE 0
+#define CF_MASK_U8 1            /* uint8 per cell, 1 = wet                                          */
+#define CF_MASK_BOTTOM_HEIGHT 2 /* f64 bottom height; cell is land when z_surface_center <= zb      */
+
+/* ocean albedo */
+#define CF_ALBEDO_CONSTANT 0            /* SurfaceRadiationProperties(0.06, 1.00), atmosphere.jl:43 */
+#define CF_ALBEDO_LATITUDE_DEPENDENT 1  /* α = a_diffuse − a_direct·cos(2φ) (Large & Yeager 2009)    */
+
+typedef struct cf_roughness {
+    int32_t kind;                 /* CF_ROUGHNESS_* (momentum) or CF_SCALAR_ROUGHNESS_* (scalars) */
+    int32_t viscosity_kind;       /* CF_VISCOSITY_*                                              */
+    double constant_length;       /* used when kind == *_CONSTANT                                 */
+    double maximum_length;        /* cap (momentum 1.0; scalars 1.6e-4, COARE 3.6)                */
+    double charnock;              /* Charnock parameter (constant form) / floor of α (wind-dependent form) */
+    double laminar;               /* laminar parameter 0.11                                       */
+    double wind_a1, wind_a2, wind_umax; /* wind-dependent α = max(charnock, a1·min(U,umax) + a2)  */
+    double reynolds_A, reynolds_b;      /* scalar roughness ℓ = A / R★^b                            */
+    double viscosity[4];          /* ν = c0 + c1 T' + c2 T'^2 + c3 T'^3 (T' in °C); c0 only if constant */
+} cf_roughness;
+
+typedef struct cf_thermodynamics {
+    double gas_constant;          /* 8.3144598 */
+    double dry_air_molar_mass;    /* 0.02897   */
+    double water_molar_mass;      /* 0.018015  */
+    double kappa_d;               /* 2/7       */
+    double cp_v, cp_l, cp_i;      /* 1859, 4181, 2100 */
+    double LH_v0, LH_s0;          /* 2500800, 2834400 */
+    double T_0, T_triple, p_triple; /* 273.16, 273.16, 611.657 */
+    double T_freeze, T_icenuc;    /* 273.15, 233 */
+    double pow_icenuc;            /* 1 */
+} cf_thermodynamics;
+
+typedef struct cf_seawater {
+    double water_molar_mass;      /* 18.02 (g/mol; used only as a ratio) */
+    double constituent_molar_mass[4];    /* Cl 35.45, Na 22.99, SO4 96.06, Mg 24.31 */
+    double constituent_mass_fraction[4]; /*    0.56,     0.31,      0.08,     0.05  */
+} cf_seawater;
+
+typedef struct cf_flux_params {
+    int32_t struct_size;          /* sizeof(cf_flux_params), checked by the library */
+    int32_t abi_version;          /* CF_ABI_VERSION */
+
+    /* SimilarityTheoryFluxes */
+    int32_t similarity_form;      /* CF_SIMILARITY_* */
+    int32_t stability_functions;  /* CF_STABILITY_*  */
+    int32_t stop_kind;            /* CF_STOP_*       */
+    int32_t maxiter;              /* convergence: cap (100); fixed: the iteration count */
+    int32_t velocity_difference;  /* CF_VELOCITY_*   */
+    int32_t mask_kind;            /* CF_MASK_*       */
+    double tolerance;             /* 1e-8 */
+    double von_karman;            /* 0.4  */
+    double gustiness_parameter;   /* β, 1 (0 in :ncar sea ice, omip_simulation.jl:109) */
+    double minimum_gustiness;     /* 0.5 ocean :40,44; 0.2 ice :66 */
+    double similarity_profile_floor; /* guard: log(h/ℓ) − ψ(h/L) [+ψ(ℓ/L)] is floored at this value (1.0),
+                                        i.e. transfer coefficients are capped at κ/floor.  Only the
+                                        pathological first iterates from the 1e-4 initial guess (ζ ≈ −10⁵)
+                                        ever reach it; converged states have 4 ≲ profile ≲ 20. */
+    cf_roughness momentum_roughness;
+    cf_roughness temperature_roughness;
+    cf_roughness water_vapor_roughness;
+
+    /* atmosphere properties (PrescribedAtmosphere) */
+    double reference_height;      /* 10 m  */
+    double boundary_layer_height; /* 600 m */
+    double gravitational_acceleration; /* 9.81 */
+    cf_thermodynamics thermo;
+    cf_seawater seawater;
+
+    /* ocean properties */
+    double ocean_reference_density;   /* 1026,            visualize/common.jl:17 */
+    double ocean_heat_capacity;       /* 3991.86795711963, visualize/common.jl:18 */
+    double ocean_freshwater_density;  /* 1000: converts P, E mass fluxes to volume fluxes */
+    double ocean_temperature_offset;  /* 273.15: ocean T is in °C                 */
+    double ocean_minimum_salinity;    /* omip_simulation.jl:125,131,314; launch.sh:74-78 */
+    double ocean_surface_z;           /* z of the top cell centre, for CF_MASK_BOTTOM_HEIGHT */
+
+    /* radiation: SurfaceRadiationProperties(albedo, emissivity), atmosphere.jl:41-44 */
+    int32_t ocean_albedo_kind;    /* CF_ALBEDO_* */
+    int32_t penetrating_shortwave; /* 1: transmitted SW goes to the separate surface_flux field
+                                      (KPP/kpp_surface_forcing.jl:47-51) and not into JT */
+    double ocean_albedo;          /* 0.06 */
+    double ocean_albedo_diffuse;  /* 0.069 */
+    double ocean_albedo_direct;   /* 0.011 */
+    double ocean_emissivity;      /* 1.0  */
+    double stefan_boltzmann;      /* 5.67e-8 */
+} cf_flux_params;
+
+/* Fill `p` with the ":default" configuration (omip_simulation.jl:128-132, :263). */
+int cf_default_flux_params(cf_flux_params* p);
+
+/* ------------------------------------------------------------------------------------------
+ * Field bundles (device pointers, ocean-grid layout unless noted)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Ocean surface state read by compute_atmosphere_ocean_fluxes! (k = Nz level): T (°C), S (g/kg)
+ * at centres, u at x-faces, v at y-faces (src/ClimaOcean.jl:29 imports the ℑ operators).      */
+typedef struct cf_ocean_surface {
+    const double* T;
+    const double* S;
+    const double* u;
+    const double* v;
+    const void* mask;      /* per cf_flux_params.mask_kind; may be NULL for CF_MASK_NONE */
+} cf_ocean_surface;
+
+/* Atmosphere state on the exchange (ocean) grid: output of interpolate_atmosphere_state!,
+ * input of the flux solver and of the net-flux assembly.                                       */
+typedef struct cf_exchange_fields {
+    double* u;   /* m/s, rotated to the grid-intrinsic frame */
+    double* v;
+    double* T;   /* K      (JRA55 tas)  */
+    double* p;   /* Pa     (psl)        */
+    double* q;   /* kg/kg  (huss)       */
+    double* Qs;  /* W/m²   (rsds)       */
+    double* Ql;  /* W/m²   (rlds)       */
+    double* Mp;  /* kg/m²/s (prra+prsn) */
+} cf_exchange_fields;
+
+/* interface (turbulent) fluxes: model.interfaces.atmosphere_ocean_interface.fluxes.*,
+ * omip_diagnostics.jl:81-82; positive = upward (ocean loses).                                  */
+typedef struct cf_interface_fluxes {
+    double* sensible_heat;  /* Qc  W/m²     */
+    double* latent_heat;    /* Qv  W/m²     */
+    double* water_vapor;    /* Fv  kg/m²/s  */
+    double* x_momentum;     /* ρτx N/m²     */
+    double* y_momentum;     /* ρτy N/m²     */
+    double* temperature;    /* interface temperature Ts, ocean units (°C) */
+    double* friction_velocity;    /* optional (may be NULL): u★ */
+    double* temperature_scale;    /* optional: θ★ */
+    double* humidity_scale;       /* optional: q★ */
+    int32_t* iterations;          /* optional: iteration count per cell (diagnostic) */
+} cf_interface_fluxes;
+
+/* sea-ice inputs to the partition (atmosphere.jl:34-39, src/ClimaOcean.jl:62-63); all may be
+ * NULL ⇒ ice-free.                                                                             */
+typedef struct cf_sea_ice_fields {
+    const double* concentration;   /* ℵ                        */
+    const double* interface_heat;  /* Qio  W/m² (ice→ocean)    */
+    const double* salt_flux;       /* Jˢio g/kg m/s            */
+    const double* x_stress;        /* ice–ocean stress at u-faces, kinematic m²/s² */
+    const double* y_stress;
+} cf_sea_ice_fields;
+
+/* net ocean fluxes: model.interfaces.net_fluxes.ocean.{u,v,T,S}, omip_diagnostics.jl:77-80.    */
+typedef struct cf_net_ocean_fluxes {
+    double* u;   /* τx kinematic m²/s² at u-faces (KPP/kpp_surface_forcing.jl:18-22) */
+    double* v;   /* τy kinematic at v-faces                                           */
+    double* T;   /* JT  K m/s   (hfds = JT·ρ·cp, visualize/cache.jl:359-361)          */
+    double* S;   /* JS  g/kg m/s                                                      */
+    double* shortwave_surface_flux; /* radiation.surface_flux (KPP/kpp_surface_forcing.jl:47-51); may be NULL */
+    double* upwelling_longwave;     /* optional diagnostics, may be NULL */
+    double* downwelling_longwave;
+    double* downwelling_shortwave;
+} cf_net_ocean_fluxes;
+
+/* JRA55 source window on its native 640×320 grid (launch.sh:86-87), Float32, NO halos:
+ *   value(var, level, js, is) = d_data[var][(level * ns_y + js) * ns_x + is].
+ * Variable order follows jra55_data_staging.jl:8.                                               */
+#define CF_JRA55_TAS 0
+#define CF_JRA55_HUSS 1
+#define CF_JRA55_PSL 2
+#define CF_JRA55_UAS 3
+#define CF_JRA55_VAS 4
+#define CF_JRA55_RLDS 5
+#define CF_JRA55_RSDS 6
+#define CF_JRA55_PRRA 7
+#define CF_JRA55_PRSN 8
+#define CF_JRA55_NVARS 9
+
+typedef struct cf_atmos_source {
+    const float* data[CF_JRA55_NVARS]; /* device pointers, each [n_levels][ns_y][ns_x] */
+    int32_t ns_x, ns_y;     /* 640, 320 */
+    int32_t n_levels;       /* time indices in memory (atmosphere.jl:26, backend_size)  */
+    int32_t level1, level2; /* the two bracketing snapshots n₁, n₂ (memory indices)     */
+    double time_fraction;   /* ñ ∈ [0,1): value = ψ₂·ñ + ψ₁·(1−ñ)                       */
+} cf_atmos_source;
+
+/* Fractional source indices of every target cell (the reference precomputes the same pair,
+ * `space_fractional_indices`).  Either separable (lat-lon → lat-lon: fi[i], fj[j]) or general
+ * (tripolar: 2-D arrays in ocean-grid layout).  Optional rotation to the grid-intrinsic frame.  */
+typedef struct cf_interp_weights {
+    int32_t separable;      /* 1: fi has nx+2*hx entries, fj has ny+2*hy entries (halo-inclusive) */
+    int32_t reserved;
+    const double* fi;       /* 0-based fractional index along source x (periodic)  */
+    const double* fj;       /* 0-based fractional index along source y (clamped)   */
+    const double* cos_rot;  /* ocean-grid 2-D arrays or NULL (no rotation)         */
+    const double* sin_rot;
+    const double* latitude; /* φ (deg) per row (ny+2*hy) if separable else 2-D; needed only for
+                               CF_ALBEDO_LATITUDE_DEPENDENT; may be NULL            */
+} cf_interp_weights;
+
+/* ------------------------------------------------------------------------------------------
+ * Lifecycle
+ * ---------------------------------------------------------------------------------------- */
+int cf_version(void);
+/* Creates a context bound to HIP device `device`.  Fails (CF_ERR_NODEVICE) when there is no GPU. */
+int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_params* params);
+int cf_destroy(cf_ctx* ctx);
+const char* cf_last_error(const cf_ctx* ctx); /* ctx may be NULL: last error of the calling thread */
+int cf_set_flux_params(cf_ctx* ctx, const cf_flux_params* params);
+int cf_set_stream(cf_ctx* ctx, void* hip_stream); /* NULL ⇒ library-owned stream */
+int cf_sync(cf_ctx* ctx);
+
+/* Device memory for callers that cannot own HIP memory themselves (Julia without AMDGPU.jl). */
+void* cf_device_alloc(cf_ctx* ctx, size_t bytes);
+int cf_device_free(cf_ctx* ctx, void* d_ptr);
+int cf_h2d(cf_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int cf_d2h(cf_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * The hot path — one entry per reference function of SURVEY.md §3.1
+ * ---------------------------------------------------------------------------------------- */
+
+/* interpolate_atmosphere_state!(interfaces, atmosphere::JRA55PrescribedAtmosphere, model)
+ * (construction site atmosphere.jl:20-29, README.md:74): bilinear in (λ,φ) × linear in time,
+ * rain+snow summed, winds rotated to the grid frame.                                           */
+int cf_interpolate_atmosphere_state(cf_ctx* ctx, const cf_atmos_source* src,
+                                    const cf_interp_weights* w, const cf_exchange_fields* out);
+
+/* compute_atmosphere_ocean_fluxes!(coupled_model) with SimilarityTheoryFluxes
+ * (omip_simulation.jl:42-49; README.md:75): the per-cell Monin–Obukhov fixed point.            */
+int cf_compute_atmosphere_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean,
+                                       const cf_exchange_fields* atmos,
+                                       const cf_interface_fluxes* out);
+
+/* compute_net_ocean_fluxes!(coupled_model): radiation (atmosphere.jl:41-44) + (1−ℵ) partition +
+ * unit conversion → τx, τy, JT, JS (omip_diagnostics.jl:77-80).                                 */
+int cf_compute_net_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean,
+                                const cf_exchange_fields* atmos,
+                                const cf_interface_fluxes* fluxes,
+                                const cf_sea_ice_fields* ice /* may be NULL */,
+                                const cf_interp_weights* w /* latitude only; may be NULL */,
+                                const cf_net_ocean_fluxes* out);
+
+/* update_state!(coupled_model) (NEMOTKE/nemo_tke_compute_closure_fields.jl:7-8): the three
+ * stages above back to back on the context's stream, with the interpolation fused into the
+ * solver kernel (the exchange fields are still written).                                       */
+int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
+                    const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
+                    const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice,
+                    const cf_net_ocean_fluxes* net);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement helper: run `launches` back-to-back launches of one stage on the context's stream
+ * bracketed by HIP events ON THAT STREAM and return the average milliseconds per launch.
+ * stage: 0 = interpolate, 1 = atmosphere–ocean fluxes, 2 = net ocean fluxes, 3 = update_state.  */
+#define CF_STAGE_INTERPOLATE 0
+#define CF_STAGE_AO_FLUXES 1
+#define CF_STAGE_NET_FLUXES 2
+#define CF_STAGE_UPDATE_STATE 3
+#define CF_STAGE_COPY 4 /* device copy of `bytes` (calibrates the HBM denominator) */
+int cf_time_stage(cf_ctx* ctx, int stage, int launches, const cf_atmos_source* src,
+                  const cf_interp_weights* w, const cf_ocean_surface* ocean,
+                  const cf_exchange_fields* atmos, const cf_interface_fluxes* fluxes,
+                  const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net,
+                  double* ms_per_launch);
+int cf_time_copy(cf_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int launches,
+                 double* ms_per_launch);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: latitude-slab halo rows over RCCL (Partition(1,4) launch.sh:165,
+ * Partition(1,8) pbs_launch.sh:51).  The unique id is produced on rank 0 and distributed by the
+ * host (MPI.jl bcast in Julia; torch.distributed in the Python mirror).
+ * ---------------------------------------------------------------------------------------- */
+#define CF_COMM_ID_BYTES 128
+int cf_comm_unique_id(void* id128);
+int cf_comm_init(cf_ctx* ctx, const void* id128, int rank, int nranks);
+int cf_comm_destroy(cf_ctx* ctx);
+/* Exchange `rows` boundary rows of `nfields` ocean-grid arrays with the south (rank−1) and north
+ * (rank+1) neighbours: my first/last interior rows → their north/south halos.                   */
+int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COFLUX_H */

@@ -1,0 +1,617 @@
+/*
+ * coflux_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, double precision, scalar per-cell loops) of the surface-flux hot
+ * path of ClimaOcean's OceanSeaIceModel: interpolate_atmosphere_state!, the
+ * SimilarityTheoryFluxes Monin–Obukhov fixed point of compute_atmosphere_ocean_fluxes!, and
+ * compute_net_ocean_fluxes!.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product (libcoflux.so) never links or calls it.
+ *
+ * PARITY UNPINNED.  The arithmetic of this path is not in /root/reference: it lives in the
+ * third-party package NumericalEarth.jl (uuid 904d977b-046a-4731-8b86-9235c0d1ef02), which
+ * the reference takes un-vendored at `rev = "main"` with compat 0.4–0.8 and no Manifest
+ * (Project.toml:21,31-32,48; .gitignore:1).  No Julia toolchain exists in this image, the
+ * reference's tests hold no numerical vector for this path (test/test_module.jl:11-45 are
+ * isdefined checks) and there are no golden files.  This file therefore restates the published
+ * algorithm of that package's InterfaceComputations module (the code that was
+ * ClimaOcean.OceanSeaIceModels.InterfaceComputations up to ClimaOcean v0.8.x, README.md:13-16)
+ * together with CliMA Thermodynamics.jl's moist-air relations and the cited literature
+ * (Edson et al. 2013; COARE 3.6; Large & Yeager 2009; Grachev et al. 2007;
+ * docs/climaocean.bib:1-51), and is anchored on every parameter, keyword, unit and sign
+ * convention the reference tree itself fixes:
+ *   - formulation parameter sets .......... src/OMIPConfigurations/omip_simulation.jl:40-113
+ *   - constant Charnock 0.02 default ...... omip_simulation.jl:263
+ *   - velocity difference policy .......... omip_simulation.jl:135-137, 283-286
+ *   - minimum-salinity semantics .......... experiments/OMIPSimulations/scripts/launch.sh:74-78
+ *   - albedo 0.06 / emissivity 1.0 ........ src/OMIPConfigurations/atmosphere.jl:41-44
+ *   - ρₒ = 1026, cₒ = 3991.86795711963 .... experiments/OMIPSimulations/scripts/visualize/common.jl:17-18
+ *   - τ kinematic at faces, JT·ρ·cp=W/m² .. visualize/cache.jl:359-383, KPP/kpp_surface_forcing.jl:18-29
+ *   - SW to radiation.surface_flux ........ KPP/kpp_surface_forcing.jl:47-51
+ *   - JRA55 variable list, 640×320 f32 .... jra55_data_staging.jl:8, launch.sh:86-87
+ * It is cross-checked by an independently written NumPy restatement (oracle/numpy_oracle.py)
+ * and by physical known-answer tests (tests/test_oracle.py).
+ *
+ * Operation order follows the upstream kernels as recalled so that a future run against the
+ * real package (julia/oracle_dump.jl, only possible where Julia+NumericalEarth exist) is as
+ * close as floating point allows.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/coflux.h"
+
+#define IDX(g, i, j) ((size_t)((j) + (g)->hy) * (size_t)((g)->nx + 2 * (g)->hx) + (size_t)((i) + (g)->hx))
+
+/* ------------------------------------------------------------------------------------------
+ * Moist-air thermodynamics (CliMA Thermodynamics.jl relations behind
+ * AtmosphericThermodynamics.PhaseEquil_pTq and friends)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double R_d, R_v, eps, cp_d;
+} thermo_derived;
+
+static thermo_derived derive(const cf_thermodynamics* t) {
+    thermo_derived d;
+    d.R_d = t->gas_constant / t->dry_air_molar_mass;
+    d.R_v = t->gas_constant / t->water_molar_mass;
+    d.eps = t->dry_air_molar_mass / t->water_molar_mass; /* molmass_ratio */
+    d.cp_d = d.R_d / t->kappa_d;
+    return d;
+}
+
+/* liquid_fraction(param_set, T, PhaseEquil) */
+static double liquid_fraction(const cf_thermodynamics* t, double T) {
+    if (T > t->T_freeze) return 1.0;
+    if (T > t->T_icenuc) return pow((T - t->T_icenuc) / (t->T_freeze - t->T_icenuc), t->pow_icenuc);
+    return 0.0;
+}
+
+/* saturation_vapor_pressure(param_set, T, LH_0, Δcp): Clausius–Clapeyron with linear L(T) */
+static double svp_general(const cf_thermodynamics* t, const thermo_derived* d, double T, double LH_0,
+                          double dcp) {
+    return t->p_triple * pow(T / t->T_triple, dcp / d->R_v) *
+           exp((LH_0 - dcp * t->T_0) / d->R_v * (1.0 / t->T_triple - 1.0 / T));
+}
+
+static double svp_liquid(const cf_thermodynamics* t, const thermo_derived* d, double T) {
+    return svp_general(t, d, T, t->LH_v0, t->cp_v - t->cp_l);
+}
+
+/* saturation_vapor_pressure(param_set, PhaseEquil, T): liquid-fraction weighted */
+static double svp_equil(const cf_thermodynamics* t, const thermo_derived* d, double T) {
+    double lam = liquid_fraction(t, T);
+    double LH_0 = lam * t->LH_v0 + (1.0 - lam) * t->LH_s0;
+    double dcp = lam * (t->cp_v - t->cp_l) + (1.0 - lam) * (t->cp_v - t->cp_i);
+    return svp_general(t, d, T, LH_0, dcp);
+}
+
+typedef struct {
+    double rho, p, T, q_tot;
+} thermo_state; /* PhaseEquil state (internal energy is never used on this path) */
+
+static double gas_constant_air(const thermo_derived* d, double q_tot, double q_c) {
+    return d->R_d * (1.0 + (d->eps - 1.0) * q_tot - d->eps * q_c);
+}
+
+/* PhaseEquil_pTq(param_set, p, T, q_tot) */
+static thermo_state phase_equil_pTq(const cf_thermodynamics* t, const thermo_derived* d, double p,
+                                    double T, double q_tot) {
+    thermo_state s;
+    double q = fmin(fmax(q_tot, 0.0), 1.0);
+    double p_vs = svp_equil(t, d, T);
+    /* q_vap_saturation_from_pressure */
+    double q_vs = (p - p_vs >= 2.220446049250313e-16)
+                      ? d->R_d / d->R_v * (1.0 - q) * p_vs / (p - p_vs)
+                      : 1.0 / 2.220446049250313e-16;
+    double q_c = fmax(q - q_vs, 0.0);
+    s.rho = p / (gas_constant_air(d, q, q_c) * T);
+    s.p = p;
+    s.T = T;
+    s.q_tot = q;
+    return s;
+}
+
+/* PhasePartition(ts::PhaseEquil): condensate from (T, ρ, q_tot) */
+static double condensate(const cf_thermodynamics* t, const thermo_derived* d, const thermo_state* s,
+                         double* q_liq, double* q_ice) {
+    double p_vs = svp_equil(t, d, s->T);
+    double q_vs = p_vs / (s->rho * d->R_v * s->T);
+    double q_c = fmax(s->q_tot - q_vs, 0.0);
+    double lam = liquid_fraction(t, s->T);
+    *q_liq = lam * q_c;
+    *q_ice = (1.0 - lam) * q_c;
+    return q_c;
+}
+
+static double cp_m(const cf_thermodynamics* t, const thermo_derived* d, const thermo_state* s) {
+    double ql, qi;
+    condensate(t, d, s, &ql, &qi);
+    return d->cp_d + (t->cp_v - d->cp_d) * s->q_tot + (t->cp_l - t->cp_v) * ql + (t->cp_i - t->cp_v) * qi;
+}
+
+static double vapor_specific_humidity(const cf_thermodynamics* t, const thermo_derived* d,
+                                      const thermo_state* s) {
+    double ql, qi;
+    condensate(t, d, s, &ql, &qi);
+    return fmax(0.0, s->q_tot - ql - qi);
+}
+
+static double virtual_temperature(const cf_thermodynamics* t, const thermo_derived* d,
+                                  const thermo_state* s) {
+    double ql, qi;
+    double q_c = condensate(t, d, s, &ql, &qi);
+    return gas_constant_air(d, s->q_tot, q_c) / d->R_d * s->T;
+}
+
+static double latent_heat_vapor(const cf_thermodynamics* t, double T) {
+    return t->LH_v0 + (t->cp_v - t->cp_l) * (T - t->T_0);
+}
+
+/* compute_water_mole_fraction(::WaterMoleFraction, S): Raoult's law factor of sea water */
+static double water_mole_fraction(const cf_seawater* w, double S) {
+    double s = S / 1000.0;
+    double alpha = s / (1.0 - s);
+    double inv_mu = 0.0;
+    for (int k = 0; k < 4; ++k) inv_mu += w->constituent_mass_fraction[k] / w->constituent_molar_mass[k];
+    double inv_w = 1.0 / w->water_molar_mass;
+    return inv_w / (inv_w + alpha * inv_mu);
+}
+
+/* saturation_specific_humidity(SpecificHumidityFormulation(Liquid, WaterMoleFraction), ℂ, ρ, T, S) */
+static double saturation_specific_humidity_ocean(const cf_flux_params* P, const thermo_derived* d,
+                                                 double rho, double T, double S) {
+    double x = water_mole_fraction(&P->seawater, S);
+    double p_star = svp_liquid(&P->thermo, d, T);
+    double q_star = p_star / (rho * d->R_v * T);
+    return q_star * x;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stability functions ψ(ζ)
+ * ---------------------------------------------------------------------------------------- */
+static double psi_momentum(int kind, double zeta) {
+    const double pi = 3.14159265358979323846;
+    double zm = fmin(0.0, zeta), zp = fmax(0.0, zeta);
+    if (kind == CF_STABILITY_EDSON2013) {
+        /* Edson et al. 2013 / COARE 3.5 psiu_26 */
+        double dz = fmin(50.0, 0.35 * zp);
+        double ps = -0.7 * zp - 0.75 * (zp - 5.0 / 0.35) * exp(-dz) - 0.75 * 5.0 / 0.35;
+        double f1 = sqrt(sqrt(1.0 - 15.0 * zm));
+        double pu1 = 2.0 * log((1.0 + f1) / 2.0) + log((1.0 + f1 * f1) / 2.0) - 2.0 * atan(f1) + pi / 2.0;
+        double f2 = cbrt(1.0 - 10.15 * zm);
+        double pu2 = 1.5 * log((1.0 + f2 + f2 * f2) / 3.0) - sqrt(3.0) * atan((1.0 + 2.0 * f2) / sqrt(3.0)) +
+                     pi / sqrt(3.0);
+        double f = zm * zm / (1.0 + zm * zm);
+        double pu = (1.0 - f) * pu1 + f * pu2;
+        return zeta < 0.0 ? pu : ps;
+    } else if (kind == CF_STABILITY_SHEBA) {
+        /* stable: Grachev et al. 2007 eq. 12; unstable: Paulson 1970 */
+        const double a = 5.0, b = 5.0 / 6.5;
+        double B = cbrt((1.0 - b) / b);
+        double x = cbrt(1.0 + zp);
+        double r3 = sqrt(3.0);
+        double ps = -3.0 * a / b * (x - 1.0) +
+                    a * B / (2.0 * b) *
+                        (2.0 * log((x + B) / (1.0 + B)) - log((x * x - x * B + B * B) / (1.0 - B + B * B)) +
+                         2.0 * r3 * (atan((2.0 * x - B) / (r3 * B)) - atan((2.0 - B) / (r3 * B))));
+        double y = sqrt(sqrt(1.0 - 16.0 * zm));
+        double pu = 2.0 * log((1.0 + y) / 2.0) + log((1.0 + y * y) / 2.0) - 2.0 * atan(y) + pi / 2.0;
+        return zeta < 0.0 ? pu : ps;
+    } else {
+        /* Large & Yeager 2009: Paulson unstable, −5ζ stable */
+        double y = sqrt(sqrt(1.0 - 16.0 * zm));
+        double pu = 2.0 * log((1.0 + y) / 2.0) + log((1.0 + y * y) / 2.0) - 2.0 * atan(y) + pi / 2.0;
+        double ps = -5.0 * zp;
+        return zeta < 0.0 ? pu : ps;
+    }
+}
+
+static double psi_scalar(int kind, double zeta) {
+    const double pi = 3.14159265358979323846;
+    double zm = fmin(0.0, zeta), zp = fmax(0.0, zeta);
+    if (kind == CF_STABILITY_EDSON2013) {
+        /* COARE 3.5 psit_26 */
+        double dz = fmin(50.0, 0.35 * zp);
+        double base = 1.0 + 2.0 / 3.0 * zp;
+        double ps = -(base * sqrt(base)) - 2.0 / 3.0 * (zp - 14.28) * exp(-dz) - 8.525;
+        double f1 = sqrt(1.0 - 15.0 * zm);
+        double pu1 = 2.0 * log((1.0 + f1) / 2.0);
+        double f2 = cbrt(1.0 - 34.15 * zm);
+        double pu2 = 1.5 * log((1.0 + f2 + f2 * f2) / 3.0) - sqrt(3.0) * atan((1.0 + 2.0 * f2) / sqrt(3.0)) +
+                     pi / sqrt(3.0);
+        double f = zm * zm / (1.0 + zm * zm);
+        double pu = (1.0 - f) * pu1 + f * pu2;
+        return zeta < 0.0 ? pu : ps;
+    } else if (kind == CF_STABILITY_SHEBA) {
+        /* Grachev et al. 2007 eq. 13 */
+        const double a = 5.0, b = 5.0, c = 3.0;
+        double B = sqrt(c * c - 4.0);
+        double ps = -b / 2.0 * log(1.0 + c * zp + zp * zp) +
+                    (-a / B + b * c / (2.0 * B)) *
+                        (log((2.0 * zp + c - B) / (2.0 * zp + c + B)) - log((c - B) / (c + B)));
+        double y2 = sqrt(1.0 - 16.0 * zm);
+        double pu = 2.0 * log((1.0 + y2) / 2.0);
+        return zeta < 0.0 ? pu : ps;
+    } else {
+        double y2 = sqrt(1.0 - 16.0 * zm);
+        double pu = 2.0 * log((1.0 + y2) / 2.0);
+        double ps = -5.0 * zp;
+        return zeta < 0.0 ? pu : ps;
+    }
+}
+
+/* similarity_profile(form, ψ, h, ℓ, L) */
+static double similarity_profile(int form, int stab, int scalar, double h, double l, double L,
+                                 double floor_) {
+    double psi_h = scalar ? psi_scalar(stab, h / L) : psi_momentum(stab, h / L);
+    double r = log(h / l) - psi_h;
+    if (form == CF_SIMILARITY_LOGARITHMIC) r += scalar ? psi_scalar(stab, l / L) : psi_momentum(stab, l / L);
+    /* restatement guard (include/coflux.h: similarity_profile_floor): the first iterate from the
+       1e-4 initial guess has ζ ≈ −10⁵ and, in the COARE form, a negative profile ⇒ u★ < 0 ⇒
+       log of a negative roughness length.  Upstream's own guard is unknown (parity unpinned). */
+    return r < floor_ ? floor_ : r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Roughness lengths
+ * ---------------------------------------------------------------------------------------- */
+static double air_viscosity(const cf_roughness* r, double T_kelvin) {
+    if (r->viscosity_kind == CF_VISCOSITY_CONSTANT) return r->viscosity[0];
+    double Tc = T_kelvin - 273.15;
+    return r->viscosity[0] + r->viscosity[1] * Tc + r->viscosity[2] * Tc * Tc + r->viscosity[3] * Tc * Tc * Tc;
+}
+
+/* roughness_length(ℓ::MomentumRoughnessLength, u★, …); `U` = |Δu| at the reference height feeds
+ * the wind-dependent Charnock parameter (Edson 2013 eq. 13, omip_simulation.jl:35). */
+static double momentum_roughness(const cf_roughness* r, double g, double ustar, double U, double Ts) {
+    if (r->kind == CF_ROUGHNESS_CONSTANT) return r->constant_length;
+    double alpha = r->charnock;
+    if (r->kind == CF_ROUGHNESS_WIND_CHARNOCK) /* `charnock` is the floor of the linear fit */
+        alpha = fmax(r->charnock, r->wind_a1 * fmin(U, r->wind_umax) + r->wind_a2);
+    double nu = air_viscosity(r, Ts);
+    double lm = r->maximum_length;
+    double lR = (ustar == 0.0) ? lm : r->laminar * nu / ustar;
+    return fmin(alpha * ustar * ustar / g + lR, lm);
+}
+
+/* roughness_length(ℓ::ScalarRoughnessLength, ℓu, u★, …) */
+static double scalar_roughness(const cf_roughness* r, double lu, double ustar, double Ts) {
+    if (r->kind == CF_SCALAR_ROUGHNESS_CONSTANT) return r->constant_length;
+    double nu = air_viscosity(r, Ts);
+    double lm = r->maximum_length;
+    double Rstar = lu * ustar / nu;
+    double lq = (Rstar == 0.0) ? 0.0 : r->reynolds_A / pow(Rstar, r->reynolds_b);
+    lq = (ustar == 0.0) ? lm : lq;
+    return fmin(lq, lm);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Per-cell solve: compute_interface_state + the flux formulas of
+ * _compute_atmosphere_ocean_interface_state!
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double Qc, Qv, Fv, rho_tau_x, rho_tau_y, Ts_ocean_units;
+    double ustar, theta_star, q_star;
+    int iterations;
+} cell_result;
+
+static cell_result solve_cell(const cf_flux_params* P, double ua, double va, double Ta, double pa,
+                              double qa, double uo, double vo, double To, double So, int wet) {
+    cell_result R;
+    memset(&R, 0, sizeof R);
+    const cf_thermodynamics* t = &P->thermo;
+    thermo_derived d = derive(t);
+    const double g = P->gravitational_acceleration;
+    const double kappa = P->von_karman;
+    const double h = P->reference_height;
+
+    double Ti = To + P->ocean_temperature_offset; /* convert_to_kelvin */
+    thermo_state Qa = phase_equil_pTq(t, &d, pa, Ta, qa);
+
+    /* Don't iterate (and write zeros) on land: needs_to_converge && not_water ⇒ zero state;
+       FixedIterations ⇒ iterate, then zero the state with ifelse. */
+    int skip = (!wet) && (P->stop_kind == CF_STOP_CONVERGENCE);
+
+    double ustar = 1e-4, tstar = 1e-4, qstar = 1e-4;
+    int iters = 0;
+    double Ts = Ti;
+
+    if (!skip) {
+        /* interface specific humidity from the interior temperature (BulkTemperature ⇒ Ts = Ti) */
+        double qs = saturation_specific_humidity_ocean(P, &d, Qa.rho, Ts, So);
+        double qa_v = vapor_specific_humidity(t, &d, &Qa);
+        double dq = qa_v - qs;
+        double theta_a = Ta + g * h / cp_m(t, &d, &Qa); /* surface_atmosphere_temperature */
+        double dtheta = theta_a - Ts;
+        double du, dv;
+        if (P->velocity_difference == CF_VELOCITY_RELATIVE) {
+            du = ua - uo;
+            dv = va - vo;
+        } else {
+            du = ua;
+            dv = va;
+        }
+        thermo_state Qs = phase_equil_pTq(t, &d, pa, Ts, qs);
+        double Tv = virtual_temperature(t, &d, &Qs);
+        double qv_s = vapor_specific_humidity(t, &d, &Qs);
+        double delta = d.eps - 1.0;
+
+        double up = ustar, tp = tstar, qp = qstar;
+        for (;;) {
+            /* iterating(Ψⁿ, Ψ⁻, iteration, criteria) */
+            int go;
+            if (P->stop_kind == CF_STOP_FIXED) {
+                go = iters < P->maxiter;
+            } else {
+                int hasnt_started = iters == 0;
+                int reached = iters >= P->maxiter;
+                double drift = fabs(ustar - up) + fabs(tstar - tp) + fabs(qstar - qp);
+                int converged = drift < P->tolerance;
+                go = (!(converged | reached)) | hasnt_started;
+            }
+            if (!go) break;
+            up = ustar;
+            tp = tstar;
+            qp = qstar;
+
+            /* iterate_interface_fluxes */
+            double bstar = g / Tv * (tstar * (1.0 + delta * qv_s) + delta * Tv * qstar);
+            double Jb = -ustar * bstar;
+            double Ug = P->gustiness_parameter * cbrt(fmax(Jb, 0.0) * P->boundary_layer_height);
+            Ug = fmax(Ug, P->minimum_gustiness);
+            double dU = sqrt(du * du + dv * dv);
+            double U = sqrt(du * du + dv * dv + Ug * Ug);
+
+            double lu = momentum_roughness(&P->momentum_roughness, g, ustar, dU, Ts);
+            double lq = scalar_roughness(&P->water_vapor_roughness, lu, ustar, Ts);
+            double lt = scalar_roughness(&P->temperature_roughness, lu, ustar, Ts);
+
+            double L = (bstar == 0.0) ? INFINITY : -ustar * ustar / (kappa * bstar);
+            double chi_u = kappa / similarity_profile(P->similarity_form, P->stability_functions, 0, h, lu, L, P->similarity_profile_floor);
+            double chi_t = kappa / similarity_profile(P->similarity_form, P->stability_functions, 1, h, lt, L, P->similarity_profile_floor);
+            double chi_q = kappa / similarity_profile(P->similarity_form, P->stability_functions, 1, h, lq, L, P->similarity_profile_floor);
+
+            ustar = chi_u * U;
+            tstar = chi_t * dtheta;
+            qstar = chi_q * dq;
+            ++iters;
+        }
+
+        if (!wet) { /* FixedIterations on land: zeroed afterwards */
+            ustar = tstar = qstar = 0.0;
+            Ts = 0.0;
+        }
+
+        double dU = sqrt(du * du + dv * dv);
+        double taux = (dU == 0.0) ? 0.0 : -ustar * ustar * du / dU;
+        double tauy = (dU == 0.0) ? 0.0 : -ustar * ustar * dv / dU;
+        double rho_a = Qa.rho;
+        double cp = cp_m(t, &d, &Qa);
+        double Lv = latent_heat_vapor(t, Qa.T);
+        R.Qv = -rho_a * ustar * qstar * Lv;
+        R.Qc = -rho_a * cp * ustar * tstar;
+        R.Fv = -rho_a * ustar * qstar;
+        R.rho_tau_x = rho_a * taux;
+        R.rho_tau_y = rho_a * tauy;
+    } else {
+        ustar = tstar = qstar = 0.0;
+        Ts = 0.0; /* zero_interface_state: T = 0 K */
+    }
+    /* convert_from_kelvin(ocean units, Ψₛ.T) */
+    R.Ts_ocean_units = Ts - P->ocean_temperature_offset;
+    R.ustar = ustar;
+    R.theta_star = tstar;
+    R.q_star = qstar;
+    R.iterations = iters;
+    return R;
+}
+
+static int is_wet(const cf_flux_params* P, const cf_grid* g, const void* mask, int i, int j) {
+    if (P->mask_kind == CF_MASK_NONE || mask == NULL) return 1;
+    size_t k = IDX(g, i, j);
+    if (P->mask_kind == CF_MASK_U8) return ((const uint8_t*)mask)[k] != 0;
+    return !(P->ocean_surface_z <= ((const double*)mask)[k]); /* inactive_node: z ≤ bottom height */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Exported entry points (host pointers, same layouts as include/coflux.h)
+ * ---------------------------------------------------------------------------------------- */
+int oracle_compute_atmosphere_ocean_fluxes(const cf_grid* g, const cf_flux_params* P,
+                                           const cf_ocean_surface* o, const cf_exchange_fields* a,
+                                           const cf_interface_fluxes* out, int nthreads) {
+    int r = g->ring;
+    (void)nthreads;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int j = -r; j < g->ny + r; ++j) {
+        for (int i = -r; i < g->nx + r; ++i) {
+            size_t k = IDX(g, i, j);
+            /* ℑxᶜᵃᵃ(i, j, k, grid, u) = (u[i] + u[i+1]) / 2 ; ℑyᵃᶜᵃ likewise */
+            double uo = 0.5 * (o->u[k] + o->u[IDX(g, i + 1, j)]);
+            double vo = 0.5 * (o->v[k] + o->v[IDX(g, i, j + 1)]);
+            cell_result R = solve_cell(P, a->u[k], a->v[k], a->T[k], a->p[k], a->q[k], uo, vo, o->T[k],
+                                       o->S[k], is_wet(P, g, o->mask, i, j));
+            out->sensible_heat[k] = R.Qc;
+            out->latent_heat[k] = R.Qv;
+            out->water_vapor[k] = R.Fv;
+            out->x_momentum[k] = R.rho_tau_x;
+            out->y_momentum[k] = R.rho_tau_y;
+            out->temperature[k] = R.Ts_ocean_units;
+            if (out->friction_velocity) out->friction_velocity[k] = R.ustar;
+            if (out->temperature_scale) out->temperature_scale[k] = R.theta_star;
+            if (out->humidity_scale) out->humidity_scale[k] = R.q_star;
+            if (out->iterations) out->iterations[k] = R.iterations;
+        }
+    }
+    return 0;
+}
+
+/* Oceananigans `interpolator(fractional_idx)` + `_interpolate` restricted to 2-D, then the
+ * linear blend in time of interp_atmos_time_series. */
+static double interp_one(const float* data, int nsx, int nsy, int l1, int l2, double tf, double fi,
+                         double fj) {
+    double ti = trunc(fi), tj = trunc(fj);
+    double xi = fi - ti, eta = fj - tj;
+    long i0 = (long)ti, j0 = (long)tj;
+    long i1 = i0 + (fi > 0 ? 1 : (fi < 0 ? -1 : 0));
+    long j1 = j0 + (fj > 0 ? 1 : (fj < 0 ? -1 : 0));
+    /* periodic in x (JRA55 longitude), clamped in y */
+    i0 = ((i0 % nsx) + nsx) % nsx;
+    i1 = ((i1 % nsx) + nsx) % nsx;
+    if (j0 < 0) j0 = 0;
+    if (j0 > nsy - 1) j0 = nsy - 1;
+    if (j1 < 0) j1 = 0;
+    if (j1 > nsy - 1) j1 = nsy - 1;
+    double v[2];
+    int lv[2] = {l1, l2};
+    for (int n = 0; n < 2; ++n) {
+        const float* d = data + (size_t)lv[n] * nsx * nsy;
+        double a00 = d[j0 * nsx + i0], a10 = d[j0 * nsx + i1];
+        double a01 = d[j1 * nsx + i0], a11 = d[j1 * nsx + i1];
+        v[n] = (1.0 - xi) * (1.0 - eta) * a00 + (1.0 - xi) * eta * a01 + xi * (1.0 - eta) * a10 +
+               xi * eta * a11;
+    }
+    return v[1] * tf + v[0] * (1.0 - tf);
+}
+
+int oracle_interpolate_atmosphere_state(const cf_grid* g, const cf_atmos_source* s,
+                                        const cf_interp_weights* w, const cf_exchange_fields* out) {
+    int r = g->ring;
+    for (int j = -r; j < g->ny + r; ++j) {
+        for (int i = -r; i < g->nx + r; ++i) {
+            size_t k = IDX(g, i, j);
+            double fi = w->separable ? w->fi[i + g->hx] : w->fi[k];
+            double fj = w->separable ? w->fj[j + g->hy] : w->fj[k];
+#define ITP(var) interp_one(s->data[var], s->ns_x, s->ns_y, s->level1, s->level2, s->time_fraction, fi, fj)
+            double ua = ITP(CF_JRA55_UAS), va = ITP(CF_JRA55_VAS);
+            double Ta = ITP(CF_JRA55_TAS), qa = ITP(CF_JRA55_HUSS), pa = ITP(CF_JRA55_PSL);
+            double Qs = ITP(CF_JRA55_RSDS), Ql = ITP(CF_JRA55_RLDS);
+            double Mp = ITP(CF_JRA55_PRRA) + ITP(CF_JRA55_PRSN);
+#undef ITP
+            if (w->cos_rot && w->sin_rot) { /* intrinsic_vector: geographic (E,N) → grid frame */
+                double c = w->cos_rot[k], sn = w->sin_rot[k];
+                double ui = ua * c + va * sn;
+                double vi = -ua * sn + va * c;
+                ua = ui;
+                va = vi;
+            }
+            out->u[k] = ua;
+            out->v[k] = va;
+            out->T[k] = Ta;
+            out->p[k] = pa;
+            out->q[k] = qa;
+            out->Qs[k] = Qs;
+            out->Ql[k] = Ql;
+            out->Mp[k] = Mp;
+        }
+    }
+    return 0;
+}
+
+int oracle_compute_net_ocean_fluxes(const cf_grid* g, const cf_flux_params* P, const cf_ocean_surface* o,
+                                    const cf_exchange_fields* a, const cf_interface_fluxes* f,
+                                    const cf_sea_ice_fields* ice, const cf_interp_weights* w,
+                                    const cf_net_ocean_fluxes* out) {
+    const double rho_o_inv = 1.0 / P->ocean_reference_density;
+    const double rho_f_inv = 1.0 / P->ocean_freshwater_density;
+    const double c_o = P->ocean_heat_capacity;
+    const double pi = 3.14159265358979323846;
+    for (int j = 0; j < g->ny; ++j) {
+        for (int i = 0; i < g->nx; ++i) {
+            size_t k = IDX(g, i, j), kw = IDX(g, i - 1, j), ks = IDX(g, i, j - 1);
+            int wet = is_wet(P, g, o->mask, i, j);
+            double aice = (ice && ice->concentration) ? ice->concentration[k] : 0.0;
+            double aice_w = (ice && ice->concentration) ? ice->concentration[kw] : 0.0;
+            double aice_s = (ice && ice->concentration) ? ice->concentration[ks] : 0.0;
+            double So = o->S[k];
+            double Ts = f->temperature[k] + P->ocean_temperature_offset;
+            double Mp = a->Mp[k], Qs = a->Qs[k], Ql = a->Ql[k];
+            double Qc = f->sensible_heat[k], Qv = f->latent_heat[k], Mv = f->water_vapor[k];
+
+            double alb = P->ocean_albedo;
+            if (P->ocean_albedo_kind == CF_ALBEDO_LATITUDE_DEPENDENT) {
+                double phi = w->separable ? w->latitude[j + g->hy] : w->latitude[k];
+                alb = P->ocean_albedo_diffuse - P->ocean_albedo_direct * cos(2.0 * phi * pi / 180.0);
+            }
+            double eps = P->ocean_emissivity;
+            double Qu = eps * P->stefan_boltzmann * Ts * Ts * Ts * Ts; /* emitted longwave   */
+            double Qal = -eps * Ql;                                    /* absorbed longwave  */
+            double Qts = -(1.0 - alb) * Qs * (1.0 - aice);             /* transmitted SW     */
+            double Qss = P->penetrating_shortwave ? 0.0 : Qts;
+            double SQao = (Qu + Qc + Qv + Qal) * (1.0 - aice) + Qss;
+
+            double SFao = -Mp * rho_f_inv + Mv * rho_f_inv;
+            /* ocean_minimum_salinity: suppress freshening (ΣF < 0) below the floor, launch.sh:74-78 */
+            double SFs = (So < P->ocean_minimum_salinity && SFao < 0.0) ? 0.0 : SFao;
+
+            double Qio = (ice && ice->interface_heat) ? ice->interface_heat[k] : 0.0;
+            double Jsio = (ice && ice->salt_flux) ? ice->salt_flux[k] : 0.0;
+            double JTao = SQao * rho_o_inv / c_o;
+            double JSao = -So * SFs;
+            double JTio = Qio * rho_o_inv / c_o;
+
+            double txao = 0.5 * (f->x_momentum[kw] + f->x_momentum[k]) * rho_o_inv;
+            double tyao = 0.5 * (f->y_momentum[ks] + f->y_momentum[k]) * rho_o_inv;
+            double ax = 0.5 * (aice_w + aice), ay = 0.5 * (aice_s + aice);
+            double txio = (ice && ice->x_stress) ? ice->x_stress[k] : 0.0;
+            double tyio = (ice && ice->y_stress) ? ice->y_stress[k] : 0.0;
+
+            double wetf = wet ? 1.0 : 0.0; /* immersed cells carry zero flux */
+            out->u[k] = wetf * ((1.0 - ax) * txao + ax * txio);
+            out->v[k] = wetf * ((1.0 - ay) * tyao + ay * tyio);
+            out->T[k] = wetf * (JTao + JTio);
+            out->S[k] = wetf * ((1.0 - aice) * JSao + Jsio);
+            if (out->shortwave_surface_flux) out->shortwave_surface_flux[k] = wetf * Qts * rho_o_inv / c_o;
+            if (out->upwelling_longwave) out->upwelling_longwave[k] = wetf * Qu;
+            if (out->downwelling_longwave) out->downwelling_longwave[k] = wetf * (-Qal);
+            if (out->downwelling_shortwave) out->downwelling_shortwave[k] = wetf * (-Qts);
+        }
+    }
+    return 0;
+}
+
+/* scalar hooks for known-answer tests */
+double oracle_psi_momentum(int kind, double zeta) { return psi_momentum(kind, zeta); }
+double oracle_psi_scalar(int kind, double zeta) { return psi_scalar(kind, zeta); }
+double oracle_saturation_vapor_pressure_liquid(const cf_flux_params* P, double T) {
+    thermo_derived d = derive(&P->thermo);
+    return svp_liquid(&P->thermo, &d, T);
+}
+double oracle_water_mole_fraction(const cf_flux_params* P, double S) {
+    return water_mole_fraction(&P->seawater, S);
+}
+double oracle_air_density(const cf_flux_params* P, double p, double T, double q) {
+    thermo_derived d = derive(&P->thermo);
+    thermo_state s = phase_equil_pTq(&P->thermo, &d, p, T, q);
+    return s.rho;
+}
+/* out[10] = Qc, Qv, Fv, ρτx, ρτy, Ts, u★, θ★, q★, iterations */
+int oracle_solve_cell(const cf_flux_params* P, double ua, double va, double Ta, double pa, double qa,
+                      double uo, double vo, double To, double So, int wet, double* out) {
+    cell_result R = solve_cell(P, ua, va, Ta, pa, qa, uo, vo, To, So, wet);
+    out[0] = R.Qc;
+    out[1] = R.Qv;
+    out[2] = R.Fv;
+    out[3] = R.rho_tau_x;
+    out[4] = R.rho_tau_y;
+    out[5] = R.Ts_ocean_units;
+    out[6] = R.ustar;
+    out[7] = R.theta_star;
+    out[8] = R.q_star;
+    out[9] = (double)R.iterations;
+    return 0;
+}
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

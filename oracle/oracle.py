@@ -1,0 +1,192 @@
+"""ctypes wrapper of the CPU oracle (oracle/coflux_oracle.c).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
+PARITY UNPINNED — see the header of coflux_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "climaocean.jl_amd"))
+from coflux import abi  # noqa: E402  (struct layouts of include/coflux.h)
+
+LIB = os.path.join(HERE, "liboracle_coflux.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(HERE, "coflux_oracle.c")
+    hdr = os.path.join(ROOT, "include", "coflux.h")
+    stale = (not os.path.exists(LIB)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB) for s in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", HERE, "-B", "liboracle_coflux.so"],
+                              stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        lib = C.CDLL(LIB)
+        for n in ("oracle_psi_momentum", "oracle_psi_scalar"):
+            getattr(lib, n).restype = C.c_double
+            getattr(lib, n).argtypes = [C.c_int, C.c_double]
+        lib.oracle_saturation_vapor_pressure_liquid.restype = C.c_double
+        lib.oracle_saturation_vapor_pressure_liquid.argtypes = [C.POINTER(abi.FluxParams), C.c_double]
+        lib.oracle_water_mole_fraction.restype = C.c_double
+        lib.oracle_water_mole_fraction.argtypes = [C.POINTER(abi.FluxParams), C.c_double]
+        lib.oracle_air_density.restype = C.c_double
+        lib.oracle_air_density.argtypes = [C.POINTER(abi.FluxParams)] + [C.c_double] * 3
+        lib.oracle_solve_cell.argtypes = ([C.POINTER(abi.FluxParams)] + [C.c_double] * 9 +
+                                          [C.c_int, C.POINTER(C.c_double)])
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a
+
+
+def make_grid(nx, ny, hx, hy, ring=1):
+    return abi.Grid(nx, ny, hx, hy, ring, 0)
+
+
+def _shape(g):
+    return (g.ny + 2 * g.hy, g.nx + 2 * g.hx)
+
+
+def _exchange_struct(d):
+    s = abi.ExchangeFields()
+    for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp"):
+        setattr(s, n, _ptr(d[n]))
+    return s
+
+
+def _ocean_struct(o, keep):
+    s = abi.OceanSurface()
+    for n in ("T", "S", "u", "v"):
+        a = _f64(o[n])
+        keep.append(a)
+        setattr(s, n, _ptr(a))
+    m = o.get("mask")
+    if m is not None:
+        m = np.ascontiguousarray(m)
+        keep.append(m)
+        s.mask = _ptr(m)
+    return s
+
+
+def _source_struct(src, level1, level2, tf, keep):
+    s = abi.AtmosSource()
+    first = None
+    for k, name in enumerate(abi.JRA55_VARIABLES):
+        a = np.ascontiguousarray(src[name], dtype=np.float32)
+        keep.append(a)
+        s.data[k] = a.ctypes.data
+        first = a
+    s.n_levels, s.ns_y, s.ns_x = first.shape
+    s.level1, s.level2, s.time_fraction = level1, level2, tf
+    return s
+
+
+def _weights_struct(w, keep):
+    s = abi.InterpWeights()
+    if w is None:
+        return s
+    s.separable = 1 if w.get("separable", True) else 0
+    for n in ("fi", "fj", "cos_rot", "sin_rot", "latitude"):
+        a = w.get(n)
+        if a is not None:
+            a = _f64(a)
+            keep.append(a)
+            setattr(s, n, _ptr(a))
+    return s
+
+
+def interpolate_atmosphere_state(g, src, weights, level1=0, level2=1, time_fraction=0.37):
+    lib, keep = load(), []
+    out = {n: np.zeros(_shape(g)) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
+    s = _source_struct(src, level1, level2, time_fraction, keep)
+    w = _weights_struct(weights, keep)
+    e = _exchange_struct(out)
+    rc = lib.oracle_interpolate_atmosphere_state(C.byref(g), C.byref(s), C.byref(w), C.byref(e))
+    assert rc == 0
+    return out
+
+
+def compute_atmosphere_ocean_fluxes(g, params, ocean, atmos, nthreads=1, scales=True):
+    lib, keep = load(), []
+    names = ["sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum", "temperature"]
+    if scales:
+        names += ["friction_velocity", "temperature_scale", "humidity_scale"]
+    out = {n: np.zeros(_shape(g)) for n in names}
+    if scales:
+        out["iterations"] = np.zeros(_shape(g), np.int32)
+    o = _ocean_struct(ocean, keep)
+    a = {n: _f64(atmos[n]) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp") if n in atmos}
+    for n in ("Qs", "Ql", "Mp"):
+        a.setdefault(n, np.zeros(_shape(g)))
+    e = _exchange_struct(a)
+    f = abi.InterfaceFluxes()
+    for n, arr in out.items():
+        setattr(f, n, _ptr(arr))
+    rc = lib.oracle_compute_atmosphere_ocean_fluxes(C.byref(g), C.byref(params), C.byref(o),
+                                                    C.byref(e), C.byref(f), nthreads)
+    assert rc == 0
+    return out
+
+
+def compute_net_ocean_fluxes(g, params, ocean, atmos, fluxes, ice=None, weights=None):
+    lib, keep = load(), []
+    names = ["u", "v", "T", "S", "shortwave_surface_flux", "upwelling_longwave",
+             "downwelling_longwave", "downwelling_shortwave"]
+    out = {n: np.zeros(_shape(g)) for n in names}
+    o = _ocean_struct(ocean, keep)
+    a = {n: _f64(atmos[n]) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
+    e = _exchange_struct(a)
+    f = abi.InterfaceFluxes()
+    for n in ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum", "temperature"):
+        arr = _f64(fluxes[n])
+        keep.append(arr)
+        setattr(f, n, _ptr(arr))
+    ice_s = None
+    if ice is not None:
+        ice_s = abi.SeaIceFields()
+        for n in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress"):
+            if ice.get(n) is not None:
+                arr = _f64(ice[n])
+                keep.append(arr)
+                setattr(ice_s, n, _ptr(arr))
+    w = _weights_struct(weights, keep)
+    nf = abi.NetOceanFluxes()
+    for n, arr in out.items():
+        setattr(nf, n, _ptr(arr))
+    rc = lib.oracle_compute_net_ocean_fluxes(C.byref(g), C.byref(params), C.byref(o), C.byref(e),
+                                             C.byref(f), C.byref(ice_s) if ice_s else None,
+                                             C.byref(w), C.byref(nf))
+    assert rc == 0
+    return out
+
+
+def solve_cell(params, ua, va, Ta, pa, qa, uo, vo, To, So, wet=1):
+    lib = load()
+    out = (C.c_double * 10)()
+    lib.oracle_solve_cell(C.byref(params), ua, va, Ta, pa, qa, uo, vo, To, So, wet, out)
+    keys = ("Qc", "Qv", "Fv", "rho_tau_x", "rho_tau_y", "Ts", "ustar", "theta_star", "q_star", "iterations")
+    return dict(zip(keys, list(out)))
+
+
+def max_threads():
+    return load().oracle_max_threads()
