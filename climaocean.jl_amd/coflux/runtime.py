@@ -1,0 +1,211 @@
+"""Thin runtime over the C ABI: a FluxContext owns one cf_ctx (one GPU), fields are torch CUDA
+tensors used purely as device-memory plumbing (their data_ptr() goes through the ABI).
+
+There is no CPU compute path here.  Creating a FluxContext without a GPU / without
+libcoflux.so raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+
+EXCHANGE_NAMES = ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")
+FLUX_NAMES = ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum", "temperature")
+FLUX_OPTIONAL = ("friction_velocity", "temperature_scale", "humidity_scale")
+NET_NAMES = ("u", "v", "T", "S", "shortwave_surface_flux", "upwelling_longwave",
+             "downwelling_longwave", "downwelling_shortwave")
+ICE_NAMES = ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")
+
+
+class CofluxError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class FluxContext:
+    """One libcoflux context bound to `device` (cuda:N)."""
+
+    def __init__(self, nx, ny, hx, hy, params, ring=1, device=0):
+        self.lib = abi.load_library()
+        if not torch.cuda.is_available():
+            raise CofluxError("coflux needs a HIP device (torch.cuda.is_available() is False); "
+                              "there is no CPU compute path")
+        self.device = torch.device("cuda", device)
+        self.grid = abi.Grid(nx, ny, hx, hy, ring, 0)
+        self.params = params
+        self.shape = (ny + 2 * hy, nx + 2 * hx)
+        self._h = C.c_void_p()
+        rc = self.lib.cf_create(C.byref(self._h), device, C.byref(self.grid), C.byref(params))
+        if rc != 0:
+            raise CofluxError(f"cf_create failed ({rc}): {self.lib.cf_last_error(None).decode()}")
+        self.use_torch_stream()
+
+    # -- lifecycle ----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.cf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CofluxError(f"{what} failed ({rc}): {self.lib.cf_last_error(self._h).decode()}")
+
+    def use_torch_stream(self):
+        """Order libcoflux launches on torch's current stream for this device."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.cf_set_stream(self._h, C.c_void_p(s)), "cf_set_stream")
+
+    def set_flux_params(self, params):
+        self._check(self.lib.cf_set_flux_params(self._h, C.byref(params)), "cf_set_flux_params")
+        self.params = params
+
+    def sync(self):
+        self._check(self.lib.cf_sync(self._h), "cf_sync")
+
+    # -- field helpers ------------------------------------------------------------------------
+    def zeros(self, dtype=torch.float64):
+        return torch.zeros(self.shape, dtype=dtype, device=self.device)
+
+    def to_device(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a)).to(self.device)
+
+    def field_set(self, names, optional=()):
+        d = {n: self.zeros() for n in names}
+        for n in optional:
+            d[n] = self.zeros()
+        return d
+
+    # -- struct builders ----------------------------------------------------------------------
+    @staticmethod
+    def _struct(cls, fields, names):
+        s = cls()
+        for n in names:
+            t = fields.get(n) if fields is not None else None
+            if t is not None:
+                assert t.is_cuda and t.is_contiguous(), n
+                setattr(s, n, t.data_ptr())
+        return s
+
+    def source_struct(self, src, level1, level2, time_fraction):
+        s = abi.AtmosSource()
+        shape = None
+        for k, name in enumerate(abi.JRA55_VARIABLES):
+            t = src[name]
+            assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), name
+            s.data[k] = t.data_ptr()
+            shape = t.shape
+        s.n_levels, s.ns_y, s.ns_x = shape
+        s.level1, s.level2, s.time_fraction = level1, level2, float(time_fraction)
+        return s
+
+    def weights_struct(self, w):
+        s = abi.InterpWeights()
+        if w is None:
+            return s
+        s.separable = 1 if w.get("separable", True) else 0
+        for n in ("fi", "fj", "cos_rot", "sin_rot", "latitude"):
+            t = w.get(n)
+            if t is not None:
+                assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous(), n
+                setattr(s, n, t.data_ptr())
+        return s
+
+    def ocean_struct(self, ocean):
+        return self._struct(abi.OceanSurface, ocean, ("T", "S", "u", "v", "mask"))
+
+    def exchange_struct(self, atmos):
+        return self._struct(abi.ExchangeFields, atmos, EXCHANGE_NAMES)
+
+    def fluxes_struct(self, fluxes):
+        return self._struct(abi.InterfaceFluxes, fluxes, FLUX_NAMES + FLUX_OPTIONAL + ("iterations",))
+
+    def ice_struct(self, ice):
+        return None if ice is None else self._struct(abi.SeaIceFields, ice, ICE_NAMES)
+
+    def net_struct(self, net):
+        return self._struct(abi.NetOceanFluxes, net, NET_NAMES)
+
+    # -- the hot path ---------------------------------------------------------------------------
+    def interpolate_atmosphere_state(self, src, weights, atmos, level1=0, level2=1, time_fraction=0.0):
+        s = self.source_struct(src, level1, level2, time_fraction)
+        w = self.weights_struct(weights)
+        e = self.exchange_struct(atmos)
+        self._check(self.lib.cf_interpolate_atmosphere_state(self._h, C.byref(s), C.byref(w), C.byref(e)),
+                    "cf_interpolate_atmosphere_state")
+
+    def compute_atmosphere_ocean_fluxes(self, ocean, atmos, fluxes):
+        o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
+        self._check(self.lib.cf_compute_atmosphere_ocean_fluxes(self._h, C.byref(o), C.byref(e), C.byref(f)),
+                    "cf_compute_atmosphere_ocean_fluxes")
+
+    def compute_net_ocean_fluxes(self, ocean, atmos, fluxes, net, ice=None, weights=None):
+        o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
+        i = self.ice_struct(ice)
+        w = self.weights_struct(weights)
+        n = self.net_struct(net)
+        self._check(self.lib.cf_compute_net_ocean_fluxes(self._h, C.byref(o), C.byref(e), C.byref(f),
+                                                         C.byref(i) if i is not None else None,
+                                                         C.byref(w), C.byref(n)),
+                    "cf_compute_net_ocean_fluxes")
+
+    def update_state(self, src, weights, ocean, atmos, fluxes, net, ice=None, level1=0, level2=1,
+                     time_fraction=0.0):
+        s = self.source_struct(src, level1, level2, time_fraction)
+        w = self.weights_struct(weights)
+        o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
+        i = self.ice_struct(ice)
+        n = self.net_struct(net)
+        self._check(self.lib.cf_update_state(self._h, C.byref(s), C.byref(w), C.byref(o), C.byref(e),
+                                             C.byref(f), C.byref(i) if i is not None else None, C.byref(n)),
+                    "cf_update_state")
+
+    def time_stage(self, stage, launches, *, src=None, weights=None, ocean=None, atmos=None, fluxes=None,
+                   net=None, ice=None, level1=0, level2=1, time_fraction=0.0):
+        """Average ms per launch of one stage, measured with HIP events on the launch stream."""
+        s = self.source_struct(src, level1, level2, time_fraction) if src is not None else abi.AtmosSource()
+        w = self.weights_struct(weights)
+        o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
+        i = self.ice_struct(ice)
+        n = self.net_struct(net)
+        ms = C.c_double()
+        self._check(self.lib.cf_time_stage(self._h, stage, launches, C.byref(s), C.byref(w), C.byref(o),
+                                           C.byref(e), C.byref(f), C.byref(i) if i is not None else None,
+                                           C.byref(n), C.byref(ms)), "cf_time_stage")
+        return ms.value
+
+    def time_copy(self, nbytes, launches=20):
+        a = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)
+        b = torch.empty_like(a)
+        ms = C.c_double()
+        self._check(self.lib.cf_time_copy(self._h, _ptr(b), _ptr(a), nbytes, launches, C.byref(ms)),
+                    "cf_time_copy")
+        return ms.value
+
+    # -- RCCL halo rows -------------------------------------------------------------------------
+    def comm_init(self, unique_id: bytes, rank, nranks):
+        buf = C.create_string_buffer(unique_id, abi.COMM_ID_BYTES)
+        self._check(self.lib.cf_comm_init(self._h, buf, rank, nranks), "cf_comm_init")
+
+    def halo_exchange_rows(self, tensors, rows=1):
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        self._check(self.lib.cf_halo_exchange_rows(self._h, arr, len(tensors), rows), "cf_halo_exchange_rows")
+
+
+def comm_unique_id():
+    lib = abi.load_library()
+    buf = C.create_string_buffer(abi.COMM_ID_BYTES)
+    rc = lib.cf_comm_unique_id(buf)
+    if rc != 0:
+        raise CofluxError(f"cf_comm_unique_id failed: {lib.cf_last_error(None).decode()}")
+    return buf.raw

@@ -1,0 +1,574 @@
+// coflux_abi.cpp — the C ABI of libcoflux (include/coflux.h): context, parameter lowering,
+// stream-ordered launches, HIP-event timing, and the RCCL latitude-slab halo exchange.
+// There is no CPU backend: every compute entry point launches gfx950 kernels or fails.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/coflux.h"
+#include "coflux_kernels.h"
+
+using namespace coflux;
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+struct cf_ctx {
+    int device = 0;
+    GridDesc grid{};
+    cf_flux_params params{};
+    DevParams dev{};
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int interp_cap = 256;  // floats per (variable, level) plane of the LDS-staged JRA55 tile
+    std::string error;
+    // RCCL
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+static thread_local std::string g_error;
+static RcclApi g_rccl;
+
+static int fail(cf_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    if (ctx) ctx->error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(ctx, CF_ERR_HIP, "%s:%d: %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static bool roughness_ok(const cf_roughness& r, bool scalar) {
+    if (scalar) {
+        if (r.kind == CF_SCALAR_ROUGHNESS_CONSTANT) return r.constant_length > 0;
+        if (r.kind == CF_SCALAR_ROUGHNESS_REYNOLDS) return r.maximum_length > 0 && r.reynolds_A > 0;
+        return false;
+    }
+    if (r.kind == CF_ROUGHNESS_CONSTANT) return r.constant_length > 0;
+    if (r.kind == CF_ROUGHNESS_CHARNOCK || r.kind == CF_ROUGHNESS_WIND_CHARNOCK) return r.maximum_length > 0;
+    return false;
+}
+
+static int lower_params(cf_ctx* ctx, const cf_flux_params* p, DevParams* d) {
+    if (!p) return fail(ctx, CF_ERR_INVALID, "flux params are NULL");
+    if (p->struct_size != (int32_t)sizeof(cf_flux_params))
+        return fail(ctx, CF_ERR_INVALID, "cf_flux_params.struct_size = %d, library expects %zu", p->struct_size,
+                    sizeof(cf_flux_params));
+    if (p->abi_version != CF_ABI_VERSION)
+        return fail(ctx, CF_ERR_INVALID, "cf_flux_params.abi_version = %d, library is %d", p->abi_version,
+                    CF_ABI_VERSION);
+    if (p->similarity_form < 0 || p->similarity_form > 1)
+        return fail(ctx, CF_ERR_INVALID, "Unknown similarity_form: %d", p->similarity_form);
+    if (p->stability_functions < 0 || p->stability_functions > 2)
+        return fail(ctx, CF_ERR_INVALID, "Unknown stability_functions: %d", p->stability_functions);
+    if (p->stop_kind < 0 || p->stop_kind > 1) return fail(ctx, CF_ERR_INVALID, "Unknown stop criteria: %d", p->stop_kind);
+    if (p->velocity_difference < 0 || p->velocity_difference > 1)
+        return fail(ctx, CF_ERR_INVALID, "Unknown velocity_formulation: %d. Options: relative(0), wind(1)",
+                    p->velocity_difference);
+    if (p->mask_kind < 0 || p->mask_kind > 2) return fail(ctx, CF_ERR_INVALID, "Unknown mask_kind: %d", p->mask_kind);
+    if (p->maxiter < 0) return fail(ctx, CF_ERR_INVALID, "maxiter must be >= 0");
+    if (!roughness_ok(p->momentum_roughness, false) || !roughness_ok(p->temperature_roughness, true) ||
+        !roughness_ok(p->water_vapor_roughness, true))
+        return fail(ctx, CF_ERR_INVALID, "invalid roughness-length block");
+    if (!(p->reference_height > 0) || !(p->von_karman > 0) || !(p->gravitational_acceleration > 0))
+        return fail(ctx, CF_ERR_INVALID, "reference_height, von_karman and gravitational_acceleration must be > 0");
+
+    const cf_thermodynamics& t = p->thermo;
+    DevParams D{};
+    D.R_d = t.gas_constant / t.dry_air_molar_mass;
+    D.R_v = t.gas_constant / t.water_molar_mass;
+    D.eps = t.dry_air_molar_mass / t.water_molar_mass;
+    D.delta = D.eps - 1.0;
+    D.cp_d = D.R_d / t.kappa_d;
+    D.cp_v = t.cp_v;
+    D.cp_l = t.cp_l;
+    D.cp_i = t.cp_i;
+    D.LH_v0 = t.LH_v0;
+    D.LH_s0 = t.LH_s0;
+    D.T_0 = t.T_0;
+    D.T_triple = t.T_triple;
+    D.inv_T_triple = 1.0 / t.T_triple;
+    D.p_triple = t.p_triple;
+    D.T_freeze = t.T_freeze;
+    D.T_icenuc = t.T_icenuc;
+    D.inv_icenuc_span = 1.0 / (t.T_freeze - t.T_icenuc);
+    D.pow_icenuc = t.pow_icenuc;
+    D.inv_R_v = 1.0 / D.R_v;
+    D.inv_R_d = 1.0 / D.R_d;
+    D.Rd_over_Rv = D.R_d / D.R_v;
+    const double dcp = t.cp_v - t.cp_l;
+    D.svp_a_liq = dcp / D.R_v;
+    D.svp_b_liq = (t.LH_v0 - dcp * t.T_0) / D.R_v;
+    D.sw_inv_w = 1.0 / p->seawater.water_molar_mass;
+    D.sw_inv_mu = 0.0;
+    for (int k = 0; k < 4; ++k)
+        D.sw_inv_mu += p->seawater.constituent_mass_fraction[k] / p->seawater.constituent_molar_mass[k];
+    D.kappa = p->von_karman;
+    D.beta_gust = p->gustiness_parameter;
+    D.min_gust = p->minimum_gustiness;
+    D.profile_floor = p->similarity_profile_floor;
+    D.tol = p->tolerance;
+    D.h_ref = p->reference_height;
+    D.h_bl = p->boundary_layer_height;
+    D.g = p->gravitational_acceleration;
+    D.inv_g = 1.0 / D.g;
+    D.log_h = std::log(D.h_ref);
+    D.similarity_form = p->similarity_form;
+    D.stability = p->stability_functions;
+    D.stop_kind = p->stop_kind;
+    D.maxiter = p->maxiter;
+    D.velocity_difference = p->velocity_difference;
+    D.mask_kind = p->mask_kind;
+    D.rm = p->momentum_roughness;
+    D.rt = p->temperature_roughness;
+    D.rq = p->water_vapor_roughness;
+    D.rho_o_inv = 1.0 / p->ocean_reference_density;
+    D.c_o_inv = 1.0 / p->ocean_heat_capacity;
+    D.rho_f_inv = 1.0 / p->ocean_freshwater_density;
+    D.T_offset = p->ocean_temperature_offset;
+    D.S_min = p->ocean_minimum_salinity;
+    D.z_surface = p->ocean_surface_z;
+    D.albedo = p->ocean_albedo;
+    D.albedo_diffuse = p->ocean_albedo_diffuse;
+    D.albedo_direct = p->ocean_albedo_direct;
+    D.emissivity = p->ocean_emissivity;
+    D.sigma = p->stefan_boltzmann;
+    D.albedo_kind = p->ocean_albedo_kind;
+    D.penetrating_sw = p->penetrating_shortwave;
+    *d = D;
+    return CF_OK;
+}
+
+extern "C" {
+
+int cf_version(void) { return CF_ABI_VERSION; }
+
+const char* cf_last_error(const cf_ctx* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+int cf_default_flux_params(cf_flux_params* p) {
+    if (!p) return fail(nullptr, CF_ERR_INVALID, "params is NULL");
+    std::memset(p, 0, sizeof *p);
+    p->struct_size = (int32_t)sizeof *p;
+    p->abi_version = CF_ABI_VERSION;
+    p->similarity_form = CF_SIMILARITY_LOGARITHMIC;
+    p->stability_functions = CF_STABILITY_EDSON2013;
+    p->stop_kind = CF_STOP_CONVERGENCE;
+    p->maxiter = 100;
+    p->velocity_difference = CF_VELOCITY_RELATIVE;
+    p->mask_kind = CF_MASK_U8;
+    p->tolerance = 1e-8;
+    p->von_karman = 0.4;
+    p->gustiness_parameter = 1.0;
+    p->minimum_gustiness = 0.2;
+    p->similarity_profile_floor = 1.0;
+    const double nu0 = 1.326e-5;
+    cf_roughness m{};
+    m.kind = CF_ROUGHNESS_CHARNOCK;
+    m.viscosity_kind = CF_VISCOSITY_TEMPERATURE_DEPENDENT;
+    m.maximum_length = 1.0;
+    m.charnock = 0.02; /* omip_simulation.jl:263 */
+    m.laminar = 0.11;
+    m.viscosity[0] = nu0;
+    m.viscosity[1] = nu0 * 6.542e-3;
+    m.viscosity[2] = nu0 * 8.301e-6;
+    m.viscosity[3] = -nu0 * 4.84e-9;
+    cf_roughness s = m;
+    s.kind = CF_SCALAR_ROUGHNESS_REYNOLDS;
+    s.maximum_length = 1.6e-4;
+    s.charnock = 0;
+    s.laminar = 0;
+    s.reynolds_A = 5.85e-5;
+    s.reynolds_b = 0.72;
+    p->momentum_roughness = m;
+    p->temperature_roughness = s;
+    p->water_vapor_roughness = s;
+    p->reference_height = 10.0;
+    p->boundary_layer_height = 600.0;
+    p->gravitational_acceleration = 9.81;
+    p->thermo = cf_thermodynamics{8.3144598, 0.02897, 0.018015, 2.0 / 7.0, 1859.0,  4181.0, 2100.0, 2500800.0,
+                                  2834400.0, 273.16,  273.16,   611.657,   273.15, 233.0,  1.0};
+    p->seawater.water_molar_mass = 18.02;
+    const double mm[4] = {35.45, 22.99, 96.06, 24.31}, mf[4] = {0.56, 0.31, 0.08, 0.05};
+    for (int k = 0; k < 4; ++k) {
+        p->seawater.constituent_molar_mass[k] = mm[k];
+        p->seawater.constituent_mass_fraction[k] = mf[k];
+    }
+    p->ocean_reference_density = 1026.0;
+    p->ocean_heat_capacity = 3991.86795711963;
+    p->ocean_freshwater_density = 1000.0;
+    p->ocean_temperature_offset = 273.15;
+    p->ocean_minimum_salinity = 0.0;
+    p->ocean_surface_z = -150.0;
+    p->ocean_albedo_kind = CF_ALBEDO_CONSTANT;
+    p->penetrating_shortwave = 1;
+    p->ocean_albedo = 0.06;
+    p->ocean_albedo_diffuse = 0.069;
+    p->ocean_albedo_direct = 0.011;
+    p->ocean_emissivity = 1.0;
+    p->stefan_boltzmann = 5.67e-8;
+    return CF_OK;
+}
+
+int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_params* params) {
+    if (!out || !grid) return fail(nullptr, CF_ERR_INVALID, "cf_create: NULL argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, CF_ERR_NODEVICE, "no HIP device available (%s); libcoflux has no CPU backend",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, CF_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    if (grid->nx <= 0 || grid->ny <= 0 || grid->hx < 0 || grid->hy < 0 || grid->ring < 0 || grid->ring > 1)
+        return fail(nullptr, CF_ERR_INVALID, "invalid grid: nx=%d ny=%d hx=%d hy=%d ring=%d", grid->nx, grid->ny,
+                    grid->hx, grid->hy, grid->ring);
+    if (grid->hx < grid->ring + 1 || grid->hy < grid->ring + 1)
+        return fail(nullptr, CF_ERR_INVALID, "halo (%d,%d) too small: need >= ring+1 = %d for the face stencils",
+                    grid->hx, grid->hy, grid->ring + 1);
+    cf_ctx* ctx = new cf_ctx();
+    ctx->device = device;
+    ctx->grid = GridDesc{grid->nx, grid->ny, grid->hx, grid->hy, grid->ring, grid->nx + 2 * grid->hx};
+    if (params) {
+        int rc = lower_params(ctx, params, &ctx->dev);
+        if (rc != CF_OK) {
+            g_error = ctx->error;
+            delete ctx;
+            return rc;
+        }
+        ctx->params = *params;
+    } else {
+        cf_default_flux_params(&ctx->params);
+        lower_params(ctx, &ctx->params, &ctx->dev);
+    }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, CF_ERR_HIP, "cannot create a stream on device %d", device);
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return CF_OK;
+}
+
+int cf_destroy(cf_ctx* ctx) {
+    if (!ctx) return CF_OK;
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    if (ctx->own_stream) {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->own_stream);
+        hipStreamDestroy(ctx->own_stream);
+    }
+    delete ctx;
+    return CF_OK;
+}
+
+int cf_set_flux_params(cf_ctx* ctx, const cf_flux_params* params) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    DevParams d;
+    int rc = lower_params(ctx, params, &d);
+    if (rc != CF_OK) return rc;
+    ctx->params = *params;
+    ctx->dev = d;
+    return CF_OK;
+}
+
+int cf_set_stream(cf_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return CF_OK;
+}
+
+int cf_sync(cf_ctx* ctx) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+
+void* cf_device_alloc(cf_ctx* ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    void* p = nullptr;
+    hipSetDevice(ctx->device);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        fail(ctx, CF_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+int cf_device_free(cf_ctx* ctx, void* d_ptr) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return CF_OK;
+}
+
+int cf_h2d(cf_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+
+int cf_d2h(cf_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CF_OK;
+}
+
+// ---- argument checks ------------------------------------------------------------------------
+static int check_source(cf_ctx* ctx, const cf_atmos_source* s) {
+    if (!s) return fail(ctx, CF_ERR_INVALID, "atmosphere source is NULL");
+    for (int v = 0; v < CF_JRA55_NVARS; ++v)
+        if (!s->data[v]) return fail(ctx, CF_ERR_INVALID, "atmosphere source variable %d is NULL", v);
+    if (s->ns_x <= 0 || s->ns_y <= 0 || s->n_levels <= 0) return fail(ctx, CF_ERR_INVALID, "invalid source shape");
+    if (s->level1 < 0 || s->level1 >= s->n_levels || s->level2 < 0 || s->level2 >= s->n_levels)
+        return fail(ctx, CF_ERR_INVALID, "time levels (%d,%d) outside the %d levels in memory", s->level1, s->level2,
+                    s->n_levels);
+    return CF_OK;
+}
+static int check_weights(cf_ctx* ctx, const cf_interp_weights* w) {
+    if (!w || !w->fi || !w->fj) return fail(ctx, CF_ERR_INVALID, "interpolation weights (fi, fj) are NULL");
+    if ((w->cos_rot == nullptr) != (w->sin_rot == nullptr))
+        return fail(ctx, CF_ERR_INVALID, "cos_rot and sin_rot must both be given or both be NULL");
+    return CF_OK;
+}
+static int check_exchange(cf_ctx* ctx, const cf_exchange_fields* e, bool all) {
+    if (!e || !e->u || !e->v || !e->T || !e->p || !e->q) return fail(ctx, CF_ERR_INVALID, "exchange fields u,v,T,p,q are NULL");
+    if (all && (!e->Qs || !e->Ql || !e->Mp)) return fail(ctx, CF_ERR_INVALID, "exchange fields Qs,Ql,Mp are NULL");
+    return CF_OK;
+}
+static int check_ocean(cf_ctx* ctx, const cf_ocean_surface* o) {
+    if (!o || !o->T || !o->S || !o->u || !o->v) return fail(ctx, CF_ERR_INVALID, "ocean surface fields are NULL");
+    if (ctx->dev.mask_kind != CF_MASK_NONE && !o->mask)
+        return fail(ctx, CF_ERR_INVALID, "mask_kind = %d but ocean mask is NULL", ctx->dev.mask_kind);
+    return CF_OK;
+}
+static int check_fluxes(cf_ctx* ctx, const cf_interface_fluxes* f) {
+    if (!f || !f->sensible_heat || !f->latent_heat || !f->water_vapor || !f->x_momentum || !f->y_momentum || !f->temperature)
+        return fail(ctx, CF_ERR_INVALID, "interface flux fields are NULL");
+    return CF_OK;
+}
+static int check_net(cf_ctx* ctx, const cf_net_ocean_fluxes* n, const cf_interp_weights* w) {
+    if (!n || !n->u || !n->v || !n->T || !n->S) return fail(ctx, CF_ERR_INVALID, "net ocean flux fields are NULL");
+    if (ctx->dev.albedo_kind == CF_ALBEDO_LATITUDE_DEPENDENT && (!w || !w->latitude))
+        return fail(ctx, CF_ERR_INVALID, "latitude-dependent albedo needs cf_interp_weights.latitude");
+    return CF_OK;
+}
+
+#define CHECK(call)            \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_ != CF_OK) return rc_; \
+    } while (0)
+
+int cf_interpolate_atmosphere_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
+                                    const cf_exchange_fields* out) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    CHECK(check_source(ctx, src));
+    CHECK(check_weights(ctx, w));
+    CHECK(check_exchange(ctx, out, true));
+    HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->grid, src, w, out, ctx->interp_cap));
+    return CF_OK;
+}
+
+int cf_compute_atmosphere_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
+                                       const cf_interface_fluxes* out) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    CHECK(check_ocean(ctx, ocean));
+    CHECK(check_exchange(ctx, atmos, false));
+    CHECK(check_fluxes(ctx, out));
+    HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, out));
+    return CF_OK;
+}
+
+int cf_compute_net_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
+                                const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice,
+                                const cf_interp_weights* w, const cf_net_ocean_fluxes* out) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    CHECK(check_ocean(ctx, ocean));
+    CHECK(check_exchange(ctx, atmos, true));
+    CHECK(check_fluxes(ctx, fluxes));
+    CHECK(check_net(ctx, out, w));
+    HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, out));
+    return CF_OK;
+}
+
+int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
+                    const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
+                    const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    CHECK(check_source(ctx, src));
+    CHECK(check_weights(ctx, w));
+    CHECK(check_ocean(ctx, ocean));
+    CHECK(check_exchange(ctx, atmos, true));
+    CHECK(check_fluxes(ctx, fluxes));
+    CHECK(check_net(ctx, net, w));
+    HIP_TRY(ctx, launch_fused(ctx->stream, ctx->dev, ctx->grid, src, w, ocean, atmos, fluxes, ctx->interp_cap));
+    HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net));
+    return CF_OK;
+}
+
+static int run_stage(cf_ctx* ctx, int stage, const cf_atmos_source* src, const cf_interp_weights* w,
+                     const cf_ocean_surface* ocean, const cf_exchange_fields* atmos, const cf_interface_fluxes* fluxes,
+                     const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net) {
+    switch (stage) {
+        case CF_STAGE_INTERPOLATE: return cf_interpolate_atmosphere_state(ctx, src, w, atmos);
+        case CF_STAGE_AO_FLUXES: return cf_compute_atmosphere_ocean_fluxes(ctx, ocean, atmos, fluxes);
+        case CF_STAGE_NET_FLUXES: return cf_compute_net_ocean_fluxes(ctx, ocean, atmos, fluxes, ice, w, net);
+        case CF_STAGE_UPDATE_STATE: return cf_update_state(ctx, src, w, ocean, atmos, fluxes, ice, net);
+        default: return fail(ctx, CF_ERR_INVALID, "unknown stage %d", stage);
+    }
+}
+
+int cf_time_stage(cf_ctx* ctx, int stage, int launches, const cf_atmos_source* src, const cf_interp_weights* w,
+                  const cf_ocean_surface* ocean, const cf_exchange_fields* atmos, const cf_interface_fluxes* fluxes,
+                  const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, double* ms_per_launch) {
+    if (!ctx || !ms_per_launch || launches <= 0) return fail(ctx, CF_ERR_INVALID, "cf_time_stage: bad arguments");
+    hipEvent_t t0, t1;
+    HIP_TRY(ctx, hipEventCreate(&t0));
+    HIP_TRY(ctx, hipEventCreate(&t1));
+    CHECK(run_stage(ctx, stage, src, w, ocean, atmos, fluxes, ice, net));  // one untimed launch (code load)
+    HIP_TRY(ctx, hipEventRecord(t0, ctx->stream));
+    for (int n = 0; n < launches; ++n) CHECK(run_stage(ctx, stage, src, w, ocean, atmos, fluxes, ice, net));
+    HIP_TRY(ctx, hipEventRecord(t1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(t1));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, t0, t1));
+    hipEventDestroy(t0);
+    hipEventDestroy(t1);
+    *ms_per_launch = (double)ms / launches;
+    return CF_OK;
+}
+
+int cf_time_copy(cf_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int launches, double* ms_per_launch) {
+    if (!ctx || !ms_per_launch || launches <= 0 || !d_dst || !d_src)
+        return fail(ctx, CF_ERR_INVALID, "cf_time_copy: bad arguments");
+    hipEvent_t t0, t1;
+    HIP_TRY(ctx, hipEventCreate(&t0));
+    HIP_TRY(ctx, hipEventCreate(&t1));
+    HIP_TRY(ctx, launch_copy(ctx->stream, d_dst, d_src, bytes));
+    HIP_TRY(ctx, hipEventRecord(t0, ctx->stream));
+    for (int n = 0; n < launches; ++n) HIP_TRY(ctx, launch_copy(ctx->stream, d_dst, d_src, bytes));
+    HIP_TRY(ctx, hipEventRecord(t1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(t1));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, t0, t1));
+    hipEventDestroy(t0);
+    hipEventDestroy(t1);
+    *ms_per_launch = (double)ms / launches;
+    return CF_OK;
+}
+
+// ---- RCCL halo rows ---------------------------------------------------------------------------
+static int load_rccl(cf_ctx* ctx) {
+    if (g_rccl.handle) return CF_OK;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail(ctx, CF_ERR_COMM, "cannot dlopen librccl.so: %s", dlerror());
+#define SYM(field, name)                                                     \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(h, name);                   \
+    if (!g_rccl.field) return fail(ctx, CF_ERR_COMM, "librccl lacks %s", name);
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.handle = h;
+    return CF_OK;
+}
+
+#define NCCL_TRY(ctx, expr)                                                                            \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess)                                                                         \
+            return fail(ctx, CF_ERR_COMM, "%s:%d: %s: %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+int cf_comm_unique_id(void* id128) {
+    if (!id128) return fail(nullptr, CF_ERR_INVALID, "id buffer is NULL");
+    static_assert(sizeof(ncclUniqueId) == CF_COMM_ID_BYTES, "ncclUniqueId size");
+    CHECK(load_rccl(nullptr));
+    NCCL_TRY(nullptr, g_rccl.GetUniqueId((ncclUniqueId*)id128));
+    return CF_OK;
+}
+
+int cf_comm_init(cf_ctx* ctx, const void* id128, int rank, int nranks) {
+    if (!ctx || !id128 || nranks <= 0 || rank < 0 || rank >= nranks)
+        return fail(ctx, CF_ERR_INVALID, "cf_comm_init: bad arguments");
+    CHECK(load_rccl(ctx));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    NCCL_TRY(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, id, rank));
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return CF_OK;
+}
+
+int cf_comm_destroy(cf_ctx* ctx) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    if (ctx->comm) {
+        NCCL_TRY(ctx, g_rccl.CommDestroy(ctx->comm));
+        ctx->comm = nullptr;
+    }
+    return CF_OK;
+}
+
+int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int rows) {
+    if (!ctx || !d_fields || nfields <= 0) return fail(ctx, CF_ERR_INVALID, "cf_halo_exchange_rows: bad arguments");
+    if (!ctx->comm) return fail(ctx, CF_ERR_COMM, "cf_comm_init has not been called");
+    const GridDesc& G = ctx->grid;
+    if (rows <= 0 || rows > G.hy || rows > G.ny) return fail(ctx, CF_ERR_INVALID, "rows = %d outside [1, min(hy, ny)]", rows);
+    const size_t count = (size_t)rows * G.sj;  // whole rows, x-halos included
+    const int south = ctx->rank - 1, north = ctx->rank + 1;
+    NCCL_TRY(ctx, g_rccl.GroupStart());
+    for (int f = 0; f < nfields; ++f) {
+        double* base = d_fields[f];
+        double* first_interior = base + (size_t)G.hy * G.sj;
+        double* last_interior = base + (size_t)(G.hy + G.ny - rows) * G.sj;
+        double* south_halo = base + (size_t)(G.hy - rows) * G.sj;
+        double* north_halo = base + (size_t)(G.hy + G.ny) * G.sj;
+        if (south >= 0) {
+            NCCL_TRY(ctx, g_rccl.Send(first_interior, count, ncclFloat64, south, ctx->comm, ctx->stream));
+            NCCL_TRY(ctx, g_rccl.Recv(south_halo, count, ncclFloat64, south, ctx->comm, ctx->stream));
+        }
+        if (north < ctx->nranks) {
+            NCCL_TRY(ctx, g_rccl.Send(last_interior, count, ncclFloat64, north, ctx->comm, ctx->stream));
+            NCCL_TRY(ctx, g_rccl.Recv(north_halo, count, ncclFloat64, north, ctx->comm, ctx->stream));
+        }
+    }
+    NCCL_TRY(ctx, g_rccl.GroupEnd());
+    return CF_OK;
+}
+
+}  // extern "C"

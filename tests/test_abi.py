@@ -1,0 +1,80 @@
+"""CPU-side checks of the drop-in boundary: libcoflux.so loads, exports every symbol that
+include/coflux.h declares, agrees with the ctypes mirror on struct sizes, and refuses to run
+without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from coflux import abi
+from coflux import interface_computations as ic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "coflux.h")).read()
+    return set(re.findall(r"\b(cf_[a-z0-9_]+)\s*\(", text))
+
+
+def test_header_and_mirror_list_the_same_symbols():
+    assert _header_symbols() == set(abi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = abi.load_library()
+    for name in _header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.cf_version() == abi.ABI_VERSION
+
+
+def test_struct_layout_matches_library():
+    lib = abi.load_library()
+    p = abi.FluxParams()
+    assert lib.cf_default_flux_params(C.byref(p)) == 0
+    assert p.struct_size == C.sizeof(abi.FluxParams)
+    # the library's ":default" block equals the Python mirror's defaults field by field
+    q = ic.flux_params()
+    for name, _ in abi.FluxParams._fields_:
+        a, b = getattr(p, name), getattr(q, name)
+        if isinstance(a, C.Structure):
+            assert bytes(a) == bytes(b), name
+        else:
+            assert a == b, name
+
+
+def test_presets_lower_to_valid_blocks():
+    for make in (ic.corrected_atmosphere_ocean_fluxes, ic.corrected_atmosphere_sea_ice_fluxes,
+                 ic.ncar_atmosphere_sea_ice_fluxes):
+        p = ic.flux_params(make(), velocity_difference=ic.WindVelocity())
+        assert p.velocity_difference == abi.VELOCITY_WIND
+        assert p.similarity_form == abi.SIMILARITY_COARE_LOGARITHMIC  # omip_simulation.jl:43,65,108
+    p = ic.flux_params(ic.corrected_atmosphere_ocean_fluxes())
+    assert p.momentum_roughness.kind == abi.ROUGHNESS_WIND_CHARNOCK and p.minimum_gustiness == 0.5
+    p = ic.flux_params(ic.corrected_atmosphere_sea_ice_fluxes())
+    assert (p.momentum_roughness.constant_length, p.temperature_roughness.constant_length) == (5e-4, 5e-5)
+    assert p.stability_functions == abi.STABILITY_SHEBA and p.minimum_gustiness == 0.2
+    p = ic.flux_params(ic.ncar_atmosphere_sea_ice_fluxes())
+    assert p.gustiness_parameter == 0.0 and p.stability_functions == abi.STABILITY_LARGE_YEAGER
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = abi.load_library()
+    h = C.c_void_p()
+    g = abi.Grid(8, 8, 2, 2, 1, 0)
+    p = ic.flux_params()
+    rc = lib.cf_create(C.byref(h), 0, C.byref(g), C.byref(p))
+    assert rc == -3 and not h.value
+    assert b"no CPU backend" in lib.cf_last_error(None)
+    from coflux.runtime import CofluxError, FluxContext
+    with pytest.raises(CofluxError):
+        FluxContext(8, 8, 2, 2, p)
+
+
+def test_missing_library_is_loud(tmp_path):
+    with pytest.raises(abi.CofluxLibraryMissing):
+        abi.load_library(str(tmp_path / "libcoflux.so"))

@@ -1,0 +1,175 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerance (north_star): all six flux fields within 1e-6 relative of the CPU reference.  We use
+|Δ| ≤ TOL · max(|ref|, field scale) with the scales in tests/util.py and TOL = 1e-9 for the
+faithful solver (three orders tighter than required); the interpolation and the net-flux
+assembly are held to 1e-12.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+import util
+from coflux import abi
+from coflux import interface_computations as ic
+from coflux.runtime import FLUX_NAMES, FLUX_OPTIONAL, NET_NAMES, EXCHANGE_NAMES, FluxContext
+
+pytestmark = pytest.mark.gpu
+
+TOL_SOLVER = 1e-9
+TOL_LINEAR = 1e-12
+
+
+def run_gpu(case, params, *, ring=1, fused=False, ice=False, time_fraction=0.37, level1=0, level2=1):
+    nx, ny, hx, hy = case["nx"], case["ny"], case["hx"], case["hy"]
+    ctx = FluxContext(nx, ny, hx, hy, params, ring=ring)
+    dev = ctx.to_device
+    ocean = {k: dev(case["ocean"][k]) for k in ("T", "S", "u", "v", "mask")}
+    src = {k: dev(v) for k, v in case["src"].items()}
+    w = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in case["weights"].items()}
+    icef = {k: dev(v) for k, v in case["ice"].items()} if ice else None
+    atmos = ctx.field_set(EXCHANGE_NAMES)
+    fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL)
+    fluxes["iterations"] = ctx.zeros(torch.int32)
+    net = ctx.field_set(NET_NAMES)
+    if fused:
+        ctx.update_state(src, w, ocean, atmos, fluxes, net, ice=icef, level1=level1, level2=level2,
+                         time_fraction=time_fraction)
+    else:
+        ctx.interpolate_atmosphere_state(src, w, atmos, level1, level2, time_fraction)
+        ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
+        ctx.compute_net_ocean_fluxes(ocean, atmos, fluxes, net, ice=icef, weights=w)
+    ctx.sync()
+    torch.cuda.synchronize()
+    out = dict(atmos={k: v.cpu().numpy() for k, v in atmos.items()},
+               fluxes={k: v.cpu().numpy() for k, v in fluxes.items()},
+               net={k: v.cpu().numpy() for k, v in net.items()})
+    ctx.close()
+    return out
+
+
+def run_oracle(case, params, *, ring=1, ice=False, time_fraction=0.37, level1=0, level2=1):
+    g = orc.make_grid(case["nx"], case["ny"], case["hx"], case["hy"], ring)
+    atmos = orc.interpolate_atmosphere_state(g, case["src"], case["weights"], level1, level2, time_fraction)
+    fluxes = orc.compute_atmosphere_ocean_fluxes(g, params, case["ocean"], atmos, nthreads=0)
+    net = orc.compute_net_ocean_fluxes(g, params, case["ocean"], atmos, fluxes, ice=case["ice"] if ice else None,
+                                       weights=case["weights"])
+    return dict(atmos=atmos, fluxes=fluxes, net=net)
+
+
+def compare(case, got, ref, ring, tol_solver=TOL_SOLVER):
+    nx, ny, hx, hy = case["nx"], case["ny"], case["hx"], case["hy"]
+    worst = {}
+    for k in EXCHANGE_NAMES:
+        e = util.rel_err(util.window(got["atmos"][k], hx, hy, nx, ny, ring),
+                         util.window(ref["atmos"][k], hx, hy, nx, ny, ring), util.ATMOS_SCALE[k])
+        worst["atmos." + k] = e
+        assert e <= TOL_LINEAR, (k, e)
+    for k in FLUX_NAMES + FLUX_OPTIONAL:
+        e = util.rel_err(util.window(got["fluxes"][k], hx, hy, nx, ny, ring),
+                         util.window(ref["fluxes"][k], hx, hy, nx, ny, ring), util.FIELD_SCALE[k])
+        worst["fluxes." + k] = e
+        assert e <= tol_solver, (k, e)
+    for k in NET_NAMES:
+        e = util.rel_err(util.window(got["net"][k], hx, hy, nx, ny, 0),
+                         util.window(ref["net"][k], hx, hy, nx, ny, 0), util.FIELD_SCALE[k])
+        worst["net." + k] = e
+        assert e <= tol_solver, (k, e)
+    return worst
+
+
+@pytest.mark.parametrize("config", list(util.CONFIGS))
+def test_config1_plumbing_90x40_all_formulations(config):
+    """BASELINE config 1 shape (4° 90×40) through every flux formulation the reference tree
+    configures (omip_simulation.jl:40-113)."""
+    fluxes, vd = util.CONFIGS[config]()
+    params = ic.flux_params(fluxes, velocity_difference=vd)
+    case = util.build_case(90, 40)
+    got = run_gpu(case, params)
+    ref = run_oracle(case, params)
+    compare(case, got, ref, 1)
+    it_g = util.window(got["fluxes"]["iterations"], 3, 3, 90, 40, 1)
+    it_r = util.window(ref["fluxes"]["iterations"], 3, 3, 90, 40, 1)
+    # identical trip counts except where the drift sits within rounding of the tolerance
+    assert np.mean(it_g != it_r) < 0.01
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_quarter_degree_tile_with_sea_ice(fused):
+    """A 360×140 slab of the 1/4° problem with ℵ-weighted partition (BASELINE config 3), halo 7,
+    latitude-dependent albedo, emissivity 0.97, minimum salinity, SW into JT."""
+    params = ic.flux_params(ocean_surface=ic.SurfaceRadiationProperties(ic.LatitudeDependentAlbedo(), 0.97),
+                            ocean_minimum_salinity=34.0, penetrating_shortwave=False)
+    case = util.build_case(360, 140, 7, 7, ny_global=560, j_offset=400)
+    got = run_gpu(case, params, fused=fused, ice=True)
+    ref = run_oracle(case, params, ice=True)
+    compare(case, got, ref, 1)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_tripolar_like_general_weights_and_rotation(fused):
+    """General 2-D fractional indices + vector rotation (BASELINE config 4 shape 360×180, halo 5)."""
+    params = ic.flux_params(ic.corrected_atmosphere_ocean_fluxes())
+    case = util.build_case(360, 180, 5, 5, weights="tripolar")
+    got = run_gpu(case, params, fused=fused)
+    ref = run_oracle(case, params)
+    compare(case, got, ref, 1)
+
+
+def test_ring0_and_ragged_sizes():
+    """Sizes that are not multiples of the 64×4 tile / 256-thread block; ring = 0."""
+    params = ic.flux_params()
+    for (nx, ny) in [(1, 1), (7, 3), (65, 5), (130, 9)]:
+        case = util.build_case(nx, ny, 2, 2)
+        for fused in (False, True):
+            got = run_gpu(case, params, ring=0, fused=fused)
+            ref = run_oracle(case, params, ring=0)
+            # ring 0: the face averages at i=0 / j=0 read flux halos that nobody computed (zeros in both)
+            compare(case, got, ref, 0)
+
+
+def test_all_land_and_all_ocean():
+    params = ic.flux_params()
+    case = util.build_case(64, 8, land=False)
+    compare(case, run_gpu(case, params), run_oracle(case, params), 1)
+    case["ocean"]["mask"][:] = 0
+    got = run_gpu(case, params)
+    compare(case, got, run_oracle(case, params), 1)
+    for k in ("sensible_heat", "latent_heat", "x_momentum"):
+        assert not np.any(util.window(got["fluxes"][k], 3, 3, 64, 8, 1))
+
+
+def test_time_interpolation_endpoints_and_window_levels():
+    """ñ = 0 returns snapshot n₁, and any two levels of a longer in-memory window can be blended."""
+    params = ic.flux_params()
+    case = util.build_case(90, 40, n_levels=4)
+    got = run_gpu(case, params, time_fraction=0.0, level1=2, level2=3)
+    ref = run_oracle(case, params, time_fraction=0.0, level1=2, level2=3)
+    compare(case, got, ref, 1)
+    got2 = run_gpu(case, params, time_fraction=0.0, level1=2, level2=0)
+    for k in EXCHANGE_NAMES:
+        np.testing.assert_array_equal(got["atmos"][k], got2["atmos"][k])
+
+
+def test_bottom_height_mask_encoding():
+    params = ic.flux_params(mask_kind=abi.MASK_BOTTOM_HEIGHT)
+    case = util.build_case(90, 40)
+    wet = case["ocean"]["mask"] != 0
+    case["ocean"]["mask"] = np.where(wet, -3000.0, 10.0)  # bottom height: land where z_surface <= zb
+    compare(case, run_gpu(case, params), run_oracle(case, params), 1)
+
+
+def test_invalid_arguments_are_reported():
+    from coflux.runtime import CofluxError
+    params = ic.flux_params()
+    with pytest.raises(CofluxError):
+        FluxContext(16, 16, 1, 1, params, ring=1)  # halo too small for the face stencil
+    bad = ic.flux_params()
+    bad.velocity_difference = 7
+    with pytest.raises(CofluxError, match="velocity_formulation"):
+        FluxContext(16, 16, 2, 2, bad)
+    ctx = FluxContext(16, 16, 2, 2, params)
+    with pytest.raises(CofluxError, match="NULL"):
+        ctx.compute_atmosphere_ocean_fluxes({}, {}, {})
+    ctx.close()
