@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py — surface-flux hot path throughput on MI355X (BASELINE.json metric).
+
+A "step" is one update_state! of the coupled model's flux path over one synthetic surface:
+(N>1: one-row halo exchange of the ocean surface state over RCCL) → fused JRA55
+interpolation + Monin–Obukhov solve → net ocean fluxes, all through the C ABI (libcoflux.so).
+Workload at N = 1 is BASELINE.json configs[1]: the 1/4° 1440×560 surface, JRA55 atmosphere,
+SimilarityTheory fluxes + Radiation, Float64, inputs resident in HBM before the timed region.
+At N > 1 every rank owns one 1440×560 latitude slab of a 1440×(560·N) surface (weak scaling);
+`--scaling strong` shards the fixed 1440×560 surface instead.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "climaocean.jl_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from coflux import abi, synthetic as syn  # noqa: E402
+from coflux import interface_computations as ic  # noqa: E402
+from coflux.distributed import SlabHaloExchanger, slab_bounds  # noqa: E402
+from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, NET_NAMES, FluxContext  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Algorithmic bytes per surface cell (derivation in DESIGN.md §4)
+BYTES_AO = 128.0                       # compute_atmosphere_ocean_fluxes!: 80 read + 48 written
+BYTES_INTERP = 18.3 + 64.0             # JRA55 window amortised + 8 exchange fields written
+BYTES_FUSED = BYTES_INTERP + BYTES_AO - 40.0   # the 5 atmosphere fields never round-trip through HBM
+BYTES_NET = 88.0 + 40.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nx", type=int, default=1440)
+    ap.add_argument("--ny", type=int, default=560)
+    ap.add_argument("--halo", type=int, default=7)  # README.md:58 halo=(7,7,7)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--halo-backend", choices=("rccl", "torch"), default="rccl")
+    ap.add_argument("--flux-configuration", choices=("default", "corrected"), default="default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-repeats", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(case_np, params, nx, ny, h, repeats):
+    """The CPU oracle (C restatement, OpenMP over rows) timed on this box's host cores on the same
+    workload: `repeats` full passes of interpolate + solver + net fluxes over the rank-0 slab."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    g = orc.make_grid(nx, ny, h, h, 1)
+    cores = orc.max_threads()
+    t_best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        atmos = orc.interpolate_atmosphere_state(g, case_np["src"], case_np["weights"], 0, 1, 0.37)
+        fl = orc.compute_atmosphere_ocean_fluxes(g, params, case_np["ocean"], atmos, nthreads=0, scales=False)
+        orc.compute_net_ocean_fluxes(g, params, case_np["ocean"], atmos, fl, weights=case_np["weights"])
+        dt = time.perf_counter() - t0
+        t_best = dt if t_best is None else min(t_best, dt)
+    return dict(value=nx * ny / t_best, unit="cells/s", cores=cores, kind="port",
+                sample=f"{repeats} full update_state passes over the {nx}x{ny} surface (best of {repeats}); "
+                       "oracle/coflux_oracle.c, OpenMP over rows")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the flux path has no CPU backend")
+    torch.cuda.set_device(local_rank)
+
+    h = a.halo
+    if a.scaling == "weak":
+        ny_global, (j0, j1) = a.ny * world, (rank * a.ny, (rank + 1) * a.ny)
+    else:
+        ny_global = a.ny
+        j0, j1 = slab_bounds(a.ny, rank, world)
+    nx, ny = a.nx, j1 - j0
+
+    fluxes_cfg = ic.SimilarityTheoryFluxes() if a.flux_configuration == "default" else ic.corrected_atmosphere_ocean_fluxes()
+    params = ic.flux_params(fluxes_cfg, ocean_surface=ic.SurfaceRadiationProperties(0.06, 1.0))
+
+    # ---- synthetic inputs, resident in HBM before the timed region ---------------------------------
+    ocean_np = syn.ocean_state(nx, ny, h, h, ny_global=ny_global, j_offset=j0)
+    src_np = syn.jra55_snapshots(2)
+    fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h, ny_global=ny_global, j_offset=j0)
+    w_np = dict(separable=True, fi=fi, fj=fj, latitude=phi)
+
+    ctx = FluxContext(nx, ny, h, h, params, ring=1, device=local_rank)
+    ocean = {k: ctx.to_device(ocean_np[k]) for k in ("T", "S", "u", "v", "mask")}
+    src = {k: ctx.to_device(v) for k, v in src_np.items()}
+    w = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj), latitude=ctx.to_device(phi))
+    atmos = ctx.field_set(EXCHANGE_NAMES)
+    fl = ctx.field_set(FLUX_NAMES)
+    net = ctx.field_set(NET_NAMES)
+    halo = SlabHaloExchanger(ctx, ny, h, rows=1, backend=a.halo_backend)
+    halo_fields = [ocean[k] for k in ("T", "S", "u", "v")]
+
+    def step():
+        halo(halo_fields)
+        ctx.update_state(src, w, ocean, atmos, fl, net, time_fraction=0.37)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    ctx.profile_enable(min(a.steps, 4096))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cells_total = nx * (ny_global if a.scaling == "weak" else a.ny) if world > 1 else nx * ny
+    cells_rank = (nx + 2) * (ny + 2)  # launch covers the ring as the reference does
+    value = cells_total * a.steps / elapsed
+
+    if rank == 0:
+        fused_ms, nrec = ctx.profile_read(0)  # kernel 0 = fused interpolate+solver
+        net_ms, _ = ctx.profile_read(1)
+        # stand-alone stages, HIP events on the launch stream (outside the timed region)
+        ao_ms = ctx.time_stage(abi.STAGE_AO_FLUXES, 20, ocean=ocean, atmos=atmos, fluxes=fl)
+        interp_ms = ctx.time_stage(abi.STAGE_INTERPOLATE, 20, src=src, weights=w, atmos=atmos, time_fraction=0.37)
+        copy_bytes = 256 << 20
+        copy_ms = ctx.time_copy(copy_bytes, 20)
+        achieved = BYTES_FUSED * cells_rank / (fused_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel="fused_interp_flux_kernel", achieved=achieved, peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                        bytes_per_cell=BYTES_FUSED, cells_per_launch=cells_rank, avg_launch_ms=fused_ms,
+                        launches_timed=nrec)
+        ao_achieved = BYTES_AO * cells_rank / (ao_ms * 1e-3) / 1e9
+        out = dict(metric="flux-kernel surface cells/s (update_state!: JRA55 interp + similarity-theory fluxes + net fluxes)",
+                   value=value, unit="cells/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling=a.scaling,
+                   vs_baseline=None, dtype="f64", data="synthetic",
+                   config=dict(workload=f"1/4-degree LatitudeLongitudeGrid surface {nx}x{a.ny} per "
+                                        f"{'GPU' if a.scaling == 'weak' else 'job'}, JRA55 640x320 f32 atmosphere, "
+                                        f"SimilarityTheoryFluxes(:{a.flux_configuration}) + Radiation, halo {h}, ring 1",
+                               global_cells=cells_total, parallelism=f"latitude-slab x{world}",
+                               halo_backend=halo.backend),
+                   roofline=roofline,
+                   roofline_ao_fluxes=dict(bound="hbm", kernel="ao_flux_kernel (compute_atmosphere_ocean_fluxes! alone)",
+                                           achieved=ao_achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                                           frac=ao_achieved / HBM_PEAK_GBS, traffic=None, bytes_per_cell=BYTES_AO,
+                                           avg_launch_ms=ao_ms, cells_per_s=cells_rank / (ao_ms * 1e-3)),
+                   stages_ms=dict(fused_interp_flux=fused_ms, net_fluxes=net_ms, ao_fluxes_alone=ao_ms,
+                                  interpolate_alone=interp_ms),
+                   device_copy_GBs=2 * copy_bytes / (copy_ms * 1e-3) / 1e9,
+                   parity="vs reference: unpinned (self-consistent restatements only; see DESIGN.md)")
+        if not a.no_cpu_baseline:
+            case_np = dict(ocean=ocean_np, src=src_np, weights=w_np)
+            out["cpu_baseline"] = cpu_baseline(case_np, params, nx, ny, h, a.cpu_repeats)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,8 @@ STOP_CONVERGENCE, STOP_FIXED = 0, 1
 VELOCITY_RELATIVE, VELOCITY_WIND = 0, 1
 MASK_NONE, MASK_U8, MASK_BOTTOM_HEIGHT = 0, 1, 2
 ALBEDO_CONSTANT, ALBEDO_LATITUDE_DEPENDENT = 0, 1
+OPT_SOLVER, OPT_INTERP_TILE_CAP, OPT_MAX_BLOCKS = 0, 1, 2
+SOLVER_TABLES, SOLVER_LIBM = 0, 1
 STAGE_INTERPOLATE, STAGE_AO_FLUXES, STAGE_NET_FLUXES, STAGE_UPDATE_STATE = 0, 1, 2, 3
 
 JRA55_VARIABLES = ("tas", "huss", "psl", "uas", "vas", "rlds", "rsds", "prra", "prsn")
@@ -124,11 +126,11 @@ class InterpWeights(C.Structure):
 # Every symbol include/coflux.h declares (tests check they are all exported).
 EXPORTED_SYMBOLS = (
     "cf_version", "cf_default_flux_params", "cf_create", "cf_destroy", "cf_last_error",
-    "cf_set_flux_params", "cf_set_stream", "cf_sync",
+    "cf_set_flux_params", "cf_set_stream", "cf_set_option", "cf_debug_eval", "cf_sync",
     "cf_device_alloc", "cf_device_free", "cf_h2d", "cf_d2h",
     "cf_interpolate_atmosphere_state", "cf_compute_atmosphere_ocean_fluxes",
     "cf_compute_net_ocean_fluxes", "cf_update_state",
-    "cf_time_stage", "cf_time_copy",
+    "cf_time_stage", "cf_time_copy", "cf_profile_enable", "cf_profile_read",
     "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
 )
 
@@ -163,6 +165,8 @@ def load_library(path=None):
     lib.cf_last_error.restype = C.c_char_p
     lib.cf_set_flux_params.argtypes = [vp, C.POINTER(FluxParams)]
     lib.cf_set_stream.argtypes = [vp, vp]
+    lib.cf_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.cf_debug_eval.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     lib.cf_sync.argtypes = [vp]
     lib.cf_device_alloc.argtypes = [vp, C.c_size_t]
     lib.cf_device_alloc.restype = vp
@@ -185,6 +189,8 @@ def load_library(path=None):
         C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes),
         C.POINTER(SeaIceFields), C.POINTER(NetOceanFluxes), C.POINTER(C.c_double)]
     lib.cf_time_copy.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    lib.cf_profile_enable.argtypes = [vp, C.c_int]
+    lib.cf_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.cf_comm_unique_id.argtypes = [vp]
     lib.cf_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.cf_comm_destroy.argtypes = [vp]

@@ -1,0 +1,75 @@
+"""Latitude-slab sharding of the surface grid (the reference's own production
+shapes are Partition(1,4) launch.sh:165 and Partition(1,8) pbs_launch.sh:51: contiguous j-slabs,
+one rank per GPU).
+
+The flux kernels need one halo row of the ocean surface state from each neighbour
+(v[j+1] north; the ring row south/north when ring = 1).  On GPUs the rows travel over
+RCCL/xGMI through libcoflux's cf_halo_exchange_rows; the torch.distributed point-to-point form
+below is the same exchange for CPU tensors (gloo) and is what the world_size-2 CPU tests run.
+"""
+import torch
+import torch.distributed as dist
+
+
+def slab_bounds(ny_global, rank, world_size):
+    """Rows [j0, j1) owned by `rank`: as equal as possible, remainder to the southern ranks."""
+    base, rem = divmod(ny_global, world_size)
+    j0 = rank * base + min(rank, rem)
+    return j0, j0 + base + (1 if rank < rem else 0)
+
+
+def halo_row_slices(ny, hy, rows):
+    """(send_south, recv_south, send_north, recv_north) row slices of a (ny+2hy, ·) slab array."""
+    return (slice(hy, hy + rows), slice(hy - rows, hy),
+            slice(hy + ny - rows, hy + ny), slice(hy + ny, hy + ny + rows))
+
+
+def exchange_halo_rows_torch(tensors, ny, hy, rows=1, group=None):
+    """Neighbour exchange of `rows` boundary rows for every tensor in `tensors` using
+    torch.distributed P2P (gloo on CPU, RCCL on GPU).  Non-periodic in j: the first and last
+    ranks keep their outer halos."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world == 1:
+        return
+    ss, rs, sn, rn = halo_row_slices(ny, hy, rows)
+    ops, recvs = [], []
+    for t in tensors:
+        if rank > 0:
+            buf = torch.empty_like(t[rs])
+            ops.append(dist.P2POp(dist.isend, t[ss].contiguous(), rank - 1, group))
+            ops.append(dist.P2POp(dist.irecv, buf, rank - 1, group))
+            recvs.append((t, rs, buf))
+        if rank < world - 1:
+            buf = torch.empty_like(t[rn])
+            ops.append(dist.P2POp(dist.isend, t[sn].contiguous(), rank + 1, group))
+            ops.append(dist.P2POp(dist.irecv, buf, rank + 1, group))
+            recvs.append((t, rn, buf))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    for t, sl, buf in recvs:
+        t[sl].copy_(buf)
+
+
+class SlabHaloExchanger:
+    """Per-step halo exchange of the ocean surface fields of one slab.
+
+    backend "rccl": libcoflux's grouped ncclSend/ncclRecv on the kernels' stream (the unique id is
+    created on rank 0 and broadcast with torch.distributed); "torch": torch.distributed P2P.
+    """
+
+    def __init__(self, ctx, ny, hy, rows=1, backend="rccl"):
+        self.ctx, self.ny, self.hy, self.rows = ctx, ny, hy, rows
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.backend = backend if self.world > 1 else "none"
+        if self.backend == "rccl":
+            from .runtime import comm_unique_id
+            ident = [comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            ctx.comm_init(ident[0], self.rank, self.world)
+
+    def __call__(self, tensors):
+        if self.backend == "rccl":
+            self.ctx.halo_exchange_rows(tensors, self.rows)
+        elif self.backend == "torch":
+            exchange_halo_rows_torch(tensors, self.ny, self.hy, self.rows)

@@ -64,11 +64,21 @@ class FluxContext:
     def use_torch_stream(self):
         """Order libcoflux launches on torch's current stream for this device."""
         s = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self.lib.cf_set_stream(self._h, C.c_void_p(s)), "cf_set_stream")
+        # torch's default stream has handle 0 = the legacy null stream; 0 means "own stream" in the ABI
+        self._check(self.lib.cf_set_stream(self._h, C.c_void_p(s if s else 1)), "cf_set_stream")
 
     def set_flux_params(self, params):
         self._check(self.lib.cf_set_flux_params(self._h, C.byref(params)), "cf_set_flux_params")
         self.params = params
+
+    def set_option(self, option, value):
+        self._check(self.lib.cf_set_option(self._h, option, value), "cf_set_option")
+
+    def debug_eval(self, function, x):
+        """y = f(x) with the device primitives of the solver (self-test hook)."""
+        y = torch.empty_like(x)
+        self._check(self.lib.cf_debug_eval(self._h, function, x.numel(), _ptr(x), _ptr(y)), "cf_debug_eval")
+        return y
 
     def sync(self):
         self._check(self.lib.cf_sync(self._h), "cf_sync")
@@ -191,6 +201,15 @@ class FluxContext:
         self._check(self.lib.cf_time_copy(self._h, _ptr(b), _ptr(a), nbytes, launches, C.byref(ms)),
                     "cf_time_copy")
         return ms.value
+
+    def profile_enable(self, max_records):
+        self._check(self.lib.cf_profile_enable(self._h, max_records), "cf_profile_enable")
+
+    def profile_read(self, kernel):
+        """(average ms, records) of kernel 0 (fused interpolate+solver) or 1 (net fluxes)."""
+        ms, n = C.c_double(), C.c_int()
+        self._check(self.lib.cf_profile_read(self._h, kernel, C.byref(ms), C.byref(n)), "cf_profile_read")
+        return ms.value, n.value
 
     # -- RCCL halo rows -------------------------------------------------------------------------
     def comm_init(self, unique_id: bytes, rank, nranks):

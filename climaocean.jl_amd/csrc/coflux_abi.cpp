@@ -10,9 +10,12 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/coflux.h"
+#include "coflux_fast.hpp"
 #include "coflux_kernels.h"
+#include "coflux_tables.h"
 
 using namespace coflux;
 
@@ -35,11 +38,17 @@ struct cf_ctx {
     DevParams dev{};
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    int interp_cap = 256;  // floats per (variable, level) plane of the LDS-staged JRA55 tile
+    FastConsts fast{};
+    LaunchCfg launch{CF_SOLVER_TABLES, 256, 1024, nullptr};
+    double* d_tables = nullptr;
+    int tables_kind = -1;
     std::string error;
     // RCCL
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    // per-kernel event recorder (cf_profile_enable): 3 events per recorded update_state
+    std::vector<hipEvent_t> prof_events;
+    int prof_capacity = 0, prof_count = 0;
 };
 
 static thread_local std::string g_error;
@@ -164,6 +173,41 @@ static int lower_params(cf_ctx* ctx, const cf_flux_params* p, DevParams* d) {
     return CF_OK;
 }
 
+static FastConsts fast_consts(const cf_flux_params& p) {
+    FastConsts C{};
+    auto lg = [](double x) { return x > 0 ? std::log(x) : 0.0; };
+    C.log_lm_t = lg(p.temperature_roughness.maximum_length);
+    C.log_A_t = lg(p.temperature_roughness.reynolds_A);
+    C.log_const_t = lg(p.temperature_roughness.constant_length);
+    C.log_lm_q = lg(p.water_vapor_roughness.maximum_length);
+    C.log_A_q = lg(p.water_vapor_roughness.reynolds_A);
+    C.log_const_q = lg(p.water_vapor_roughness.constant_length);
+    C.log_const_m = lg(p.momentum_roughness.constant_length);
+    C.same_scalar = std::memcmp(&p.temperature_roughness, &p.water_vapor_roughness, sizeof(cf_roughness)) == 0;
+    return C;
+}
+
+// (Re)build the LDS tables for the configured stability functions and upload them.
+static int install_params(cf_ctx* ctx, const cf_flux_params* params) {
+    DevParams d;
+    int rc = lower_params(ctx, params, &d);
+    if (rc != CF_OK) return rc;
+    if (ctx->tables_kind != d.stability) {
+        std::vector<double> t = build_solver_tables(d.stability);
+        if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CF_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+        if (!ctx->d_tables && hipMalloc((void**)&ctx->d_tables, sizeof(double) * TABLE_DOUBLES) != hipSuccess)
+            return fail(ctx, CF_ERR_HIP, "hipMalloc of the solver tables failed");
+        if (hipMemcpy(ctx->d_tables, t.data(), sizeof(double) * TABLE_DOUBLES, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(ctx, CF_ERR_HIP, "upload of the solver tables failed");
+        ctx->tables_kind = d.stability;
+        ctx->launch.d_tables = ctx->d_tables;
+    }
+    ctx->params = *params;
+    ctx->dev = d;
+    ctx->fast = fast_consts(*params);
+    return CF_OK;
+}
+
 extern "C" {
 
 int cf_version(void) { return CF_ABI_VERSION; }
@@ -252,22 +296,24 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
     cf_ctx* ctx = new cf_ctx();
     ctx->device = device;
     ctx->grid = GridDesc{grid->nx, grid->ny, grid->hx, grid->hy, grid->ring, grid->nx + 2 * grid->hx};
-    if (params) {
-        int rc = lower_params(ctx, params, &ctx->dev);
-        if (rc != CF_OK) {
-            g_error = ctx->error;
-            delete ctx;
-            return rc;
-        }
-        ctx->params = *params;
-    } else {
-        cf_default_flux_params(&ctx->params);
-        lower_params(ctx, &ctx->params, &ctx->dev);
-    }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return fail(nullptr, CF_ERR_HIP, "cannot create a stream on device %d", device);
     }
+    cf_flux_params defaults;
+    if (!params) {
+        cf_default_flux_params(&defaults);
+        params = &defaults;
+    }
+    int rc = install_params(ctx, params);
+    if (rc != CF_OK) {
+        g_error = ctx->error;
+        cf_destroy(ctx);
+        return rc;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->launch.max_blocks = ((4 * prop.multiProcessorCount + 7) / 8) * 8;
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return CF_OK;
@@ -276,6 +322,8 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
 int cf_destroy(cf_ctx* ctx) {
     if (!ctx) return CF_OK;
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->own_stream) {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->own_stream);
@@ -287,11 +335,32 @@ int cf_destroy(cf_ctx* ctx) {
 
 int cf_set_flux_params(cf_ctx* ctx, const cf_flux_params* params) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
-    DevParams d;
-    int rc = lower_params(ctx, params, &d);
-    if (rc != CF_OK) return rc;
-    ctx->params = *params;
-    ctx->dev = d;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // tables may be rewritten
+    return install_params(ctx, params);
+}
+
+int cf_set_option(cf_ctx* ctx, int option, int value) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    switch (option) {
+        case CF_OPT_SOLVER:
+            if (value != CF_SOLVER_TABLES && value != CF_SOLVER_LIBM) return fail(ctx, CF_ERR_INVALID, "unknown solver %d", value);
+            ctx->launch.solver = value;
+            return CF_OK;
+        case CF_OPT_INTERP_TILE_CAP:
+            if (value < 16 || value > 1536) return fail(ctx, CF_ERR_INVALID, "interp tile cap %d outside [16, 1536]", value);
+            ctx->launch.interp_cap = value;
+            return CF_OK;
+        case CF_OPT_MAX_BLOCKS:
+            if (value < 8 || value % 8) return fail(ctx, CF_ERR_INVALID, "max blocks %d must be a positive multiple of 8", value);
+            ctx->launch.max_blocks = value;
+            return CF_OK;
+        default: return fail(ctx, CF_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+int cf_debug_eval(cf_ctx* ctx, int function, int n, const double* d_x, double* d_y) {
+    if (!ctx || !d_x || !d_y || n < 0) return fail(ctx, CF_ERR_INVALID, "cf_debug_eval: bad arguments");
+    HIP_TRY(ctx, launch_debug_eval(ctx->stream, ctx->launch, function, n, d_x, d_y));
     return CF_OK;
 }
 
@@ -391,7 +460,7 @@ int cf_interpolate_atmosphere_state(cf_ctx* ctx, const cf_atmos_source* src, con
     CHECK(check_source(ctx, src));
     CHECK(check_weights(ctx, w));
     CHECK(check_exchange(ctx, out, true));
-    HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->grid, src, w, out, ctx->interp_cap));
+    HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, out));
     return CF_OK;
 }
 
@@ -401,7 +470,7 @@ int cf_compute_atmosphere_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocea
     CHECK(check_ocean(ctx, ocean));
     CHECK(check_exchange(ctx, atmos, false));
     CHECK(check_fluxes(ctx, out));
-    HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, out));
+    HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, out));
     return CF_OK;
 }
 
@@ -427,8 +496,47 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     CHECK(check_exchange(ctx, atmos, true));
     CHECK(check_fluxes(ctx, fluxes));
     CHECK(check_net(ctx, net, w));
-    HIP_TRY(ctx, launch_fused(ctx->stream, ctx->dev, ctx->grid, src, w, ocean, atmos, fluxes, ctx->interp_cap));
+    const bool rec = ctx->prof_count < ctx->prof_capacity;
+    hipEvent_t* ev = rec ? &ctx->prof_events[3 * (size_t)ctx->prof_count] : nullptr;
+    if (rec) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    if (ctx->launch.solver == CF_SOLVER_LIBM) {  // cross-check path: unfused
+        HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
+        HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes));
+    } else {
+        HIP_TRY(ctx, launch_fused(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, src, w, ocean, atmos, fluxes));
+    }
+    if (rec) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net));
+    if (rec) {
+        HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
+        ++ctx->prof_count;
+    }
+    return CF_OK;
+}
+
+int cf_profile_enable(cf_ctx* ctx, int max_records) {
+    if (!ctx || max_records < 0) return fail(ctx, CF_ERR_INVALID, "cf_profile_enable: bad arguments");
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    ctx->prof_events.clear();
+    ctx->prof_capacity = ctx->prof_count = 0;
+    ctx->prof_events.resize(3 * (size_t)max_records);
+    for (auto& e : ctx->prof_events) HIP_TRY(ctx, hipEventCreate(&e));
+    ctx->prof_capacity = max_records;
+    return CF_OK;
+}
+
+int cf_profile_read(cf_ctx* ctx, int kernel, double* avg_ms, int* records) {
+    if (!ctx || !avg_ms || kernel < 0 || kernel > 1) return fail(ctx, CF_ERR_INVALID, "cf_profile_read: bad arguments");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    for (int n = 0; n < ctx->prof_count; ++n) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_events[3 * (size_t)n + kernel],
+                                        ctx->prof_events[3 * (size_t)n + kernel + 1]));
+        sum += ms;
+    }
+    *avg_ms = ctx->prof_count ? sum / ctx->prof_count : 0.0;
+    if (records) *records = ctx->prof_count;
     return CF_OK;
 }
 

@@ -1,0 +1,325 @@
+// coflux_fast.hpp — the production Monin–Obukhov solver for gfx950.
+//
+// Same iteration, same initial guess and same stop rule as the reference path (see
+// coflux_device.hpp::solve_cell, which is kept as the libm cross-check), but every
+// transcendental is replaced by something CDNA4 can issue cheaply in FP64:
+//   * ψ_m, ψ_h  : degree-7 piecewise polynomials in w = log(1 + 16|ζ|) staged in LDS
+//                 (coflux_tables.cpp); one instruction stream for both signs of ζ;
+//   * log       : 128-entry mantissa table in LDS + degree-6 log1p polynomial;
+//   * exp       : Cody–Waite reduction + degree-12 polynomial (v_ldexp_f64 to rebuild);
+//   * cbrt      : v_log_f32 / v_exp_f32 seed + one FP64 Halley step;
+//   * sqrt, 1/x : v_rsq_f64 / v_rcp_f64 + Newton steps, no IEEE division sequences.
+// Everything is accurate to a few ulp (≤ 2e-13 for ψ), far inside the 1e-9 parity tolerance,
+// and an iteration costs ≈ 300 FP64 instructions instead of ≈ 2200 with ocml.
+#pragma once
+#include "coflux_device.hpp"
+#include "coflux_tables.h"
+
+namespace coflux {
+
+// ---------------------------------------------------------------------------------------------
+// FP64 primitives
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// a / b to ~1 ulp
+__device__ __forceinline__ double fdiv(double a, double b) {
+    double r = frcp(b);
+    double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+
+__device__ __forceinline__ double fsqrt(double x) {  // x ≥ 0
+    double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+}
+
+// natural log of a positive normal double; `logt` = LDS table of (1/c_k, log c_k)
+__device__ __forceinline__ double flog(const double* logt, double x) {
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    const int e = (hi >> 20) - 1023;
+    const int k = (hi >> 13) & (LOG_SEG - 1);
+    const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);  // [1, 2)
+    const double2 ck = *reinterpret_cast<const double2*>(logt + 2 * k);
+    const double r = __builtin_fma(m, ck.x, -1.0);  // |r| ≤ 2^-8
+    double q = __builtin_fma(r, -1.0 / 6.0, 1.0 / 5.0);
+    q = __builtin_fma(r, q, -1.0 / 4.0);
+    q = __builtin_fma(r, q, 1.0 / 3.0);
+    q = __builtin_fma(r, q, -1.0 / 2.0);
+    const double p = __builtin_fma(r * r, q, r);
+    const double res = __builtin_fma((double)e, 0.6931471805599453094, ck.y + p);
+    return x > 0.0 ? res : -__builtin_inf();
+}
+
+__device__ __forceinline__ double fexp(double x) {
+    const double kf = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(-kf, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double kc = fmin(fmax(kf, -2000.0), 2000.0);
+    return __builtin_amdgcn_ldexp(p, (int)kc);
+}
+
+__device__ __forceinline__ double fcbrt(double x) {  // x ≥ 0
+    const float xf = (float)x;
+    const float y0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (1.0f / 3.0f));
+    double y = (double)y0;
+    const double y3 = y * y * y;
+    y = y * (y3 + 2.0 * x) * frcp(__builtin_fma(2.0, y3, x));  // Halley: cubic convergence
+    return (x > 0.0 && y0 > 0.0f) ? y : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tabulated stability functions
+// ---------------------------------------------------------------------------------------------
+struct PsiArg {
+    int k;       // segment
+    double t;    // position in the segment, [-1, 1]
+    int side;    // 0: ζ < 0 (unstable table), 1: ζ ≥ 0
+};
+
+__device__ __forceinline__ PsiArg psi_arg(const double* logt, double zeta) {
+    PsiArg a;
+    double w = flog(logt, __builtin_fma(PSI_A, fabs(zeta), 1.0));
+    w = fmin(w, PSI_WMAX);  // |ζ| > 1.65e9 is evaluated at the table edge (never a converged state)
+    const double s = w * (PSI_SEG / PSI_WMAX);
+    int k = (int)s;
+    k = min(k, PSI_SEG - 1);
+    a.k = k;
+    a.t = __builtin_fma(2.0, s - (double)k, -1.0);
+    a.side = zeta < 0.0 ? 0 : 1;
+    return a;
+}
+
+// fn: 0 = ψ_m, 1 = ψ_h
+__device__ __forceinline__ double psi_eval(const double* psi, int fn, const PsiArg& a) {
+    const double* c = psi + (2 * fn + a.side) * PSI_TABLE + a.k;
+    double p = c[7 * PSI_SEG];
+    p = __builtin_fma(p, a.t, c[6 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[5 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[4 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[3 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[2 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[1 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[0]);
+    return p;
+}
+
+// Cooperative copy of the tables into LDS (call once per workgroup, then __syncthreads()).
+__device__ __forceinline__ void stage_tables(double* lds_tab, const double* __restrict__ g_tab, int tid, int nthreads) {
+    const double2* src = reinterpret_cast<const double2*>(g_tab);
+    double2* dst = reinterpret_cast<double2*>(lds_tab);
+    for (int n = tid; n < TABLE_DOUBLES / 2; n += nthreads) dst[n] = src[n];
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-cell constants shared by the iteration
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double svp_liquid_fast(const DevParams& P, const double* logt, double T, double inv_T) {
+    return P.p_triple * fexp(__builtin_fma(P.svp_a_liq, flog(logt, T * P.inv_T_triple), P.svp_b_liq * (P.inv_T_triple - inv_T)));
+}
+
+__device__ __forceinline__ double liquid_fraction_fast(const DevParams& P, const double* logt, double T) {
+    double r = (T - P.T_icenuc) * P.inv_icenuc_span;
+    double ramp = r;
+    if (P.pow_icenuc != 1.0) ramp = r > 0.0 ? fexp(P.pow_icenuc * flog(logt, r)) : 0.0;
+    return T > P.T_freeze ? 1.0 : (T > P.T_icenuc ? ramp : 0.0);
+}
+
+__device__ __forceinline__ double svp_equil_fast(const DevParams& P, const double* logt, double T, double inv_T, double lam) {
+    if (lam == 1.0) return svp_liquid_fast(P, logt, T, inv_T);
+    double LH_0 = lam * P.LH_v0 + (1.0 - lam) * P.LH_s0;
+    double dcp = lam * (P.cp_v - P.cp_l) + (1.0 - lam) * (P.cp_v - P.cp_i);
+    double a = dcp * P.inv_R_v, b = (LH_0 - dcp * P.T_0) * P.inv_R_v;
+    return P.p_triple * fexp(__builtin_fma(a, flog(logt, T * P.inv_T_triple), b * (P.inv_T_triple - inv_T)));
+}
+
+__device__ __forceinline__ AirState air_state_fast(const DevParams& P, double p, double T, double inv_T, double q_tot,
+                                                   double lam, double p_vs) {
+    AirState s;
+    double q = fmin(fmax(q_tot, 0.0), 1.0);
+    const double tiny = 2.220446049250313e-16;
+    double q_vs_p = (p - p_vs >= tiny) ? P.Rd_over_Rv * (1.0 - q) * p_vs * frcp(p - p_vs) : 1.0 / tiny;
+    double q_c0 = fmax(q - q_vs_p, 0.0);
+    double inv_rho = P.R_d * (1.0 + P.delta * q - P.eps * q_c0) * T * frcp(p);
+    s.rho = frcp(inv_rho);
+    double q_vs_rho = p_vs * inv_rho * P.inv_R_v * inv_T;
+    double q_c = fmax(q - q_vs_rho, 0.0);
+    double q_l = lam * q_c, q_i = (1.0 - lam) * q_c;
+    s.cp_m = P.cp_d + (P.cp_v - P.cp_d) * q + (P.cp_l - P.cp_v) * q_l + (P.cp_i - P.cp_v) * q_i;
+    s.q_vap = fmax(0.0, q - q_l - q_i);
+    s.T_virtual = (1.0 + P.delta * q - P.eps * q_c) * T;
+    return s;
+}
+
+// log-roughness helper for the scalars: returns log ℓ (and ℓ itself when `need_l`)
+__device__ __forceinline__ double scalar_log_roughness(const cf_roughness& r, const double* logt, double log_A,
+                                                       double log_lm, double log_const, double lu, double us,
+                                                       double inv_nu) {
+    if (r.kind == CF_SCALAR_ROUGHNESS_CONSTANT) return log_const;
+    double Rstar = lu * us * inv_nu;
+    double ll = fmin(__builtin_fma(-r.reynolds_b, flog(logt, Rstar), log_A), log_lm);
+    return us == 0.0 ? log_lm : ll;
+}
+
+struct FastConsts {  // host-precomputed logs of the roughness constants
+    double log_lm_t, log_A_t, log_const_t;
+    double log_lm_q, log_A_q, log_const_q;
+    double log_const_m;
+    int32_t same_scalar;  // temperature and water-vapour roughness blocks are identical
+    int32_t pad;
+};
+
+template <bool COARE>
+__device__ __forceinline__ CellFluxes solve_cell_fast(const DevParams& P, const FastConsts& C, const double* tab,
+                                                      double ua, double va, double Ta, double pa, double qa, double uo,
+                                                      double vo, double To, double So, bool wet, bool in_range) {
+    const double* psi = tab;
+    const double* logt = tab + 4 * PSI_TABLE;
+    CellFluxes R;
+    const double Ts = To + P.T_offset;
+    const double inv_Ta = frcp(Ta), inv_Ts = frcp(Ts);
+
+    // --- iteration-invariant state -------------------------------------------------------------
+    const double lam_a = liquid_fraction_fast(P, logt, Ta);
+    const double pvs_a = svp_equil_fast(P, logt, Ta, inv_Ta, lam_a);
+    const AirState A = air_state_fast(P, pa, Ta, inv_Ta, qa, lam_a, pvs_a);
+
+    const double pstar_s = svp_liquid_fast(P, logt, Ts, inv_Ts);
+    const double sal = So * 1e-3;
+    const double x_h2o = P.sw_inv_w * frcp(__builtin_fma(sal * frcp(1.0 - sal), P.sw_inv_mu, P.sw_inv_w));
+    const double qs = x_h2o * pstar_s * frcp(A.rho * P.R_v * Ts);
+    const double dq = A.q_vap - qs;
+    const double dtheta = Ta + P.g * P.h_ref * frcp(A.cp_m) - Ts;
+    double du = ua, dv = va;
+    if (P.velocity_difference == CF_VELOCITY_RELATIVE) {
+        du = ua - uo;
+        dv = va - vo;
+    }
+    const double dU2 = du * du + dv * dv;
+    const double dU = fsqrt(dU2);
+
+    const double lam_s = liquid_fraction_fast(P, logt, Ts);
+    const double pvs_s = (lam_s == 1.0) ? pstar_s : svp_equil_fast(P, logt, Ts, inv_Ts, lam_s);
+    const AirState Sfc = air_state_fast(P, pa, Ts, inv_Ts, qs, lam_s, pvs_s);
+    const double g_over_Tv = P.g * frcp(Sfc.T_virtual);
+    const double b_theta = 1.0 + P.delta * Sfc.q_vap;
+    const double b_q = P.delta * Sfc.T_virtual;
+
+    const double nu_m = air_viscosity(P.rm, Ts);
+    const double inv_nu_t = frcp(air_viscosity(P.rt, Ts));
+    const double inv_nu_q = frcp(air_viscosity(P.rq, Ts));
+    double alpha = P.rm.charnock;
+    if (P.rm.kind == CF_ROUGHNESS_WIND_CHARNOCK)
+        alpha = fmax(P.rm.charnock, P.rm.wind_a1 * fmin(dU, P.rm.wind_umax) + P.rm.wind_a2);
+    const double lam_nu = P.rm.laminar * nu_m;
+    const double alpha_g = alpha * P.inv_g;
+
+    // --- the fixed point -----------------------------------------------------------------------
+    double us = 1e-4, ts = 1e-4, qq = 1e-4;
+    double drift = 0.0;
+    int it = 0;
+    const bool fixed = P.stop_kind == CF_STOP_FIXED;
+    const bool participates = in_range && (fixed || wet);
+    for (;;) {
+        bool go;
+        if (fixed) {
+            go = participates && it < P.maxiter;
+        } else {
+            go = participates && ((it == 0) || !(drift < P.tol || it >= P.maxiter));
+        }
+        if (__ballot(go) == 0ull) break;  // the wave leaves the loop together
+        if (go) {
+            const double bstar = g_over_Tv * __builtin_fma(ts, b_theta, b_q * qq);
+            const double Jb = -us * bstar;
+            double Ug = P.min_gust;
+            if (P.beta_gust != 0.0) Ug = fmax(P.beta_gust * fcbrt(fmax(Jb, 0.0) * P.h_bl), P.min_gust);
+            const double U = fsqrt(__builtin_fma(Ug, Ug, dU2));
+
+            const double inv_us = frcp(us);
+            double lu, log_lu;
+            if (P.rm.kind == CF_ROUGHNESS_CONSTANT) {
+                lu = P.rm.constant_length;
+                log_lu = C.log_const_m;
+            } else {
+                const double lm = P.rm.maximum_length;
+                const double lR = (us == 0.0) ? lm : lam_nu * inv_us;
+                lu = fmin(__builtin_fma(alpha_g * us, us, lR), lm);
+                log_lu = flog(logt, lu);
+            }
+            const double log_lq = scalar_log_roughness(P.rq, logt, C.log_A_q, C.log_lm_q, C.log_const_q, lu, us, inv_nu_q);
+            const double log_lt = C.same_scalar ? log_lq
+                                                : scalar_log_roughness(P.rt, logt, C.log_A_t, C.log_lm_t, C.log_const_t,
+                                                                       lu, us, inv_nu_t);
+
+            // 1/L★ = −κ b★ / u★²  (0 when b★ = 0)
+            const double inv_L = (bstar == 0.0) ? 0.0 : -(P.kappa * bstar) * (inv_us * inv_us);
+            const PsiArg ah = psi_arg(logt, P.h_ref * inv_L);
+            double Du = P.log_h - log_lu - psi_eval(psi, 0, ah);
+            const double psi_hh = psi_eval(psi, 1, ah);
+            double Dq = P.log_h - log_lq - psi_hh;
+            double Dt = P.log_h - log_lt - psi_hh;
+            if constexpr (!COARE) {
+                Du += psi_eval(psi, 0, psi_arg(logt, lu * inv_L));
+                const double psi_lq = psi_eval(psi, 1, psi_arg(logt, fexp(log_lq) * inv_L));
+                Dq += psi_lq;
+                Dt += C.same_scalar ? psi_lq : psi_eval(psi, 1, psi_arg(logt, fexp(log_lt) * inv_L));
+            }
+            Du = fmax(Du, P.profile_floor);
+            Dq = fmax(Dq, P.profile_floor);
+            Dt = fmax(Dt, P.profile_floor);
+            const double chi_q = P.kappa * frcp(Dq);
+            const double chi_t = C.same_scalar ? chi_q : P.kappa * frcp(Dt);
+            const double un = P.kappa * frcp(Du) * U, tn = chi_t * dtheta, qn = chi_q * dq;
+            drift = fabs(un - us) + fabs(tn - ts) + fabs(qn - qq);
+            us = un;
+            ts = tn;
+            qq = qn;
+            ++it;
+        }
+    }
+
+    const bool zero = !wet;
+    if (zero) us = ts = qq = 0.0;
+    const double inv_dU = (dU == 0.0) ? 0.0 : frcp(dU);
+    const double tau = -us * us * inv_dU;
+    const double Lv = P.LH_v0 + (P.cp_v - P.cp_l) * (Ta - P.T_0);
+    const double rho_u = A.rho * us;
+    R.Fv = -rho_u * qq;
+    R.Qv = R.Fv * Lv;
+    R.Qc = -rho_u * A.cp_m * ts;
+    R.rho_tau_x = A.rho * tau * du;
+    R.rho_tau_y = A.rho * tau * dv;
+    R.Ts_ocean = (zero ? 0.0 : Ts) - P.T_offset;
+    R.ustar = us;
+    R.tstar = ts;
+    R.qstar = qq;
+    R.iterations = it;
+    return R;
+}
+
+}  // namespace coflux

@@ -6,16 +6,27 @@
 
 namespace coflux {
 
-hipError_t launch_interpolate(hipStream_t st, const GridDesc& G, const cf_atmos_source* s, const cf_interp_weights* w,
-                              const cf_exchange_fields* e, int cap);
-hipError_t launch_ao_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
-                            const cf_exchange_fields* e, const cf_interface_fluxes* f);
-hipError_t launch_fused(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_atmos_source* s,
-                        const cf_interp_weights* w, const cf_ocean_surface* o, const cf_exchange_fields* e,
-                        const cf_interface_fluxes* f, int cap);
+struct FastConsts;
+
+struct LaunchCfg {
+    int solver;              // CF_SOLVER_*
+    int interp_cap;          // floats per (variable, level) plane of the LDS-staged JRA55 tile
+    int max_blocks;          // persistent grid size (multiple of 8: one share per XCD)
+    const double* d_tables;  // device copy of the solver tables (coflux_tables.cpp)
+};
+
+hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
+                              const cf_interp_weights* w, const cf_exchange_fields* e);
+hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const FastConsts& C,
+                            const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
+                            const cf_interface_fluxes* f);
+hipError_t launch_fused(hipStream_t st, const LaunchCfg& L, const DevParams& P, const FastConsts& C, const GridDesc& G,
+                        const cf_atmos_source* s, const cf_interp_weights* w, const cf_ocean_surface* o,
+                        const cf_exchange_fields* e, const cf_interface_fluxes* f);
 hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_exchange_fields* e, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
                              const cf_interp_weights* w, const cf_net_ocean_fluxes* n);
+hipError_t launch_debug_eval(hipStream_t st, const LaunchCfg& L, int fn, int n, const double* x, double* y);
 hipError_t launch_copy(hipStream_t st, void* dst, const void* src, size_t bytes);
 
 }  // namespace coflux

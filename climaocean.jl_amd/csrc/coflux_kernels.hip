@@ -1,27 +1,59 @@
 // coflux_kernels.hip — gfx950 kernels of the surface-flux path.
 //
-//   interpolate_kernel ....... interpolate_atmosphere_state!  (JRA55 f32 window → 8 exchange fields)
-//   ao_flux_kernel ........... compute_atmosphere_ocean_fluxes! (Monin–Obukhov fixed point)
-//   fused_interp_flux_kernel . the two above in one pass (update_state! path)
-//   net_flux_kernel .......... compute_net_ocean_fluxes!       (radiation + partition)
+//   interpolate_kernel ....... interpolate_atmosphere_state!   (JRA55 f32 window → 8 exchange fields)
+//   ao_flux_fast_kernel ...... compute_atmosphere_ocean_fluxes! (Monin–Obukhov fixed point, LDS tables)
+//   fused_fast_kernel ........ the two above in one pass (update_state! path)
+//   net_flux_kernel .......... compute_net_ocean_fluxes!        (radiation + partition)
+//   ao_flux_libm_kernel ...... cross-check variant of the solver on ocml's libm (CF_SOLVER_LIBM)
 //
-// All are pointwise / 1-cell-stencil kernels bounded by HBM, not by MFMA: nothing here is a
-// contraction.  Lanes run along i (the contiguous axis) so every field access is a coalesced
-// 512-B wave transaction; the JRA55 source tile a workgroup needs is staged once through LDS.
+// All are pointwise / 1-cell-stencil kernels: nothing here is a contraction, so no MFMA.
+// Lanes run along i (the contiguous axis) so every field access is a coalesced 512-B wave
+// transaction; the JRA55 source tile a workgroup needs is staged once through LDS; the solver's
+// ψ / log tables live in LDS; workgroups are persistent (grid = k × 256 CUs) and walk tiles so
+// that each XCD keeps to its own latitude band of the JRA55 window (private 4 MB L2 per XCD).
 #include <hip/hip_runtime.h>
 
 #include "coflux_device.hpp"
+#include "coflux_fast.hpp"
 #include "coflux_kernels.h"
 
 namespace coflux {
 
+constexpr int TILE_X = 64;                   // one wave spans 64 consecutive i
+constexpr int TILE_Y = 4;                    // 4 waves per workgroup, one row each
+constexpr int NPLANES = 2 * CF_JRA55_NVARS;  // (variable, time level)
+constexpr int BOX_BYTES = 32;                // 8 ints of tile bookkeeping in dynamic LDS
+constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
+constexpr int NUM_XCD = 8;
+
+// ---------------------------------------------------------------------------------------------
+// Persistent tile walk.  Workgroup b is (observed to be) placed on XCD b % 8; giving XCD x the
+// contiguous tile range [x·chunk, (x+1)·chunk) keeps the JRA55 rows it touches (1/8 of 14.7 MB)
+// inside that XCD's own L2.  Placement only affects speed, never results.
+// ---------------------------------------------------------------------------------------------
+struct TileWalk {
+    int tile, end, step;
+};
+__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
+    const int b = blockIdx.x, nb = gridDim.x;
+    TileWalk w;
+    if (nb % NUM_XCD == 0 && nb >= NUM_XCD) {
+        const int chunk = (ntiles + NUM_XCD - 1) / NUM_XCD;
+        const int xcd = b % NUM_XCD, slot = b / NUM_XCD;
+        w.tile = xcd * chunk + slot;
+        w.end = min((xcd + 1) * chunk, ntiles);
+        w.step = nb / NUM_XCD;
+    } else {
+        w.tile = b;
+        w.end = ntiles;
+        w.step = nb;
+    }
+    return w;
+}
+
 // =============================================================================================
 // JRA55 tile staging + bilinear × linear-in-time interpolation
 // =============================================================================================
-constexpr int TILE_X = 64;   // one wave spans 64 consecutive i
-constexpr int TILE_Y = 4;    // 4 waves per workgroup, one row each
-constexpr int NPLANES = 2 * CF_JRA55_NVARS;  // (variable, time level)
-
 struct InterpCell {
     double v[CF_JRA55_NVARS];
 };
@@ -49,24 +81,24 @@ __device__ __forceinline__ int wrap_index(int i, int n) {
 // Stages the (≤ cap floats per plane) source footprint of this workgroup's TILE_X×TILE_Y cells
 // into LDS and interpolates the 9 variables for the calling thread's cell.  When the footprint
 // does not fit (coarse target grids, folds) the workgroup gathers from global memory instead —
-// the window is 14.7 MB and lives in L2/Infinity Cache.
-__device__ __forceinline__ InterpCell interpolate_cell(const SourceDesc& S, const WeightDesc& Wt,
-                                                       const GridDesc& G, int i, int j, bool in_range,
-                                                       float* lds, int cap) {
-    __shared__ int box[5];  // dmin, dmax, jmin, jmax, ref
+// the window is 14.7 MB and lives in L2 / Infinity Cache.  `box` = 8 ints of dynamic LDS.
+// Ends with the tile still live in LDS: callers __syncthreads() before the next tile.
+__device__ __forceinline__ InterpCell interpolate_cell(const SourceDesc& S, const WeightDesc& Wt, const GridDesc& G,
+                                                       int i, int j, int* box, float* lds, int cap) {
     const int tid = threadIdx.y * TILE_X + threadIdx.x;
 
     // clamp out-of-window threads onto a valid cell so that they do not widen the footprint
-    int ic = min(max(i, -G.ring), G.nx + G.ring - 1);
-    int jc = min(max(j, -G.ring), G.ny + G.ring - 1);
-    size_t k = cell_index(G, ic, jc);
-    double fi = Wt.separable ? Wt.fi[ic + G.hx] : Wt.fi[k];
-    double fj = Wt.separable ? Wt.fj[jc + G.hy] : Wt.fj[k];
+    const int ic = min(max(i, -G.ring), G.nx + G.ring - 1);
+    const int jc = min(max(j, -G.ring), G.ny + G.ring - 1);
+    const size_t k = cell_index(G, ic, jc);
+    const double fi = Wt.separable ? Wt.fi[ic + G.hx] : Wt.fi[k];
+    const double fj = Wt.separable ? Wt.fj[jc + G.hy] : Wt.fj[k];
 
-    double ti = trunc(fi), tj = trunc(fj);
-    double xi = fi - ti, eta = fj - tj;
-    int i0 = (int)ti, j0 = (int)tj;
-    int i1 = i0 + (fi > 0.0 ? 1 : (fi < 0.0 ? -1 : 0));
+    const double ti = trunc(fi), tj = trunc(fj);
+    const double xi = fi - ti, eta = fj - tj;
+    const int i0 = (int)ti;
+    int j0 = (int)tj;
+    const int i1 = i0 + (fi > 0.0 ? 1 : (fi < 0.0 ? -1 : 0));
     int j1 = j0 + (fj > 0.0 ? 1 : (fj < 0.0 ? -1 : 0));
     j0 = min(max(j0, 0), S.ns_y - 1);
     j1 = min(max(j1, 0), S.ns_y - 1);
@@ -80,11 +112,10 @@ __device__ __forceinline__ InterpCell interpolate_cell(const SourceDesc& S, cons
     }
     __syncthreads();
     const int ref = box[4];
-    // offsets relative to the tile's reference column, wrapped to (−ns_x/2, ns_x/2]
-    int d0 = i0 - ref, d1 = i1 - ref;
+    // offsets relative to the tile's reference column, wrapped to [−ns_x/2, ns_x/2)
     const int half = S.ns_x / 2;
-    d0 = wrap_index(d0 + half, S.ns_x) - half;
-    d1 = d0 + (i1 - i0);
+    const int d0 = wrap_index(i0 - ref + half, S.ns_x) - half;
+    const int d1 = d0 + (i1 - i0);
     atomicMin(&box[0], min(d0, d1));
     atomicMax(&box[1], max(d0, d1));
     atomicMin(&box[2], min(j0, j1));
@@ -99,13 +130,13 @@ __device__ __forceinline__ InterpCell interpolate_cell(const SourceDesc& S, cons
         const int per_plane = W * H;
         const int total = per_plane * NPLANES;
         for (int e = tid; e < total; e += TILE_X * TILE_Y) {
-            int p = e / per_plane;
-            int r = e - p * per_plane;
-            int y = r / W;
-            int x = r - y * W;
-            int var = p >> 1;
-            int lev = (p & 1) ? S.level2 : S.level1;
-            int is = wrap_index(ref + dmin + x, S.ns_x);
+            const int p = e / per_plane;
+            const int r = e - p * per_plane;
+            const int y = r / W;
+            const int x = r - y * W;
+            const int var = p >> 1;
+            const int lev = (p & 1) ? S.level2 : S.level1;
+            const int is = wrap_index(ref + dmin + x, S.ns_x);
             lds[p * cap + r] = S.data[var][(size_t)lev * plane_stride + (size_t)(jmin + y) * S.ns_x + is];
         }
     }
@@ -138,7 +169,6 @@ __device__ __forceinline__ InterpCell interpolate_cell(const SourceDesc& S, cons
             out.v[var] = v2 * S.tf + v1 * (1.0 - S.tf);
         }
     }
-    (void)in_range;
     return out;
 }
 
@@ -190,14 +220,22 @@ __device__ __forceinline__ void store_exchange(const Exchange& E, size_t k, cons
 
 __global__ __launch_bounds__(TILE_X* TILE_Y) void interpolate_kernel(SourceDesc S, WeightDesc Wt, GridDesc G,
                                                                       Exchange E, int cap) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int i = (int)blockIdx.x * TILE_X + (int)threadIdx.x - G.ring;
-    const int j = (int)blockIdx.y * TILE_Y + (int)threadIdx.y - G.ring;
-    const bool in_range = (i < G.nx + G.ring) && (j < G.ny + G.ring);
-    InterpCell c = interpolate_cell(S, Wt, G, i, j, in_range, lds, cap);
-    if (in_range) {
-        size_t k = cell_index(G, i, j);
-        store_exchange(E, k, finish_interp(c, Wt, k));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* box = reinterpret_cast<int*>(smem);
+    float* lds = reinterpret_cast<float*>(smem + BOX_BYTES);
+    const int tiles_x = (G.nx + 2 * G.ring + TILE_X - 1) / TILE_X;
+    const int tiles_y = (G.ny + 2 * G.ring + TILE_Y - 1) / TILE_Y;
+    for (TileWalk w = tile_walk(tiles_x * tiles_y); w.tile < w.end; w.tile += w.step) {
+        const int ty = w.tile / tiles_x, tx = w.tile - ty * tiles_x;
+        const int i = tx * TILE_X + (int)threadIdx.x - G.ring;
+        const int j = ty * TILE_Y + (int)threadIdx.y - G.ring;
+        const bool in_range = (i < G.nx + G.ring) && (j < G.ny + G.ring);
+        InterpCell c = interpolate_cell(S, Wt, G, i, j, box, lds, cap);
+        if (in_range) {
+            size_t k = cell_index(G, i, j);
+            store_exchange(E, k, finish_interp(c, Wt, k));
+        }
+        __syncthreads();  // tile and box are rewritten by the next iteration
     }
 }
 
@@ -238,19 +276,76 @@ __device__ __forceinline__ void store_fluxes(const FluxOut& F, size_t k, const C
     if (F.iters) F.iters[k] = R.iterations;
 }
 
-template <int STAB, bool COARE>
-__device__ __forceinline__ CellFluxes solve_dispatch(const DevParams& P, const AtmosCell& a, double uo, double vo,
-                                                     double To, double So, bool wet, bool in_range) {
-    if (P.stop_kind == CF_STOP_FIXED)
-        return solve_cell<STAB, COARE, true>(P, a.u, a.v, a.T, a.p, a.q, uo, vo, To, So, wet, in_range);
-    return solve_cell<STAB, COARE, false>(P, a.u, a.v, a.T, a.p, a.q, uo, vo, To, So, wet, in_range);
-}
-
 constexpr int AO_BLOCK = 256;
 
+// ---- production solver: LDS tables, persistent workgroups ------------------------------------
+template <bool COARE>
+__global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(DevParams P, FastConsts C, GridDesc G, OceanIn O,
+                                                                Exchange E, FluxOut F,
+                                                                const double* __restrict__ g_tab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tab = reinterpret_cast<double*>(smem);
+    stage_tables(tab, g_tab, threadIdx.x, AO_BLOCK);
+    __syncthreads();
+
+    const int wx = G.nx + 2 * G.ring;
+    const int ncells = wx * (G.ny + 2 * G.ring);
+    for (int base = (int)blockIdx.x * AO_BLOCK; base < ncells; base += (int)gridDim.x * AO_BLOCK) {
+        const int idx = base + (int)threadIdx.x;
+        const bool in_range = idx < ncells;
+        const int cidx = in_range ? idx : ncells - 1;
+        const int jj = cidx / wx;
+        const int i = cidx - jj * wx - G.ring;
+        const int j = jj - G.ring;
+        const size_t k = cell_index(G, i, j);
+        // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
+        const double uo = 0.5 * (O.u[k] + O.u[k + 1]);
+        const double vo = 0.5 * (O.v[k] + O.v[k + (size_t)G.sj]);
+        const bool wet = cell_is_wet(P, O.mask, k);
+        CellFluxes R = solve_cell_fast<COARE>(P, C, tab, E.u[k], E.v[k], E.T[k], E.p[k], E.q[k], uo, vo, O.T[k], O.S[k],
+                                              wet, in_range);
+        if (in_range) store_fluxes(F, k, R);
+    }
+}
+
+template <bool COARE>
+__global__ __launch_bounds__(TILE_X* TILE_Y) void fused_fast_kernel(DevParams P, FastConsts C, SourceDesc S,
+                                                                     WeightDesc Wt, GridDesc G, OceanIn O, Exchange E,
+                                                                     FluxOut F, const double* __restrict__ g_tab,
+                                                                     int cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tab = reinterpret_cast<double*>(smem);
+    int* box = reinterpret_cast<int*>(smem + TABLE_BYTES);
+    float* lds = reinterpret_cast<float*>(smem + TABLE_BYTES + BOX_BYTES);
+    const int tid = threadIdx.y * TILE_X + threadIdx.x;
+    stage_tables(tab, g_tab, tid, TILE_X * TILE_Y);  // visible after the first barrier in interpolate_cell
+
+    const int tiles_x = (G.nx + 2 * G.ring + TILE_X - 1) / TILE_X;
+    const int tiles_y = (G.ny + 2 * G.ring + TILE_Y - 1) / TILE_Y;
+    for (TileWalk w = tile_walk(tiles_x * tiles_y); w.tile < w.end; w.tile += w.step) {
+        const int ty = w.tile / tiles_x, tx = w.tile - ty * tiles_x;
+        const int i = tx * TILE_X + (int)threadIdx.x - G.ring;
+        const int j = ty * TILE_Y + (int)threadIdx.y - G.ring;
+        const bool in_range = (i < G.nx + G.ring) && (j < G.ny + G.ring);
+        InterpCell c = interpolate_cell(S, Wt, G, i, j, box, lds, cap);
+        const int ic = min(i, G.nx + G.ring - 1), jc = min(j, G.ny + G.ring - 1);
+        const size_t k = cell_index(G, ic, jc);
+        AtmosCell a = finish_interp(c, Wt, k);
+        if (in_range) store_exchange(E, k, a);
+
+        const double uo = 0.5 * (O.u[k] + O.u[k + 1]);
+        const double vo = 0.5 * (O.v[k] + O.v[k + (size_t)G.sj]);
+        const bool wet = cell_is_wet(P, O.mask, k);
+        CellFluxes R = solve_cell_fast<COARE>(P, C, tab, a.u, a.v, a.T, a.p, a.q, uo, vo, O.T[k], O.S[k], wet, in_range);
+        if (in_range) store_fluxes(F, k, R);
+        __syncthreads();  // tile and box are rewritten by the next iteration
+    }
+}
+
+// ---- cross-check solver on ocml's libm (CF_SOLVER_LIBM) --------------------------------------
 template <int STAB, bool COARE>
-__global__ __launch_bounds__(AO_BLOCK) void ao_flux_kernel(DevParams P, GridDesc G, OceanIn O, Exchange E,
-                                                           FluxOut F) {
+__global__ __launch_bounds__(AO_BLOCK) void ao_flux_libm_kernel(DevParams P, GridDesc G, OceanIn O, Exchange E,
+                                                                FluxOut F) {
     const int wx = G.nx + 2 * G.ring;
     const int ncells = wx * (G.ny + 2 * G.ring);
     const int idx = (int)blockIdx.x * AO_BLOCK + (int)threadIdx.x;
@@ -260,42 +355,14 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_kernel(DevParams P, GridDesc
     const int i = cidx - jj * wx - G.ring;
     const int j = jj - G.ring;
     const size_t k = cell_index(G, i, j);
-
-    AtmosCell a;
-    a.u = E.u[k];
-    a.v = E.v[k];
-    a.T = E.T[k];
-    a.p = E.p[k];
-    a.q = E.q[k];
-    // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
     const double uo = 0.5 * (O.u[k] + O.u[k + 1]);
     const double vo = 0.5 * (O.v[k] + O.v[k + (size_t)G.sj]);
-    const double To = O.T[k], So = O.S[k];
     const bool wet = cell_is_wet(P, O.mask, k);
-
-    CellFluxes R = solve_dispatch<STAB, COARE>(P, a, uo, vo, To, So, wet, in_range);
-    if (in_range) store_fluxes(F, k, R);
-}
-
-template <int STAB, bool COARE>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void fused_interp_flux_kernel(DevParams P, SourceDesc S, WeightDesc Wt,
-                                                                            GridDesc G, OceanIn O, Exchange E,
-                                                                            FluxOut F, int cap) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int i = (int)blockIdx.x * TILE_X + (int)threadIdx.x - G.ring;
-    const int j = (int)blockIdx.y * TILE_Y + (int)threadIdx.y - G.ring;
-    const bool in_range = (i < G.nx + G.ring) && (j < G.ny + G.ring);
-    InterpCell c = interpolate_cell(S, Wt, G, i, j, in_range, lds, cap);
-    const int ic = min(i, G.nx + G.ring - 1), jc = min(j, G.ny + G.ring - 1);
-    const size_t k = cell_index(G, ic, jc);
-    AtmosCell a = finish_interp(c, Wt, k);
-    if (in_range) store_exchange(E, k, a);
-
-    const double uo = 0.5 * (O.u[k] + O.u[k + 1]);
-    const double vo = 0.5 * (O.v[k] + O.v[k + (size_t)G.sj]);
-    const double To = O.T[k], So = O.S[k];
-    const bool wet = cell_is_wet(P, O.mask, k);
-    CellFluxes R = solve_dispatch<STAB, COARE>(P, a, uo, vo, To, So, wet, in_range);
+    CellFluxes R;
+    if (P.stop_kind == CF_STOP_FIXED)
+        R = solve_cell<STAB, COARE, true>(P, E.u[k], E.v[k], E.T[k], E.p[k], E.q[k], uo, vo, O.T[k], O.S[k], wet, in_range);
+    else
+        R = solve_cell<STAB, COARE, false>(P, E.u[k], E.v[k], E.T[k], E.p[k], E.q[k], uo, vo, O.T[k], O.S[k], wet, in_range);
     if (in_range) store_fluxes(F, k, R);
 }
 
@@ -380,6 +447,33 @@ __global__ __launch_bounds__(NET_BLOCK) void net_flux_kernel(DevParams P, GridDe
     if (N.sw_down) N.sw_down[k] = wf * (-Qts);
 }
 
+// ---------------------------------------------------------------------------------------------
+// table / primitive self-test: y[n] = fn(x[n]) with the device's fast primitives (tests only)
+// ---------------------------------------------------------------------------------------------
+__global__ void debug_eval_kernel(int fn, int n, const double* __restrict__ x, double* __restrict__ y,
+                                  const double* __restrict__ g_tab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tab = reinterpret_cast<double*>(smem);
+    stage_tables(tab, g_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const double* logt = tab + 4 * PSI_TABLE;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const double v = x[k];
+        double r;
+        switch (fn) {
+            case 0: r = flog(logt, v); break;
+            case 1: r = fexp(v); break;
+            case 2: r = fcbrt(v); break;
+            case 3: r = fsqrt(v); break;
+            case 4: r = frcp(v); break;
+            case 5: r = psi_eval(tab, 0, psi_arg(logt, v)); break;
+            case 6: r = psi_eval(tab, 1, psi_arg(logt, v)); break;
+            default: r = 0.0;
+        }
+        y[k] = r;
+    }
+}
+
 // =============================================================================================
 // host-side launchers (called from coflux_abi.cpp)
 // =============================================================================================
@@ -416,67 +510,74 @@ static FluxOut make_fluxes(const cf_interface_fluxes* f) {
                    f->temperature,   f->friction_velocity, f->temperature_scale, f->humidity_scale, f->iterations};
 }
 
-static dim3 tile_grid(const GridDesc& G) {
-    return dim3((G.nx + 2 * G.ring + TILE_X - 1) / TILE_X, (G.ny + 2 * G.ring + TILE_Y - 1) / TILE_Y);
+static int tile_count(const GridDesc& G) {
+    return ((G.nx + 2 * G.ring + TILE_X - 1) / TILE_X) * ((G.ny + 2 * G.ring + TILE_Y - 1) / TILE_Y);
 }
 
-hipError_t launch_interpolate(hipStream_t st, const GridDesc& G, const cf_atmos_source* s, const cf_interp_weights* w,
-                              const cf_exchange_fields* e, int cap) {
-    size_t lds = (size_t)NPLANES * cap * sizeof(float);
-    hipLaunchKernelGGL(interpolate_kernel, tile_grid(G), dim3(TILE_X, TILE_Y), lds, st, make_source(s),
-                       make_weights(w), G, make_exchange(e), cap);
+// persistent grid: a multiple of 8 (one share per XCD), at most `max_blocks`
+static int persistent_blocks(int work_items, int max_blocks) {
+    if (work_items >= max_blocks) return max_blocks;
+    if (work_items >= NUM_XCD) return (work_items / NUM_XCD) * NUM_XCD;
+    return work_items > 0 ? work_items : 1;
+}
+
+hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
+                              const cf_interp_weights* w, const cf_exchange_fields* e) {
+    size_t lds = BOX_BYTES + (size_t)NPLANES * L.interp_cap * sizeof(float);
+    int blocks = persistent_blocks(tile_count(G), L.max_blocks);
+    hipLaunchKernelGGL(interpolate_kernel, dim3(blocks), dim3(TILE_X, TILE_Y), lds, st, make_source(s),
+                       make_weights(w), G, make_exchange(e), L.interp_cap);
     return hipGetLastError();
 }
 
-template <int STAB>
-static void launch_ao_t(hipStream_t st, const DevParams& P, const GridDesc& G, const OceanIn& O, const Exchange& E,
-                        const FluxOut& F) {
-    const int ncells = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
-    dim3 grid((ncells + AO_BLOCK - 1) / AO_BLOCK);
-    if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
-        hipLaunchKernelGGL((ao_flux_kernel<STAB, true>), grid, dim3(AO_BLOCK), 0, st, P, G, O, E, F);
-    else
-        hipLaunchKernelGGL((ao_flux_kernel<STAB, false>), grid, dim3(AO_BLOCK), 0, st, P, G, O, E, F);
-}
-
-hipError_t launch_ao_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
-                            const cf_exchange_fields* e, const cf_interface_fluxes* f) {
+hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const FastConsts& C,
+                            const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
+                            const cf_interface_fluxes* f) {
     OceanIn O = make_ocean(o);
     Exchange E = make_exchange(e);
     FluxOut F = make_fluxes(f);
-    switch (P.stability) {
-        case CF_STABILITY_EDSON2013: launch_ao_t<CF_STABILITY_EDSON2013>(st, P, G, O, E, F); break;
-        case CF_STABILITY_SHEBA: launch_ao_t<CF_STABILITY_SHEBA>(st, P, G, O, E, F); break;
-        default: launch_ao_t<CF_STABILITY_LARGE_YEAGER>(st, P, G, O, E, F); break;
+    const int ncells = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
+    const int chunks = (ncells + AO_BLOCK - 1) / AO_BLOCK;
+    if (L.solver == CF_SOLVER_LIBM) {
+        dim3 grid(chunks);
+        const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
+#define LIBM_LAUNCH(STAB)                                                                                   \
+    if (coare)                                                                                              \
+        hipLaunchKernelGGL((ao_flux_libm_kernel<STAB, true>), grid, dim3(AO_BLOCK), 0, st, P, G, O, E, F);  \
+    else                                                                                                    \
+        hipLaunchKernelGGL((ao_flux_libm_kernel<STAB, false>), grid, dim3(AO_BLOCK), 0, st, P, G, O, E, F);
+        switch (P.stability) {
+            case CF_STABILITY_EDSON2013: LIBM_LAUNCH(CF_STABILITY_EDSON2013) break;
+            case CF_STABILITY_SHEBA: LIBM_LAUNCH(CF_STABILITY_SHEBA) break;
+            default: LIBM_LAUNCH(CF_STABILITY_LARGE_YEAGER) break;
+        }
+#undef LIBM_LAUNCH
+        return hipGetLastError();
     }
+    dim3 grid(persistent_blocks(chunks, L.max_blocks));
+    if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
+        hipLaunchKernelGGL((ao_flux_fast_kernel<true>), grid, dim3(AO_BLOCK), TABLE_BYTES, st, P, C, G, O, E, F, L.d_tables);
+    else
+        hipLaunchKernelGGL((ao_flux_fast_kernel<false>), grid, dim3(AO_BLOCK), TABLE_BYTES, st, P, C, G, O, E, F, L.d_tables);
     return hipGetLastError();
 }
 
-template <int STAB>
-static void launch_fused_t(hipStream_t st, const DevParams& P, const GridDesc& G, const SourceDesc& S,
-                           const WeightDesc& W, const OceanIn& O, const Exchange& E, const FluxOut& F, int cap) {
-    size_t lds = (size_t)NPLANES * cap * sizeof(float);
-    if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
-        hipLaunchKernelGGL((fused_interp_flux_kernel<STAB, true>), tile_grid(G), dim3(TILE_X, TILE_Y), lds, st, P, S,
-                           W, G, O, E, F, cap);
-    else
-        hipLaunchKernelGGL((fused_interp_flux_kernel<STAB, false>), tile_grid(G), dim3(TILE_X, TILE_Y), lds, st, P, S,
-                           W, G, O, E, F, cap);
-}
-
-hipError_t launch_fused(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_atmos_source* s,
-                        const cf_interp_weights* w, const cf_ocean_surface* o, const cf_exchange_fields* e,
-                        const cf_interface_fluxes* f, int cap) {
+hipError_t launch_fused(hipStream_t st, const LaunchCfg& L, const DevParams& P, const FastConsts& C, const GridDesc& G,
+                        const cf_atmos_source* s, const cf_interp_weights* w, const cf_ocean_surface* o,
+                        const cf_exchange_fields* e, const cf_interface_fluxes* f) {
     SourceDesc S = make_source(s);
     WeightDesc W = make_weights(w);
     OceanIn O = make_ocean(o);
     Exchange E = make_exchange(e);
     FluxOut F = make_fluxes(f);
-    switch (P.stability) {
-        case CF_STABILITY_EDSON2013: launch_fused_t<CF_STABILITY_EDSON2013>(st, P, G, S, W, O, E, F, cap); break;
-        case CF_STABILITY_SHEBA: launch_fused_t<CF_STABILITY_SHEBA>(st, P, G, S, W, O, E, F, cap); break;
-        default: launch_fused_t<CF_STABILITY_LARGE_YEAGER>(st, P, G, S, W, O, E, F, cap); break;
-    }
+    size_t lds = TABLE_BYTES + BOX_BYTES + (size_t)NPLANES * L.interp_cap * sizeof(float);
+    dim3 grid(persistent_blocks(tile_count(G), L.max_blocks));
+    if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
+        hipLaunchKernelGGL((fused_fast_kernel<true>), grid, dim3(TILE_X, TILE_Y), lds, st, P, C, S, W, G, O, E, F,
+                           L.d_tables, L.interp_cap);
+    else
+        hipLaunchKernelGGL((fused_fast_kernel<false>), grid, dim3(TILE_X, TILE_Y), lds, st, P, C, S, W, G, O, E, F,
+                           L.d_tables, L.interp_cap);
     return hipGetLastError();
 }
 
@@ -490,6 +591,11 @@ hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc&
     const int ncells = G.nx * G.ny;
     hipLaunchKernelGGL(net_flux_kernel, dim3((ncells + NET_BLOCK - 1) / NET_BLOCK), dim3(NET_BLOCK), 0, st, P, G,
                        make_ocean(o), make_exchange(e), make_fluxes(f), I, make_weights(w), N);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_eval(hipStream_t st, const LaunchCfg& L, int fn, int n, const double* x, double* y) {
+    hipLaunchKernelGGL(debug_eval_kernel, dim3(64), dim3(256), TABLE_BYTES, st, fn, n, x, y, L.d_tables);
     return hipGetLastError();
 }
 

@@ -1,0 +1,147 @@
+// coflux_tables.cpp — host-side construction of the lookup tables the gfx950 solver stages in LDS.
+//
+// The Monin–Obukhov iteration spends its time in ψ_m(ζ), ψ_h(ζ) and log().  On CDNA4 an FP64
+// libm call costs 40–120 instructions (double-double arithmetic), and the stability functions
+// need 3 log + 2 atan + cbrt + 2 sqrt each.  Instead, every ψ is tabulated once per context as
+// piecewise degree-7 polynomials in  w = log(1 + 16|ζ|)  (128 segments on w ∈ [0, 24], i.e.
+// |ζ| ≤ 1.6e9; one table per sign of ζ), which reproduces the analytic functions to ≤ 2e-13
+// relative to max(|ψ|, 1) — four orders below the 1e-9 parity tolerance — at the price of one
+// log and 8 LDS reads + 7 FMAs.  Both signs share one instruction stream, so waves that mix
+// stable and unstable cells no longer execute both branches.
+//
+// log() itself uses a 128-entry (1/c, log c) table on the mantissa.
+#include <cmath>
+#include <vector>
+
+#include "../../include/coflux.h"
+#include "coflux_tables.h"
+
+namespace coflux {
+
+namespace {
+
+const long double PI_L = 3.14159265358979323846264338327950288L;
+
+// --- analytic stability functions (same formulas as coflux_device.hpp's reference branch) -----
+long double paulson_m(long double x) {
+    return 2.0L * logl((1.0L + x) / 2.0L) + logl((1.0L + x * x) / 2.0L) - 2.0L * atanl(x) + PI_L / 2.0L;
+}
+long double convective(long double y) {
+    const long double r3 = sqrtl(3.0L);
+    return 1.5L * logl((1.0L + y + y * y) / 3.0L) - r3 * atanl((1.0L + 2.0L * y) / r3) + PI_L / r3;
+}
+
+// `unstable` selects the branch explicitly (ζ = 0 belongs to the stable branch in the reference:
+// ifelse(ζ < 0, ψᵤ, ψₛ)); `az` = |ζ|.
+long double psi_m_exact(int kind, bool unstable, long double az) {
+    if (unstable) {
+        long double zm = -az;
+        if (kind == CF_STABILITY_EDSON2013) {
+            long double p1 = paulson_m(sqrtl(sqrtl(1.0L - 15.0L * zm)));
+            long double p2 = convective(cbrtl(1.0L - 10.15L * zm));
+            long double f = zm * zm / (1.0L + zm * zm);
+            return (1.0L - f) * p1 + f * p2;
+        }
+        return paulson_m(sqrtl(sqrtl(1.0L - 16.0L * zm)));
+    }
+    long double zp = az;
+    if (kind == CF_STABILITY_EDSON2013) {
+        long double dz = fminl(50.0L, 0.35L * zp);
+        return -0.7L * zp - 0.75L * (zp - 5.0L / 0.35L) * expl(-dz) - 0.75L * 5.0L / 0.35L;
+    }
+    if (kind == CF_STABILITY_SHEBA) {
+        const long double a = 5.0L, b = 5.0L / 6.5L, r3 = sqrtl(3.0L);
+        long double B = cbrtl((1.0L - b) / b), x = cbrtl(1.0L + zp);
+        return -3.0L * a / b * (x - 1.0L) +
+               a * B / (2.0L * b) *
+                   (2.0L * logl((x + B) / (1.0L + B)) - logl((x * x - x * B + B * B) / (1.0L - B + B * B)) +
+                    2.0L * r3 * (atanl((2.0L * x - B) / (r3 * B)) - atanl((2.0L - B) / (r3 * B))));
+    }
+    return -5.0L * zp;
+}
+
+long double psi_h_exact(int kind, bool unstable, long double az) {
+    if (unstable) {
+        long double zm = -az;
+        if (kind == CF_STABILITY_EDSON2013) {
+            long double p1 = 2.0L * logl((1.0L + sqrtl(1.0L - 15.0L * zm)) / 2.0L);
+            long double p2 = convective(cbrtl(1.0L - 34.15L * zm));
+            long double f = zm * zm / (1.0L + zm * zm);
+            return (1.0L - f) * p1 + f * p2;
+        }
+        return 2.0L * logl((1.0L + sqrtl(1.0L - 16.0L * zm)) / 2.0L);
+    }
+    long double zp = az;
+    if (kind == CF_STABILITY_EDSON2013) {
+        long double dz = fminl(50.0L, 0.35L * zp);
+        long double base = 1.0L + 2.0L / 3.0L * zp;
+        return -(base * sqrtl(base)) - 2.0L / 3.0L * (zp - 14.28L) * expl(-dz) - 8.525L;
+    }
+    if (kind == CF_STABILITY_SHEBA) {
+        const long double a = 5.0L, b = 5.0L, c = 3.0L;
+        long double B = sqrtl(c * c - 4.0L);
+        return -b / 2.0L * logl(1.0L + c * zp + zp * zp) +
+               (-a / B + b * c / (2.0L * B)) *
+                   (logl((2.0L * zp + c - B) / (2.0L * zp + c + B)) - logl((c - B) / (c + B)));
+    }
+    return -5.0L * zp;
+}
+
+// Degree-(PSI_DEG) Chebyshev interpolant of f on [-1, 1], returned as monomial coefficients.
+template <class F>
+void cheb_fit_monomial(F f, double* out /* PSI_DEG+1 */) {
+    constexpr int N = PSI_DEG + 1;
+    long double fx[N], c[N];
+    for (int k = 0; k < N; ++k) fx[k] = f(cosl(PI_L * (k + 0.5L) / N));
+    for (int j = 0; j < N; ++j) {
+        long double s = 0;
+        for (int k = 0; k < N; ++k) s += fx[k] * cosl(PI_L * j * (k + 0.5L) / N);
+        c[j] = (j == 0 ? 1.0L : 2.0L) * s / N;
+    }
+    // Σ c_j T_j(t) → Σ m_i t^i via the T recurrence on coefficient vectors
+    long double Tm2[N] = {1}, Tm1[N] = {0, 1}, T[N], m[N] = {0};
+    for (int i = 0; i < N; ++i) m[i] = 0;
+    m[0] += c[0];
+    if (N > 1) m[1] += c[1];
+    for (int j = 2; j < N; ++j) {
+        for (int i = 0; i < N; ++i) T[i] = -Tm2[i] + (i > 0 ? 2.0L * Tm1[i - 1] : 0.0L);
+        for (int i = 0; i < N; ++i) {
+            m[i] += c[j] * T[i];
+            Tm2[i] = Tm1[i];
+            Tm1[i] = T[i];
+        }
+    }
+    for (int i = 0; i < N; ++i) out[i] = (double)m[i];
+}
+
+}  // namespace
+
+// Layout (doubles): table τ ∈ {ψm unstable, ψm stable, ψh unstable, ψh stable}, coefficient-major:
+//   psi[τ * PSI_TABLE + c * PSI_SEG + k],  then the log table  logt[2*k] = 1/c_k, logt[2*k+1] = log c_k.
+std::vector<double> build_solver_tables(int stability_kind) {
+    std::vector<double> t(TABLE_DOUBLES, 0.0);
+    const long double dw = (long double)PSI_WMAX / PSI_SEG;
+    for (int tau = 0; tau < 4; ++tau) {
+        const bool scalar = tau >= 2, unstable = (tau % 2) == 0;
+        for (int k = 0; k < PSI_SEG; ++k) {
+            double coef[PSI_DEG + 1];
+            auto f = [&](long double tt) {
+                long double w = dw * (k + 0.5L * (tt + 1.0L));
+                long double az = expm1l(w) / (long double)PSI_A;
+                return scalar ? psi_h_exact(stability_kind, unstable, az) : psi_m_exact(stability_kind, unstable, az);
+            };
+            cheb_fit_monomial(f, coef);
+            for (int c = 0; c <= PSI_DEG; ++c) t[(size_t)tau * PSI_TABLE + (size_t)c * PSI_SEG + k] = coef[c];
+        }
+    }
+    double* lt = t.data() + 4 * PSI_TABLE;
+    for (int k = 0; k < LOG_SEG; ++k) {
+        long double c = 1.0L + (k + 0.5L) / LOG_SEG;  // centre of the k-th mantissa interval of [1, 2)
+        double inv_c = (double)(1.0L / c);
+        lt[2 * k] = inv_c;
+        lt[2 * k + 1] = (double)(-logl((long double)inv_c));  // log of the value actually multiplied by
+    }
+    return t;
+}
+
+}  // namespace coflux

@@ -296,7 +296,21 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
 int cf_destroy(cf_ctx* ctx);
 const char* cf_last_error(const cf_ctx* ctx); /* ctx may be NULL: last error of the calling thread */
 int cf_set_flux_params(cf_ctx* ctx, const cf_flux_params* params);
-int cf_set_stream(cf_ctx* ctx, void* hip_stream); /* NULL ⇒ library-owned stream */
+/* hip_stream: a hipStream_t; NULL ⇒ the library-owned non-blocking stream; CF_STREAM_LEGACY ⇒ the
+ * legacy default (null) stream, which is what torch's default stream is (its handle is 0).        */
+#define CF_STREAM_LEGACY ((void*)1) /* == hipStreamLegacy */
+int cf_set_stream(cf_ctx* ctx, void* hip_stream);
+
+/* Implementation options (none of them changes what is computed beyond the stated tolerance).  */
+#define CF_OPT_SOLVER 0           /* CF_SOLVER_*                                                   */
+#define CF_OPT_INTERP_TILE_CAP 1  /* floats per (variable, level) plane of the LDS JRA55 tile (256) */
+#define CF_OPT_MAX_BLOCKS 2       /* persistent grid size, multiple of 8 (default 4 per CU = 1024)  */
+#define CF_SOLVER_TABLES 0  /* default: reference iteration path, LDS-tabulated ψ/log, ≤1e-12 of libm */
+#define CF_SOLVER_LIBM 1    /* same iteration on ocml's libm (slow; cross-check)                     */
+int cf_set_option(cf_ctx* ctx, int option, int value);
+/* Self-test hook: y[k] = f(x[k]) with the device primitives the solver uses
+ * (f: 0 log, 1 exp, 2 cbrt, 3 sqrt, 4 1/x, 5 ψ_m(ζ), 6 ψ_h(ζ)); d_x, d_y device pointers.        */
+int cf_debug_eval(cf_ctx* ctx, int function, int n, const double* d_x, double* d_y);
 int cf_sync(cf_ctx* ctx);
 
 /* Device memory for callers that cannot own HIP memory themselves (Julia without AMDGPU.jl). */
@@ -354,6 +368,14 @@ int cf_time_stage(cf_ctx* ctx, int stage, int launches, const cf_atmos_source* s
                   double* ms_per_launch);
 int cf_time_copy(cf_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int launches,
                  double* ms_per_launch);
+/* Per-kernel timing INSIDE a caller's timed region: while enabled, cf_update_state brackets each of
+ * its kernels with HIP events on the launch stream (no host sync).  cf_profile_read synchronises,
+ * returns the average duration of `kernel` (0 = fused interpolate+solver, 1 = net fluxes) over the
+ * recorded steps.  cf_profile_enable(ctx, n) (re)arms the recorder for n steps; 0 disables.        */
+#define CF_KERNEL_FUSED_INTERP_FLUX 0
+#define CF_KERNEL_NET_FLUXES 1
+int cf_profile_enable(cf_ctx* ctx, int max_records);
+int cf_profile_read(cf_ctx* ctx, int kernel, double* avg_ms, int* records);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU: latitude-slab halo rows over RCCL (Partition(1,4) launch.sh:165,

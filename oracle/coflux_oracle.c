@@ -484,6 +484,9 @@ static double interp_one(const float* data, int nsx, int nsy, int l1, int l2, do
 int oracle_interpolate_atmosphere_state(const cf_grid* g, const cf_atmos_source* s,
                                         const cf_interp_weights* w, const cf_exchange_fields* out) {
     int r = g->ring;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int j = -r; j < g->ny + r; ++j) {
         for (int i = -r; i < g->nx + r; ++i) {
             size_t k = IDX(g, i, j);
@@ -523,6 +526,9 @@ int oracle_compute_net_ocean_fluxes(const cf_grid* g, const cf_flux_params* P, c
     const double rho_f_inv = 1.0 / P->ocean_freshwater_density;
     const double c_o = P->ocean_heat_capacity;
     const double pi = 3.14159265358979323846;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int j = 0; j < g->ny; ++j) {
         for (int i = 0; i < g->nx; ++i) {
             size_t k = IDX(g, i, j), kw = IDX(g, i - 1, j), ks = IDX(g, i, j - 1);
