@@ -28,6 +28,19 @@ __device__ __forceinline__ double frcp(double x) {
     return __builtin_fma(r, e, r);
 }
 
+// one Newton step: (4.5e-8)² ≈ 2e-15 relative — used inside the iteration
+__device__ __forceinline__ double frcp1(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+
+__device__ __forceinline__ double fsqrt1(double x) {  // x ≥ 0, ≈ 3e-15 relative
+    double r = __builtin_amdgcn_rsq(x);
+    double g = x * r;
+    g = __builtin_fma(__builtin_fma(-g, g, x), 0.5 * r, g);
+    return x > 0.0 ? g : 0.0;
+}
+
 // a / b to ~1 ulp
 __device__ __forceinline__ double fdiv(double a, double b) {
     double r = frcp(b);
@@ -89,7 +102,7 @@ __device__ __forceinline__ double fcbrt(double x) {  // x ≥ 0
     const float y0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (1.0f / 3.0f));
     double y = (double)y0;
     const double y3 = y * y * y;
-    y = y * (y3 + 2.0 * x) * frcp(__builtin_fma(2.0, y3, x));  // Halley: cubic convergence
+    y = y * (y3 + 2.0 * x) * frcp1(__builtin_fma(2.0, y3, x));  // Halley: cubic convergence
     return (x > 0.0 && y0 > 0.0f) ? y : 0.0;
 }
 
@@ -258,9 +271,9 @@ __device__ __forceinline__ CellFluxes solve_cell_fast(const DevParams& P, const 
             const double Jb = -us * bstar;
             double Ug = P.min_gust;
             if (P.beta_gust != 0.0) Ug = fmax(P.beta_gust * fcbrt(fmax(Jb, 0.0) * P.h_bl), P.min_gust);
-            const double U = fsqrt(__builtin_fma(Ug, Ug, dU2));
+            const double U = fsqrt1(__builtin_fma(Ug, Ug, dU2));
 
-            const double inv_us = frcp(us);
+            const double inv_us = frcp1(us);
             double lu, log_lu;
             if (P.rm.kind == CF_ROUGHNESS_CONSTANT) {
                 lu = P.rm.constant_length;
@@ -292,9 +305,9 @@ __device__ __forceinline__ CellFluxes solve_cell_fast(const DevParams& P, const 
             Du = fmax(Du, P.profile_floor);
             Dq = fmax(Dq, P.profile_floor);
             Dt = fmax(Dt, P.profile_floor);
-            const double chi_q = P.kappa * frcp(Dq);
-            const double chi_t = C.same_scalar ? chi_q : P.kappa * frcp(Dt);
-            const double un = P.kappa * frcp(Du) * U, tn = chi_t * dtheta, qn = chi_q * dq;
+            const double chi_q = P.kappa * frcp1(Dq);
+            const double chi_t = C.same_scalar ? chi_q : P.kappa * frcp1(Dt);
+            const double un = P.kappa * frcp1(Du) * U, tn = chi_t * dtheta, qn = chi_q * dq;
             drift = fabs(un - us) + fabs(tn - ts) + fabs(qn - qq);
             us = un;
             ts = tn;
