@@ -1,0 +1,258 @@
+"""Host-side mirror of the user-facing API around the flux path — same names, argument meaning
+and call order as the reference:
+
+    grid       = LatitudeLongitudeGrid(size=(1440, 560, 10), halo=(7, 7, 7), longitude=(0, 360),
+                                       latitude=(-70, 70), z=(-3000, 0))          # README.md:56-61
+    ocean      = ocean_simulation(grid)                                            # README.md:67
+    atmosphere = JRA55PrescribedAtmosphere()                                       # README.md:74
+    coupled    = OceanSeaIceModel(ocean; atmosphere)                               # README.md:75
+    simulation = Simulation(coupled, Δt=20minutes, stop_time=30days); run!(sim)    # README.md:76-77
+
+Only the flux path is implemented: `time_step!(coupled)` advances the clock, lets
+the ocean component step (the hydrostatic dynamical core is OUT OF SCOPE — `ocean_simulation`
+returns a prescribed-state ocean whose step is a no-op unless a callback is given) and then runs
+`update_state!`, which is the accelerated part: interpolate_atmosphere_state! →
+compute_atmosphere_ocean_fluxes! → compute_net_ocean_fluxes!, all inside libcoflux on the GPU.
+The net fluxes land in the ocean's top-boundary-condition fields exactly where the reference puts
+them (model.interfaces.net_fluxes.ocean.{u,v,T,S}, omip_diagnostics.jl:77-80).
+
+There is no JRA55 file reader here (NetCDF staging is SURVEY §8f "next"): the atmosphere holds a
+window of snapshots in HBM that the caller fills (synthetic in tests/bench).
+"""
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import abi, synthetic
+from . import interface_computations as ic
+from .runtime import EXCHANGE_NAMES, FLUX_NAMES, FLUX_OPTIONAL, NET_NAMES, FluxContext
+
+minutes, hours, days = 60.0, 3600.0, 86400.0
+
+
+# ---------------------------------------------------------------------------------------------
+# grid
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class LatitudeLongitudeGrid:
+    """README.md:56-61 (only the metadata the surface path needs)."""
+    size: tuple = (1440, 560, 10)
+    halo: tuple = (7, 7, 7)
+    longitude: tuple = (0.0, 360.0)
+    latitude: tuple = (-70.0, 70.0)
+    z: tuple = (-3000.0, 0.0)
+    device: int = 0
+
+    @property
+    def surface_shape(self):
+        (nx, ny, _), (hx, hy, _) = self.size, self.halo
+        return (ny + 2 * hy, nx + 2 * hx)
+
+    @property
+    def surface_z(self):
+        nz = self.size[2]
+        dz = (self.z[1] - self.z[0]) / nz
+        return self.z[1] - 0.5 * dz  # centre of the top cell (uniform spacing)
+
+    def fractional_indices(self, nsx=synthetic.JRA55_NX, nsy=synthetic.JRA55_NY):
+        nx, ny, _ = self.size
+        hx, hy, _ = self.halo
+        return synthetic.latlon_fractional_indices(nx, ny, hx, hy, latitude=self.latitude, nsx=nsx, nsy=nsy)
+
+
+# ---------------------------------------------------------------------------------------------
+# ocean (boundary only: surface state in, top-BC flux fields out)
+# ---------------------------------------------------------------------------------------------
+class OceanSimulation:
+    """What `ocean_simulation(grid)` returns: `.model.tracers.{T,S}`, `.model.velocities.{u,v}` as
+    (Nz+2Hz, Ny+2Hy, Nx+2Hx) device arrays (k slowest), `.model.clock`, and the top boundary
+    condition fields the coupled model writes (omip_simulation.jl:175-206: bare 2-D fields)."""
+
+    def __init__(self, grid, step_callback=None):
+        dev = torch.device("cuda", grid.device)
+        nz, hz = grid.size[2], grid.halo[2]
+        shape3 = (nz + 2 * hz,) + grid.surface_shape
+        z3 = lambda: torch.zeros(shape3, dtype=torch.float64, device=dev)  # noqa: E731
+        z2 = lambda: torch.zeros(grid.surface_shape, dtype=torch.float64, device=dev)  # noqa: E731
+        self.grid = grid
+        self.k_top = hz + nz - 1
+        self.model = SimpleNamespace(
+            grid=grid,
+            tracers=SimpleNamespace(T=z3(), S=z3()),
+            velocities=SimpleNamespace(u=z3(), v=z3()),
+            clock=SimpleNamespace(time=0.0, iteration=0),
+            wet_mask=torch.ones(grid.surface_shape, dtype=torch.uint8, device=dev),
+            top_boundary_conditions=SimpleNamespace(u=z2(), v=z2(), T=z2(), S=z2()),
+            shortwave_surface_flux=z2())  # radiation.surface_flux, KPP/kpp_surface_forcing.jl:47-51
+        self.step_callback = step_callback
+
+    def surface_state(self):
+        m, k = self.model, self.k_top
+        return dict(T=m.tracers.T[k], S=m.tracers.S[k], u=m.velocities.u[k], v=m.velocities.v[k], mask=m.wet_mask)
+
+    def time_step(self, dt):
+        if self.step_callback is not None:
+            self.step_callback(self, dt)
+        self.model.clock.time += dt
+        self.model.clock.iteration += 1
+
+
+def ocean_simulation(grid, **kw):
+    """README.md:67; OceanConfigurations/latitude_longitude.jl:50-55."""
+    return OceanSimulation(grid, **kw)
+
+
+def set_surface(ocean, *, T=None, S=None, u=None, v=None, mask=None):
+    """set!(ocean.model, T=…, S=…) for the top level (README.md:69-71), from host arrays with halos."""
+    m, k = ocean.model, ocean.k_top
+    for tgt, src in ((m.tracers.T, T), (m.tracers.S, S), (m.velocities.u, u), (m.velocities.v, v)):
+        if src is not None:
+            tgt[k].copy_(torch.as_tensor(np.ascontiguousarray(src)))
+    if mask is not None:
+        m.wet_mask.copy_(torch.as_tensor(np.ascontiguousarray(mask)))
+
+
+# ---------------------------------------------------------------------------------------------
+# atmosphere / radiation
+# ---------------------------------------------------------------------------------------------
+class JRA55PrescribedAtmosphere:
+    """JRA55PrescribedAtmosphere(arch; dir, dataset, start_date, end_date, time_indices_in_memory,
+    prefetch) — atmosphere.jl:20-29, README.md:74.  Holds `time_indices_in_memory` 3-hourly
+    snapshots of the 9 variables (jra55_data_staging.jl:8) as Float32 640×320 fields in HBM."""
+
+    def __init__(self, snapshots=None, *, time_indices_in_memory=2, time_interval=3 * hours, device=0,
+                 reference_height=10.0, boundary_layer_height=600.0, cyclic=True):
+        dev = torch.device("cuda", device)
+        if snapshots is None:
+            snapshots = synthetic.jra55_snapshots(time_indices_in_memory)
+        self.data = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in snapshots.items()}
+        self.n_levels = next(iter(self.data.values())).shape[0]
+        self.time_interval = time_interval
+        self.reference_height = reference_height
+        self.boundary_layer_height = boundary_layer_height
+        self.cyclic = cyclic  # RepeatYearJRA55-style cyclic time indexing vs clamped
+
+    def time_indices(self, t):
+        """(n₁, n₂, ñ): the bracketing snapshots and the fractional position between them."""
+        x = t / self.time_interval
+        n = int(np.floor(x))
+        frac = x - n
+        if self.cyclic:
+            return n % self.n_levels, (n + 1) % self.n_levels, frac
+        n1 = min(max(n, 0), self.n_levels - 1)
+        n2 = min(max(n + 1, 0), self.n_levels - 1)
+        return n1, n2, (frac if 0 <= n < self.n_levels - 1 else 0.0)
+
+
+@dataclass
+class Radiation:
+    """JRA55PrescribedRadiation(arch; ocean_surface = SurfaceRadiationProperties(0.06, 1.00), …),
+    atmosphere.jl:41-44 (the downwelling fields themselves ride in the atmosphere window)."""
+    ocean_surface: ic.SurfaceRadiationProperties = field(default_factory=ic.SurfaceRadiationProperties)
+    stefan_boltzmann_constant: float = 5.67e-8
+
+
+JRA55PrescribedRadiation = Radiation
+
+
+@dataclass
+class PrescribedSeaIce:
+    """The sea-ice inputs the partition reads (atmosphere.jl:34-39, src/ClimaOcean.jl:62-63); a
+    prognostic ClimaSeaIce model is out of scope, its fields are taken as given."""
+    concentration: torch.Tensor
+    interface_heat: Optional[torch.Tensor] = None
+    salt_flux: Optional[torch.Tensor] = None
+    x_stress: Optional[torch.Tensor] = None
+    y_stress: Optional[torch.Tensor] = None
+
+    def fields(self):
+        return {k: getattr(self, k) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")
+                if getattr(self, k) is not None}
+
+
+# ---------------------------------------------------------------------------------------------
+# ComponentInterfaces / OceanSeaIceModel
+# ---------------------------------------------------------------------------------------------
+class ComponentInterfaces:
+    """ComponentInterfaces(atmosphere, ocean, sea_ice; radiation, atmosphere_ocean_fluxes,
+    atmosphere_ocean_velocity_difference, ocean_minimum_salinity) — omip_simulation.jl:128-158."""
+
+    def __init__(self, atmosphere, ocean, sea_ice=None, *, radiation=None, atmosphere_ocean_fluxes=None,
+                 atmosphere_ocean_velocity_difference=None, ocean_minimum_salinity=0.0, ocean_properties=None,
+                 store_similarity_scales=False):
+        grid = ocean.grid
+        (nx, ny, _), (hx, hy, _) = grid.size, grid.halo
+        self.radiation = radiation or Radiation()
+        self.atmosphere_ocean_fluxes = atmosphere_ocean_fluxes or ic.SimilarityTheoryFluxes()
+        props = ocean_properties or ic.OceanProperties(surface_z=grid.surface_z)
+        params = ic.flux_params(self.atmosphere_ocean_fluxes,
+                                velocity_difference=atmosphere_ocean_velocity_difference,
+                                ocean=props, ocean_surface=self.radiation.ocean_surface,
+                                reference_height=atmosphere.reference_height,
+                                boundary_layer_height=atmosphere.boundary_layer_height,
+                                ocean_minimum_salinity=ocean_minimum_salinity,
+                                stefan_boltzmann_constant=self.radiation.stefan_boltzmann_constant)
+        self.context = FluxContext(nx, ny, hx, hy, params, ring=1, device=grid.device)
+        ctx = self.context
+        fi, fj, phi = grid.fractional_indices()
+        self.weights = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj), latitude=ctx.to_device(phi))
+        self.exchange_atmosphere_state = ctx.field_set(EXCHANGE_NAMES)
+        fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL if store_similarity_scales else ())
+        self.atmosphere_ocean_interface = SimpleNamespace(fluxes=SimpleNamespace(**fluxes), _fields=fluxes)
+        bc = ocean.model.top_boundary_conditions
+        net = dict(u=bc.u, v=bc.v, T=bc.T, S=bc.S, shortwave_surface_flux=ocean.model.shortwave_surface_flux,
+                   upwelling_longwave=ctx.zeros(), downwelling_longwave=ctx.zeros(), downwelling_shortwave=ctx.zeros())
+        self.net_fluxes = SimpleNamespace(ocean=SimpleNamespace(**net), _ocean_fields=net)
+
+
+class OceanSeaIceModel:
+    """OceanSeaIceModel(ocean[, sea_ice]; atmosphere, radiation, interfaces) — README.md:75,
+    examples/one_degree_tripolar_ocean_sea_ice.jl:42, omip_simulation.jl:132,163."""
+
+    def __init__(self, ocean, sea_ice=None, *, atmosphere, radiation=None, interfaces=None):
+        self.ocean, self.sea_ice, self.atmosphere = ocean, sea_ice, atmosphere
+        self.interfaces = interfaces or ComponentInterfaces(atmosphere, ocean, sea_ice, radiation=radiation)
+        self.clock = SimpleNamespace(time=0.0, iteration=0)
+        update_state(self)
+
+
+def OceanOnlyModel(ocean, *, atmosphere, **kw):
+    """docs/src/index.md:64 alias."""
+    return OceanSeaIceModel(ocean, None, atmosphere=atmosphere, **kw)
+
+
+def update_state(model):
+    """update_state!(coupled_model) — the accelerated path."""
+    itf, atm = model.interfaces, model.atmosphere
+    n1, n2, frac = atm.time_indices(model.clock.time)
+    ice = model.sea_ice.fields() if model.sea_ice is not None else None
+    itf.context.update_state(atm.data, itf.weights, model.ocean.surface_state(), itf.exchange_atmosphere_state,
+                             itf.atmosphere_ocean_interface._fields, itf.net_fluxes._ocean_fields, ice=ice,
+                             level1=n1, level2=n2, time_fraction=frac)
+
+
+def time_step(model, dt):
+    """time_step!(coupled_model, Δt): component steps, tick, update_state!."""
+    model.ocean.time_step(dt)
+    model.clock.time += dt
+    model.clock.iteration += 1
+    update_state(model)
+
+
+@dataclass
+class Simulation:
+    model: OceanSeaIceModel
+    dt: float = 20 * minutes          # README.md:76
+    stop_time: float = float("inf")
+    stop_iteration: int = 2 ** 62
+
+
+def run(simulation):
+    """run!(simulation) — README.md:77."""
+    m = simulation.model
+    while m.clock.time < simulation.stop_time and m.clock.iteration < simulation.stop_iteration:
+        time_step(m, simulation.dt)
+    m.interfaces.context.sync()
