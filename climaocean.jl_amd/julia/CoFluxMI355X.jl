@@ -1,0 +1,158 @@
+# CoFluxMI355X.jl — the reference-side binding of libcoflux (include/coflux.h).
+#
+# NOT EXECUTED IN THIS REPOSITORY: the build image has no Julia toolchain (SURVEY.md F3), so this
+# file is the stub a ClimaOcean / NumericalEarth maintainer would add; every ccall below is kept
+# one-to-one with a C entry point that IS exercised (through ctypes) by tests/.
+#
+# Seam: the reference reaches the flux path by multiple dispatch, not through an FFI
+# (SURVEY.md §8b).  `update_state!(::OceanSeaIceModel)` calls, in order,
+#     interpolate_atmosphere_state!, compute_atmosphere_ocean_fluxes!, compute_net_ocean_fluxes!
+# (NEMOTKE/nemo_tke_compute_closure_fields.jl:7-8 names the call; the bodies live in
+# NumericalEarth.EarthSystemModels).  A coupled model whose `interfaces` carry a `CoFluxBackend`
+# dispatches those three functions here; nothing else in the user's script changes:
+#
+#     ocean      = ocean_simulation(grid)                        # README.md:67
+#     atmosphere = JRA55PrescribedAtmosphere(arch)               # README.md:74
+#     coupled    = OceanSeaIceModel(ocean; atmosphere,
+#                      interfaces = CoFluxMI355X.interfaces(atmosphere, ocean))
+#     run!(Simulation(coupled, Δt = 20minutes, stop_time = 30days))
+#
+# Host code stays Julia; no AMDGPU.jl / KernelAbstractions: device buffers are raw pointers owned
+# by libcoflux (cf_device_alloc) and wrapped in `unsafe_wrap`-free handle structs.
+module CoFluxMI355X
+
+const libcoflux = get(ENV, "LIBCOFLUX", "libcoflux.so")
+
+# ---- mirrors of the POD structs in include/coflux.h (field order is the ABI) -----------------
+struct CfGrid
+    nx::Int32; ny::Int32; hx::Int32; hy::Int32; ring::Int32; reserved::Int32
+end
+
+struct CfRoughness
+    kind::Int32; viscosity_kind::Int32
+    constant_length::Float64; maximum_length::Float64; charnock::Float64; laminar::Float64
+    wind_a1::Float64; wind_a2::Float64; wind_umax::Float64
+    reynolds_A::Float64; reynolds_b::Float64
+    viscosity::NTuple{4, Float64}
+end
+
+struct CfThermodynamics
+    gas_constant::Float64; dry_air_molar_mass::Float64; water_molar_mass::Float64; kappa_d::Float64
+    cp_v::Float64; cp_l::Float64; cp_i::Float64; LH_v0::Float64; LH_s0::Float64
+    T_0::Float64; T_triple::Float64; p_triple::Float64; T_freeze::Float64; T_icenuc::Float64; pow_icenuc::Float64
+end
+
+struct CfSeawater
+    water_molar_mass::Float64
+    constituent_molar_mass::NTuple{4, Float64}
+    constituent_mass_fraction::NTuple{4, Float64}
+end
+
+mutable struct CfFluxParams
+    struct_size::Int32; abi_version::Int32
+    similarity_form::Int32; stability_functions::Int32; stop_kind::Int32; maxiter::Int32
+    velocity_difference::Int32; mask_kind::Int32
+    tolerance::Float64; von_karman::Float64; gustiness_parameter::Float64; minimum_gustiness::Float64
+    similarity_profile_floor::Float64
+    momentum_roughness::CfRoughness; temperature_roughness::CfRoughness; water_vapor_roughness::CfRoughness
+    reference_height::Float64; boundary_layer_height::Float64; gravitational_acceleration::Float64
+    thermo::CfThermodynamics; seawater::CfSeawater
+    ocean_reference_density::Float64; ocean_heat_capacity::Float64; ocean_freshwater_density::Float64
+    ocean_temperature_offset::Float64; ocean_minimum_salinity::Float64; ocean_surface_z::Float64
+    ocean_albedo_kind::Int32; penetrating_shortwave::Int32
+    ocean_albedo::Float64; ocean_albedo_diffuse::Float64; ocean_albedo_direct::Float64
+    ocean_emissivity::Float64; stefan_boltzmann::Float64
+    CfFluxParams() = new()
+end
+
+struct CfOceanSurface;   T::Ptr{Float64}; S::Ptr{Float64}; u::Ptr{Float64}; v::Ptr{Float64}; mask::Ptr{Cvoid}; end
+struct CfExchangeFields; u::Ptr{Float64}; v::Ptr{Float64}; T::Ptr{Float64}; p::Ptr{Float64}; q::Ptr{Float64}
+                         Qs::Ptr{Float64}; Ql::Ptr{Float64}; Mp::Ptr{Float64}; end
+struct CfInterfaceFluxes
+    sensible_heat::Ptr{Float64}; latent_heat::Ptr{Float64}; water_vapor::Ptr{Float64}
+    x_momentum::Ptr{Float64}; y_momentum::Ptr{Float64}; temperature::Ptr{Float64}
+    friction_velocity::Ptr{Float64}; temperature_scale::Ptr{Float64}; humidity_scale::Ptr{Float64}
+    iterations::Ptr{Int32}
+end
+struct CfSeaIceFields
+    concentration::Ptr{Float64}; interface_heat::Ptr{Float64}; salt_flux::Ptr{Float64}
+    x_stress::Ptr{Float64}; y_stress::Ptr{Float64}
+end
+struct CfNetOceanFluxes
+    u::Ptr{Float64}; v::Ptr{Float64}; T::Ptr{Float64}; S::Ptr{Float64}; shortwave_surface_flux::Ptr{Float64}
+    upwelling_longwave::Ptr{Float64}; downwelling_longwave::Ptr{Float64}; downwelling_shortwave::Ptr{Float64}
+end
+struct CfAtmosSource
+    data::NTuple{9, Ptr{Float32}}            # tas huss psl uas vas rlds rsds prra prsn (jra55_data_staging.jl:8)
+    ns_x::Int32; ns_y::Int32; n_levels::Int32; level1::Int32; level2::Int32
+    time_fraction::Float64
+end
+struct CfInterpWeights
+    separable::Int32; reserved::Int32
+    fi::Ptr{Float64}; fj::Ptr{Float64}; cos_rot::Ptr{Float64}; sin_rot::Ptr{Float64}; latitude::Ptr{Float64}
+end
+
+# ---- error handling: Julia exceptions on the Julia side, status codes across the ABI ----------
+struct CoFluxError <: Exception; code::Cint; msg::String; end
+last_error(ctx) = unsafe_string(ccall((:cf_last_error, libcoflux), Cstring, (Ptr{Cvoid},), ctx))
+check(ctx, rc) = rc == 0 ? nothing : throw(CoFluxError(rc, last_error(ctx)))
+
+# ---- lifecycle ---------------------------------------------------------------------------------
+mutable struct CoFluxBackend
+    ctx::Ptr{Cvoid}
+    grid::CfGrid
+    params::CfFluxParams
+end
+
+function CoFluxBackend(device::Integer, grid::CfGrid, params::CfFluxParams)
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:cf_create, libcoflux), Cint, (Ref{Ptr{Cvoid}}, Cint, Ref{CfGrid}, Ref{CfFluxParams}),
+               ctx, device, grid, params)
+    rc == 0 || throw(CoFluxError(rc, last_error(C_NULL)))
+    backend = CoFluxBackend(ctx[], grid, params)
+    finalizer(b -> ccall((:cf_destroy, libcoflux), Cint, (Ptr{Cvoid},), b.ctx), backend)
+    return backend
+end
+
+default_flux_params() = (p = CfFluxParams(); ccall((:cf_default_flux_params, libcoflux), Cint, (Ref{CfFluxParams},), p); p)
+
+device_alloc(b, bytes) = ccall((:cf_device_alloc, libcoflux), Ptr{Cvoid}, (Ptr{Cvoid}, Csize_t), b.ctx, bytes)
+h2d!(b, dst, src::Array) = check(b.ctx, ccall((:cf_h2d, libcoflux), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                                              b.ctx, dst, src, sizeof(src)))
+d2h!(b, dst::Array, src) = check(b.ctx, ccall((:cf_d2h, libcoflux), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                                              b.ctx, dst, src, sizeof(dst)))
+sync(b) = check(b.ctx, ccall((:cf_sync, libcoflux), Cint, (Ptr{Cvoid},), b.ctx))
+
+# ---- the three functions of update_state! ------------------------------------------------------
+# Each body is ONE ccall; these are the methods a maintainer adds for
+#   interpolate_atmosphere_state!(interfaces::…{<:CoFluxBackend}, atmosphere, coupled_model) etc.
+interpolate_atmosphere_state!(b::CoFluxBackend, src::CfAtmosSource, w::CfInterpWeights, out::CfExchangeFields) =
+    check(b.ctx, ccall((:cf_interpolate_atmosphere_state, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfAtmosSource}, Ref{CfInterpWeights}, Ref{CfExchangeFields}), b.ctx, src, w, out))
+
+compute_atmosphere_ocean_fluxes!(b::CoFluxBackend, ocean::CfOceanSurface, atmos::CfExchangeFields, out::CfInterfaceFluxes) =
+    check(b.ctx, ccall((:cf_compute_atmosphere_ocean_fluxes, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfOceanSurface}, Ref{CfExchangeFields}, Ref{CfInterfaceFluxes}), b.ctx, ocean, atmos, out))
+
+compute_net_ocean_fluxes!(b::CoFluxBackend, ocean, atmos, fluxes, ice::Union{CfSeaIceFields, Nothing}, w, out::CfNetOceanFluxes) =
+    check(b.ctx, ccall((:cf_compute_net_ocean_fluxes, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfOceanSurface}, Ref{CfExchangeFields}, Ref{CfInterfaceFluxes}, Ptr{CfSeaIceFields},
+                        Ref{CfInterpWeights}, Ref{CfNetOceanFluxes}),
+                       b.ctx, ocean, atmos, fluxes, ice === nothing ? C_NULL : Ref(ice), w, out))
+
+# update_state!(coupled_model): the fused path (one launch for interpolation + solver, one for the net fluxes)
+update_state!(b::CoFluxBackend, src, w, ocean, atmos, fluxes, ice, net) =
+    check(b.ctx, ccall((:cf_update_state, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfAtmosSource}, Ref{CfInterpWeights}, Ref{CfOceanSurface}, Ref{CfExchangeFields},
+                        Ref{CfInterfaceFluxes}, Ptr{CfSeaIceFields}, Ref{CfNetOceanFluxes}),
+                       b.ctx, src, w, ocean, atmos, fluxes, ice === nothing ? C_NULL : Ref(ice), net))
+
+# ---- latitude-slab halo rows over RCCL (Distributed(GPU(), partition = Partition(1, R))) -------
+comm_unique_id() = (id = zeros(UInt8, 128); ccall((:cf_comm_unique_id, libcoflux), Cint, (Ptr{UInt8},), id); id)
+comm_init!(b, id::Vector{UInt8}, rank, nranks) =   # `id` is MPI.bcast from rank 0
+    check(b.ctx, ccall((:cf_comm_init, libcoflux), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), b.ctx, id, rank, nranks))
+halo_exchange_rows!(b, fields::Vector{Ptr{Float64}}, rows = 1) =
+    check(b.ctx, ccall((:cf_halo_exchange_rows, libcoflux), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Cint, Cint),
+                       b.ctx, fields, length(fields), rows))
+
+end # module
