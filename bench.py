@@ -2,8 +2,8 @@
 """bench.py — surface-flux hot path throughput on MI355X (BASELINE.json metric).
 
 A "step" is one update_state! of the coupled model's flux path over one synthetic surface:
-(N>1: one-row halo exchange of the ocean surface state over RCCL) → fused JRA55
-interpolation + Monin–Obukhov solve → net ocean fluxes, all through the C ABI (libcoflux.so).
+(N>1: one-row halo exchange of the ocean surface state over RCCL) → JRA55 interpolation →
+Monin–Obukhov solve → net ocean fluxes, all through the C ABI (libcoflux.so).
 Workload at N = 1 is BASELINE.json configs[1]: the 1/4° 1440×560 surface, JRA55 atmosphere,
 SimilarityTheory fluxes + Radiation, Float64, inputs resident in HBM before the timed region.
 At N > 1 every rank owns one 1440×560 latitude slab of a 1440×(560·N) surface (weak scaling);
@@ -33,7 +33,6 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Algorithmic bytes per surface cell (derivation in DESIGN.md §4)
 BYTES_AO = 128.0                       # compute_atmosphere_ocean_fluxes!: 80 read + 48 written
 BYTES_INTERP = 18.3 + 64.0             # JRA55 window amortised + 8 exchange fields written
-BYTES_FUSED = BYTES_INTERP + BYTES_AO - 40.0   # the 5 atmosphere fields never round-trip through HBM
 BYTES_NET = 88.0 + 40.0
 
 
@@ -142,19 +141,18 @@ def main():
     value = cells_total * a.steps / elapsed
 
     if rank == 0:
-        fused_ms, nrec = ctx.profile_read(0)  # kernel 0 = fused interpolate+solver
-        net_ms, _ = ctx.profile_read(1)
-        # stand-alone stages, HIP events on the launch stream (outside the timed region)
-        ao_ms = ctx.time_stage(abi.STAGE_AO_FLUXES, 20, ocean=ocean, atmos=atmos, fluxes=fl)
-        interp_ms = ctx.time_stage(abi.STAGE_INTERPOLATE, 20, src=src, weights=w, atmos=atmos, time_fraction=0.37)
+        interp_ms, nrec = ctx.profile_read(0)   # per-kernel HIP-event averages over the timed region
+        ao_ms, _ = ctx.profile_read(1)
+        net_ms, _ = ctx.profile_read(2)
         copy_bytes = 256 << 20
         copy_ms = ctx.time_copy(copy_bytes, 20)
-        achieved = BYTES_FUSED * cells_rank / (fused_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel="fused_interp_flux_kernel", achieved=achieved, peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
-                        bytes_per_cell=BYTES_FUSED, cells_per_launch=cells_rank, avg_launch_ms=fused_ms,
-                        launches_timed=nrec)
-        ao_achieved = BYTES_AO * cells_rank / (ao_ms * 1e-3) / 1e9
+
+        def roof(name, nbytes, ncells, ms):
+            achieved = nbytes * ncells / (ms * 1e-3) / 1e9
+            return dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, bytes_per_cell=nbytes, cells_per_launch=ncells,
+                        avg_launch_ms=ms, launches_timed=nrec, cells_per_s=ncells / (ms * 1e-3))
+
         out = dict(metric="flux-kernel surface cells/s (update_state!: JRA55 interp + similarity-theory fluxes + net fluxes)",
                    value=value, unit="cells/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling=a.scaling,
@@ -164,13 +162,11 @@ def main():
                                         f"SimilarityTheoryFluxes(:{a.flux_configuration}) + Radiation, halo {h}, ring 1",
                                global_cells=cells_total, parallelism=f"latitude-slab x{world}",
                                halo_backend=halo.backend),
-                   roofline=roofline,
-                   roofline_ao_fluxes=dict(bound="hbm", kernel="ao_flux_kernel (compute_atmosphere_ocean_fluxes! alone)",
-                                           achieved=ao_achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                                           frac=ao_achieved / HBM_PEAK_GBS, traffic=None, bytes_per_cell=BYTES_AO,
-                                           avg_launch_ms=ao_ms, cells_per_s=cells_rank / (ao_ms * 1e-3)),
-                   stages_ms=dict(fused_interp_flux=fused_ms, net_fluxes=net_ms, ao_fluxes_alone=ao_ms,
-                                  interpolate_alone=interp_ms),
+                   # dominant kernel = compute_atmosphere_ocean_fluxes! (SURVEY.md §8d contract figure 128 B/cell)
+                   roofline=roof("ao_flux_fast_kernel (compute_atmosphere_ocean_fluxes!)", BYTES_AO, cells_rank, ao_ms),
+                   roofline_interpolate=roof("interpolate_kernel (interpolate_atmosphere_state!)", BYTES_INTERP, cells_rank, interp_ms),
+                   roofline_net_fluxes=roof("net_flux_kernel (compute_net_ocean_fluxes!)", BYTES_NET, nx * ny, net_ms),
+                   stages_ms=dict(interpolate=interp_ms, ao_fluxes=ao_ms, net_fluxes=net_ms),
                    device_copy_GBs=2 * copy_bytes / (copy_ms * 1e-3) / 1e9,
                    parity="vs reference: unpinned (self-consistent restatements only; see DESIGN.md)")
         if not a.no_cpu_baseline:

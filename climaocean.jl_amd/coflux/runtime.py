@@ -206,7 +206,7 @@ class FluxContext:
         self._check(self.lib.cf_profile_enable(self._h, max_records), "cf_profile_enable")
 
     def profile_read(self, kernel):
-        """(average ms, records) of kernel 0 (fused interpolate+solver) or 1 (net fluxes)."""
+        """(average ms, records) of kernel 0 (interpolate), 1 (atmosphere–ocean fluxes) or 2 (net fluxes)."""
         ms, n = C.c_double(), C.c_int()
         self._check(self.lib.cf_profile_read(self._h, kernel, C.byref(ms), C.byref(n)), "cf_profile_read")
         return ms.value, n.value

@@ -39,14 +39,14 @@ struct cf_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     FastConsts fast{};
-    LaunchCfg launch{CF_SOLVER_TABLES, 256, 1024, nullptr};
+    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, nullptr};
     double* d_tables = nullptr;
     int tables_kind = -1;
     std::string error;
     // RCCL
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
-    // per-kernel event recorder (cf_profile_enable): 3 events per recorded update_state
+    // per-kernel event recorder (cf_profile_enable): 4 events per recorded update_state
     std::vector<hipEvent_t> prof_events;
     int prof_capacity = 0, prof_count = 0;
 };
@@ -347,7 +347,7 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->launch.solver = value;
             return CF_OK;
         case CF_OPT_INTERP_TILE_CAP:
-            if (value < 16 || value > 1536) return fail(ctx, CF_ERR_INVALID, "interp tile cap %d outside [16, 1536]", value);
+            if (value < 16 || value > 512) return fail(ctx, CF_ERR_INVALID, "interp tile cap %d outside [16, 512]", value);
             ctx->launch.interp_cap = value;
             return CF_OK;
         case CF_OPT_MAX_BLOCKS:
@@ -496,19 +496,19 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     CHECK(check_exchange(ctx, atmos, true));
     CHECK(check_fluxes(ctx, fluxes));
     CHECK(check_net(ctx, net, w));
+    // interpolate → solver → net fluxes, stream-ordered.  (Fusing the interpolation into the solver
+    // saves the 40 B/cell re-read of the atmosphere state — ≈ 6 µs — but ties the FP64-issue-bound
+    // solver to the interpolation's tile geometry and LDS footprint; measured slower, see DESIGN.md.)
     const bool rec = ctx->prof_count < ctx->prof_capacity;
-    hipEvent_t* ev = rec ? &ctx->prof_events[3 * (size_t)ctx->prof_count] : nullptr;
+    hipEvent_t* ev = rec ? &ctx->prof_events[4 * (size_t)ctx->prof_count] : nullptr;
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-    if (ctx->launch.solver == CF_SOLVER_LIBM) {  // cross-check path: unfused
-        HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
-        HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes));
-    } else {
-        HIP_TRY(ctx, launch_fused(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, src, w, ocean, atmos, fluxes));
-    }
+    HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+    HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes));
+    if (rec) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net));
     if (rec) {
-        HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ev[3], ctx->stream));
         ++ctx->prof_count;
     }
     return CF_OK;
@@ -519,20 +519,20 @@ int cf_profile_enable(cf_ctx* ctx, int max_records) {
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     ctx->prof_events.clear();
     ctx->prof_capacity = ctx->prof_count = 0;
-    ctx->prof_events.resize(3 * (size_t)max_records);
+    ctx->prof_events.resize(4 * (size_t)max_records);
     for (auto& e : ctx->prof_events) HIP_TRY(ctx, hipEventCreate(&e));
     ctx->prof_capacity = max_records;
     return CF_OK;
 }
 
 int cf_profile_read(cf_ctx* ctx, int kernel, double* avg_ms, int* records) {
-    if (!ctx || !avg_ms || kernel < 0 || kernel > 1) return fail(ctx, CF_ERR_INVALID, "cf_profile_read: bad arguments");
+    if (!ctx || !avg_ms || kernel < 0 || kernel > 2) return fail(ctx, CF_ERR_INVALID, "cf_profile_read: bad arguments");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     double sum = 0.0;
     for (int n = 0; n < ctx->prof_count; ++n) {
         float ms = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_events[3 * (size_t)n + kernel],
-                                        ctx->prof_events[3 * (size_t)n + kernel + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_events[4 * (size_t)n + kernel],
+                                        ctx->prof_events[4 * (size_t)n + kernel + 1]));
         sum += ms;
     }
     *avg_ms = ctx->prof_count ? sum / ctx->prof_count : 0.0;

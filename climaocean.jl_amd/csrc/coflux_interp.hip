@@ -1,0 +1,179 @@
+// coflux_interp.hip — interpolate_atmosphere_state! on gfx950.
+//
+// JRA55 window (9 variables × 2 time levels, Float32, 640×320) → 8 Float64 exchange fields on
+// the ocean grid: bilinear in (λ, φ), linear in time, rain + snow summed, winds rotated to the
+// grid-intrinsic frame.
+//
+// Design.  The gather (4 corners × 18 planes = 72 dwords per cell) is bound by the vector-memory
+// address path, not by HBM: 72 scattered dword loads per lane cost ≈ 16 cycles each in the
+// texture-address unit.  So every WAVE stages the source footprint of its own 64 × ROWS cell tile
+// in LDS (≈ 31 × 4 source nodes per variable at 1/4°, both time levels interleaved as float2) with
+// ≈ 9 coalesced loads per cell, and then reads each variable's four corners with two 16-byte LDS
+// reads.  Tiles belong to waves, not workgroups: there is no __syncthreads() anywhere, so the
+// waves of a CU hide each other's load latency.
+#include <hip/hip_runtime.h>
+
+#include "coflux_kernel_types.hpp"
+#include "coflux_kernels.h"
+
+namespace coflux {
+
+constexpr int IT_WAVES = 4;  // waves per workgroup (independent of each other)
+
+__device__ __forceinline__ int wrap_index(int i, int n) {
+    int r = i % n;
+    return r < 0 ? r + n : r;
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+
+// LDS traffic of one wave is ordered by issue; this only stops the compiler from moving accesses.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S, WeightDesc Wt, GridDesc G,
+                                                                     Exchange E, int cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2* tile = reinterpret_cast<float2*>(smem) + (size_t)wave * CF_JRA55_NVARS * cap;
+
+    const int wx = G.nx + 2 * G.ring, wy = G.ny + 2 * G.ring;
+    const int tiles_x = (wx + 63) / 64, tiles_y = (wy + ROWS - 1) / ROWS;
+    const int ntiles = tiles_x * tiles_y;
+    const size_t plane = (size_t)S.ns_x * S.ns_y;
+    const size_t off1 = (size_t)S.level1 * plane, off2 = (size_t)S.level2 * plane;
+    const int half = S.ns_x / 2;
+    const bool rotate = Wt.cos_rot != nullptr && Wt.sin_rot != nullptr;
+
+    for (int t = (int)blockIdx.x * IT_WAVES + wave; t < ntiles; t += (int)gridDim.x * IT_WAVES) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int i = tx * 64 + lane - G.ring;
+        const int ic = min(i, G.nx + G.ring - 1);  // out-of-window lanes shadow the last column
+
+        // ---- per-row corner indices and weights ---------------------------------------------------
+        int d0[ROWS], di[ROWS], j0[ROWS], j1[ROWS];
+        double xi[ROWS], eta[ROWS];
+        int lo = INT_MAX, hi = INT_MIN, jlo = INT_MAX, jhi = INT_MIN, ref = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int jc = min(ty * ROWS + r - G.ring, G.ny + G.ring - 1);
+            const size_t k = cell_index(G, ic, jc);
+            const double fi = Wt.separable ? Wt.fi[ic + G.hx] : Wt.fi[k];
+            const double fj = Wt.separable ? Wt.fj[jc + G.hy] : Wt.fj[k];
+            // Oceananigans `interpolator`: i⁻ = trunc(f), i⁺ = i⁻ + sign(f), ξ = f − i⁻
+            const double ti = trunc(fi), tj = trunc(fj);
+            xi[r] = fi - ti;
+            eta[r] = fj - tj;
+            const int i0 = (int)ti;
+            di[r] = fi > 0.0 ? 1 : (fi < 0.0 ? -1 : 0);
+            const int ja = (int)tj;
+            const int jb = ja + (fj > 0.0 ? 1 : (fj < 0.0 ? -1 : 0));
+            j0[r] = min(max(ja, 0), S.ns_y - 1);  // clamped in latitude
+            j1[r] = min(max(jb, 0), S.ns_y - 1);
+            if (r == 0) ref = __shfl(i0, 0);
+            // column offset relative to the tile's reference column, periodic in longitude
+            d0[r] = wrap_index(i0 - ref + half, S.ns_x) - half;
+            lo = min(lo, min(d0[r], d0[r] + di[r]));
+            hi = max(hi, max(d0[r], d0[r] + di[r]));
+            jlo = min(jlo, min(j0[r], j1[r]));
+            jhi = max(jhi, max(j0[r], j1[r]));
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        jlo = wave_min(jlo);
+        jhi = wave_max(jhi);
+        const int W = hi - lo + 1, H = jhi - jlo + 1, WH = W * H;
+        const bool fits = WH <= cap && W <= S.ns_x;
+
+        // ---- stage the footprint: tile[var][y][x] = (level1, level2) -------------------------------
+        if (fits) {
+            const float inv_W = 1.0f / (float)W;
+            for (int rem = lane; rem < WH; rem += 64) {
+                const int y = (int)(((float)rem + 0.5f) * inv_W);
+                const int x = rem - y * W;
+                const size_t off = (size_t)(jlo + y) * S.ns_x + wrap_index(ref + lo + x, S.ns_x);
+#pragma unroll
+                for (int v = 0; v < CF_JRA55_NVARS; ++v)
+                    tile[v * cap + rem] = make_float2(S.data[v][off1 + off], S.data[v][off2 + off]);
+            }
+        }
+        wave_lds_sync();
+
+        // ---- interpolate ---------------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int j = ty * ROWS + r - G.ring;
+            const double w00 = (1.0 - xi[r]) * (1.0 - eta[r]), w01 = (1.0 - xi[r]) * eta[r];
+            const double w10 = xi[r] * (1.0 - eta[r]), w11 = xi[r] * eta[r];
+            double val[CF_JRA55_NVARS];
+            if (fits) {
+                const int o00 = (j0[r] - jlo) * W + (d0[r] - lo), o01 = (j1[r] - jlo) * W + (d0[r] - lo);
+#pragma unroll
+                for (int v = 0; v < CF_JRA55_NVARS; ++v) {
+                    const float2* p = tile + v * cap;
+                    const float2 a00 = p[o00], a10 = p[o00 + di[r]], a01 = p[o01], a11 = p[o01 + di[r]];
+                    const double v1 = w00 * (double)a00.x + w01 * (double)a01.x + w10 * (double)a10.x + w11 * (double)a11.x;
+                    const double v2 = w00 * (double)a00.y + w01 * (double)a01.y + w10 * (double)a10.y + w11 * (double)a11.y;
+                    val[v] = v2 * S.tf + v1 * (1.0 - S.tf);
+                }
+            } else {  // footprint too large for the tile (coarse target grid): gather from L2
+                const int is0 = wrap_index(ref + d0[r], S.ns_x), is1 = wrap_index(ref + d0[r] + di[r], S.ns_x);
+                const size_t g00 = (size_t)j0[r] * S.ns_x + is0, g10 = (size_t)j0[r] * S.ns_x + is1;
+                const size_t g01 = (size_t)j1[r] * S.ns_x + is0, g11 = (size_t)j1[r] * S.ns_x + is1;
+#pragma unroll
+                for (int v = 0; v < CF_JRA55_NVARS; ++v) {
+                    const float* a = S.data[v] + off1;
+                    const float* b = S.data[v] + off2;
+                    const double v1 = w00 * (double)a[g00] + w01 * (double)a[g01] + w10 * (double)a[g10] + w11 * (double)a[g11];
+                    const double v2 = w00 * (double)b[g00] + w01 * (double)b[g01] + w10 * (double)b[g10] + w11 * (double)b[g11];
+                    val[v] = v2 * S.tf + v1 * (1.0 - S.tf);
+                }
+            }
+            if (i < G.nx + G.ring && j < G.ny + G.ring) {
+                const size_t k = cell_index(G, i, j);
+                double ua = val[CF_JRA55_UAS], va = val[CF_JRA55_VAS];
+                if (rotate) {  // intrinsic_vector: geographic (E, N) → grid frame
+                    const double cs = Wt.cos_rot[k], sn = Wt.sin_rot[k];
+                    const double ui = ua * cs + va * sn;
+                    va = -ua * sn + va * cs;
+                    ua = ui;
+                }
+                E.u[k] = ua;
+                E.v[k] = va;
+                E.T[k] = val[CF_JRA55_TAS];
+                E.p[k] = val[CF_JRA55_PSL];
+                E.q[k] = val[CF_JRA55_HUSS];
+                E.Qs[k] = val[CF_JRA55_RSDS];
+                E.Ql[k] = val[CF_JRA55_RLDS];
+                E.Mp[k] = val[CF_JRA55_PRRA] + val[CF_JRA55_PRSN];
+            }
+        }
+        wave_lds_sync();  // the tile is rewritten by this wave's next iteration
+    }
+}
+
+hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
+                              const cf_interp_weights* w, const cf_exchange_fields* e) {
+    constexpr int ROWS = 4;
+    const int wx = G.nx + 2 * G.ring, wy = G.ny + 2 * G.ring;
+    const int ntiles = ((wx + 63) / 64) * ((wy + ROWS - 1) / ROWS);
+    const int blocks = (ntiles + IT_WAVES - 1) / IT_WAVES;
+    const size_t lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(float2);
+    hipLaunchKernelGGL(interpolate_kernel<ROWS>, dim3(blocks), dim3(64 * IT_WAVES), lds, st, make_source(s),
+                       make_weights(w), G, make_exchange(e), L.interp_cap);
+    return hipGetLastError();
+}
+
+}  // namespace coflux

@@ -1,0 +1,124 @@
+// Kernel-side argument bundles shared by the .hip translation units (plain device pointers; built
+// from the C-ABI structs on the host).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "coflux_device.hpp"
+
+namespace coflux {
+
+constexpr int NUM_XCD = 8;
+
+struct SourceDesc {
+    const float* data[CF_JRA55_NVARS];
+    int32_t ns_x, ns_y, level1, level2;
+    double tf;
+};
+
+struct WeightDesc {
+    const double* fi;
+    const double* fj;
+    const double* cos_rot;
+    const double* sin_rot;
+    const double* latitude;
+    int32_t separable;
+};
+
+struct Exchange {
+    double* u;
+    double* v;
+    double* T;
+    double* p;
+    double* q;
+    double* Qs;
+    double* Ql;
+    double* Mp;
+};
+
+struct OceanIn {
+    const double* T;
+    const double* S;
+    const double* u;
+    const double* v;
+    const void* mask;
+};
+
+struct FluxOut {
+    double* Qc;
+    double* Qv;
+    double* Fv;
+    double* tx;
+    double* ty;
+    double* Ts;
+    double* ustar;
+    double* tstar;
+    double* qstar;
+    int32_t* iters;
+};
+
+struct IceIn {
+    const double* conc;
+    const double* Qio;
+    const double* Jsio;
+    const double* txio;
+    const double* tyio;
+};
+
+struct NetOut {
+    double* u;
+    double* v;
+    double* T;
+    double* S;
+    double* sw;
+    double* lw_up;
+    double* lw_down;
+    double* sw_down;
+};
+
+inline SourceDesc make_source(const cf_atmos_source* s) {
+    SourceDesc S;
+    for (int v = 0; v < CF_JRA55_NVARS; ++v) S.data[v] = s->data[v];
+    S.ns_x = s->ns_x;
+    S.ns_y = s->ns_y;
+    S.level1 = s->level1;
+    S.level2 = s->level2;
+    S.tf = s->time_fraction;
+    return S;
+}
+
+inline WeightDesc make_weights(const cf_interp_weights* w) {
+    WeightDesc W{};
+    if (w) {
+        W.fi = w->fi;
+        W.fj = w->fj;
+        W.cos_rot = w->cos_rot;
+        W.sin_rot = w->sin_rot;
+        W.latitude = w->latitude;
+        W.separable = w->separable;
+    }
+    return W;
+}
+
+inline Exchange make_exchange(const cf_exchange_fields* e) {
+    return Exchange{e->u, e->v, e->T, e->p, e->q, e->Qs, e->Ql, e->Mp};
+}
+inline OceanIn make_ocean(const cf_ocean_surface* o) { return OceanIn{o->T, o->S, o->u, o->v, o->mask}; }
+inline FluxOut make_fluxes(const cf_interface_fluxes* f) {
+    return FluxOut{f->sensible_heat, f->latent_heat,       f->water_vapor,       f->x_momentum,     f->y_momentum,
+                   f->temperature,   f->friction_velocity, f->temperature_scale, f->humidity_scale, f->iterations};
+}
+
+__device__ __forceinline__ void store_fluxes(const FluxOut& F, size_t k, const CellFluxes& R) {
+    F.Qc[k] = R.Qc;
+    F.Qv[k] = R.Qv;
+    F.Fv[k] = R.Fv;
+    F.tx[k] = R.rho_tau_x;
+    F.ty[k] = R.rho_tau_y;
+    F.Ts[k] = R.Ts_ocean;
+    if (F.ustar) F.ustar[k] = R.ustar;
+    if (F.tstar) F.tstar[k] = R.tstar;
+    if (F.qstar) F.qstar[k] = R.qstar;
+    if (F.iters) F.iters[k] = R.iterations;
+}
+
+}  // namespace coflux

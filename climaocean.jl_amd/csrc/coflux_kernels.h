@@ -1,4 +1,5 @@
-// Host-visible launchers of the gfx950 kernels (defined in coflux_kernels.hip).
+// Host-visible launchers of the gfx950 kernels (coflux_interp.hip, coflux_solver.hip,
+// coflux_solver_libm.hip, coflux_net.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -10,8 +11,8 @@ struct FastConsts;
 
 struct LaunchCfg {
     int solver;              // CF_SOLVER_*
-    int interp_cap;          // floats per (variable, level) plane of the LDS-staged JRA55 tile
-    int max_blocks;          // persistent grid size (multiple of 8: one share per XCD)
+    int interp_cap;          // float2 entries per variable of a wave's LDS-staged JRA55 tile
+    int max_blocks;          // reserved (persistent-grid experiments)
     const double* d_tables;  // device copy of the solver tables (coflux_tables.cpp)
 };
 
@@ -20,9 +21,8 @@ hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc
 hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const FastConsts& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
                             const cf_interface_fluxes* f);
-hipError_t launch_fused(hipStream_t st, const LaunchCfg& L, const DevParams& P, const FastConsts& C, const GridDesc& G,
-                        const cf_atmos_source* s, const cf_interp_weights* w, const cf_ocean_surface* o,
-                        const cf_exchange_fields* e, const cf_interface_fluxes* f);
+hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
+                                 const cf_exchange_fields* e, const cf_interface_fluxes* f);
 hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_exchange_fields* e, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
                              const cf_interp_weights* w, const cf_net_ocean_fluxes* n);

@@ -1,0 +1,149 @@
+// coflux_solver.hip — compute_atmosphere_ocean_fluxes! on gfx950: the Monin–Obukhov fixed point.
+//
+// One lane = one ocean cell.  The kernel is FP64-issue bound (≈ 250–480 VALU instructions per
+// iteration × 10–20 iterations per cell against 128 algorithmic bytes), so the design goal is to
+// waste no issue slot: ψ/log tables in LDS (coflux_fast.hpp), land compacted away before the
+// iteration, waves leaving the loop on a wave64 ballot, one workgroup per 512-cell chunk so that
+// the hardware dispatcher balances chunks of different wet fraction and trip count.
+#include <hip/hip_runtime.h>
+
+#include "coflux_fast.hpp"
+#include "coflux_kernel_types.hpp"
+#include "coflux_kernels.h"
+
+namespace coflux {
+
+constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
+
+constexpr int AO_BLOCK = 256;
+constexpr int AO_CHUNK = 512;  // cells classified + compacted per pass of a workgroup
+constexpr int AO_LDS_BYTES = TABLE_BYTES + AO_CHUNK * 4 + 16;
+
+// ---- production solver: LDS tables, persistent workgroups ------------------------------------
+template <bool COARE>
+__global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(DevParams P, FastConsts C, GridDesc G, OceanIn O,
+                                                                Exchange E, FluxOut F,
+                                                                const double* __restrict__ g_tab) {
+    // Land cells (≈30 % of a global grid) must not occupy lanes for 10–20 iterations: every chunk of
+    // AO_CHUNK cells is first compacted to the list of its wet cells (land gets its zeros there and
+    // then), and waves then pull 64 list entries at a time from an LDS cursor, so every lane that
+    // enters the solver holds an ocean cell.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tab = reinterpret_cast<double*>(smem);
+    int* list = reinterpret_cast<int*>(smem + TABLE_BYTES);
+    int* counters = list + AO_CHUNK;  // [0] wet count, [1] cursor
+    const int tid = threadIdx.x, lane = tid & 63;
+    stage_tables(tab, g_tab, tid, AO_BLOCK);
+
+    const int wx = G.nx + 2 * G.ring;
+    const int ncells = wx * (G.ny + 2 * G.ring);
+    const int nchunks = (ncells + AO_CHUNK - 1) / AO_CHUNK;
+    const bool fixed = P.stop_kind == CF_STOP_FIXED;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (tid < 2) counters[tid] = 0;
+        __syncthreads();
+        // ---- phase 1: classify, zero land, compact wet cells ------------------------------------
+        const int begin = chunk * AO_CHUNK, end = min(begin + AO_CHUNK, ncells);
+        for (int base = begin; base < end; base += AO_BLOCK) {
+            const int idx = base + tid;
+            const bool in_range = idx < end;
+            bool wet = false;
+            if (in_range) {
+                const int jj = idx / wx;
+                const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+                wet = cell_is_wet(P, O.mask, k);
+                if (!wet) {  // zero_interface_state: all fluxes 0, T = 0 K
+                    CellFluxes Z{};
+                    Z.Ts_ocean = -P.T_offset;
+                    Z.iterations = fixed ? P.maxiter : 0;
+                    store_fluxes(F, k, Z);
+                }
+            }
+            const unsigned long long m = __ballot(wet);
+            int wave_base = 0;
+            if (lane == 0 && m) wave_base = atomicAdd(&counters[0], __popcll(m));
+            wave_base = __shfl(wave_base, 0);
+            if (wet) list[wave_base + __popcll(m & ((1ull << lane) - 1ull))] = idx;
+        }
+        __syncthreads();
+        const int nwet = counters[0];
+        // ---- phase 2: waves pull 64 wet cells at a time ------------------------------------------
+        for (;;) {
+            int start = 0;
+            if (lane == 0) start = atomicAdd(&counters[1], 64);
+            start = __shfl(start, 0);
+            if (start >= nwet) break;
+            const int e = start + lane;
+            const bool in_range = e < nwet;
+            const int idx = list[in_range ? e : nwet - 1];
+            const int jj = idx / wx;
+            const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+            // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
+            const double uo = 0.5 * (O.u[k] + O.u[k + 1]);
+            const double vo = 0.5 * (O.v[k] + O.v[k + (size_t)G.sj]);
+            CellFluxes R = solve_cell_fast<COARE>(P, C, tab, E.u[k], E.v[k], E.T[k], E.p[k], E.q[k], uo, vo, O.T[k],
+                                                  O.S[k], true, in_range);
+            if (in_range) store_fluxes(F, k, R);
+        }
+        __syncthreads();  // list and counters are reused by the next chunk
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// table / primitive self-test: y[n] = fn(x[n]) with the device's fast primitives (tests only)
+// ---------------------------------------------------------------------------------------------
+__global__ void debug_eval_kernel(int fn, int n, const double* __restrict__ x, double* __restrict__ y,
+                                  const double* __restrict__ g_tab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tab = reinterpret_cast<double*>(smem);
+    stage_tables(tab, g_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const double* logt = tab + 4 * PSI_TABLE;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const double v = x[k];
+        double r;
+        switch (fn) {
+            case 0: r = flog(logt, v); break;
+            case 1: r = fexp(v); break;
+            case 2: r = fcbrt(v); break;
+            case 3: r = fsqrt(v); break;
+            case 4: r = frcp(v); break;
+            case 5: r = psi_eval(tab, 0, psi_arg(logt, v)); break;
+            case 6: r = psi_eval(tab, 1, psi_arg(logt, v)); break;
+            case 7: r = __builtin_amdgcn_rcp(v); break;  // raw v_rcp_f64
+            case 8: r = __builtin_amdgcn_rsq(v); break;  // raw v_rsq_f64
+            case 9: {
+                double q = __builtin_amdgcn_rcp(v);
+                r = __builtin_fma(q, __builtin_fma(-v, q, 1.0), q);  // one Newton step
+            } break;
+            default: r = 0.0;
+        }
+        y[k] = r;
+    }
+}
+
+
+hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const FastConsts& C,
+                            const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
+                            const cf_interface_fluxes* f) {
+    if (L.solver == CF_SOLVER_LIBM) return launch_ao_fluxes_libm(st, P, G, o, e, f);
+    OceanIn O = make_ocean(o);
+    Exchange E = make_exchange(e);
+    FluxOut F = make_fluxes(f);
+    const int ncells = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
+    // one workgroup per chunk: the hardware dispatcher is the dynamic load balancer (chunks differ in
+    // their wet fraction and iteration counts); the 34 KB table stage per workgroup comes from L2.
+    dim3 grid(min((ncells + AO_CHUNK - 1) / AO_CHUNK, 1 << 20));
+    if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
+        hipLaunchKernelGGL((ao_flux_fast_kernel<true>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, P, C, G, O, E, F, L.d_tables);
+    else
+        hipLaunchKernelGGL((ao_flux_fast_kernel<false>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, P, C, G, O, E, F, L.d_tables);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_eval(hipStream_t st, const LaunchCfg& L, int fn, int n, const double* x, double* y) {
+    hipLaunchKernelGGL(debug_eval_kernel, dim3(64), dim3(256), TABLE_BYTES, st, fn, n, x, y, L.d_tables);
+    return hipGetLastError();
+}
+
+}  // namespace coflux

@@ -303,8 +303,8 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 
 /* Implementation options (none of them changes what is computed beyond the stated tolerance).  */
 #define CF_OPT_SOLVER 0           /* CF_SOLVER_*                                                   */
-#define CF_OPT_INTERP_TILE_CAP 1  /* floats per (variable, level) plane of the LDS JRA55 tile (256) */
-#define CF_OPT_MAX_BLOCKS 2       /* persistent grid size, multiple of 8 (default 4 per CU = 1024)  */
+#define CF_OPT_INTERP_TILE_CAP 1  /* source nodes per variable in a wave's LDS JRA55 tile (128)      */
+#define CF_OPT_MAX_BLOCKS 2       /* reserved for persistent-grid experiments (multiple of 8)        */
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path, LDS-tabulated ψ/log, ≤1e-12 of libm */
 #define CF_SOLVER_LIBM 1    /* same iteration on ocml's libm (slow; cross-check)                     */
 int cf_set_option(cf_ctx* ctx, int option, int value);
@@ -345,8 +345,7 @@ int cf_compute_net_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean,
                                 const cf_net_ocean_fluxes* out);
 
 /* update_state!(coupled_model) (NEMOTKE/nemo_tke_compute_closure_fields.jl:7-8): the three
- * stages above back to back on the context's stream, with the interpolation fused into the
- * solver kernel (the exchange fields are still written).                                       */
+ * stages above back to back on the context's stream (three launches, no host synchronisation).  */
 int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
                     const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
                     const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice,
@@ -369,11 +368,12 @@ int cf_time_stage(cf_ctx* ctx, int stage, int launches, const cf_atmos_source* s
 int cf_time_copy(cf_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int launches,
                  double* ms_per_launch);
 /* Per-kernel timing INSIDE a caller's timed region: while enabled, cf_update_state brackets each of
- * its kernels with HIP events on the launch stream (no host sync).  cf_profile_read synchronises,
- * returns the average duration of `kernel` (0 = fused interpolate+solver, 1 = net fluxes) over the
- * recorded steps.  cf_profile_enable(ctx, n) (re)arms the recorder for n steps; 0 disables.        */
-#define CF_KERNEL_FUSED_INTERP_FLUX 0
-#define CF_KERNEL_NET_FLUXES 1
+ * its kernels with HIP events on the launch stream (no host sync).  cf_profile_read synchronises and
+ * returns the average duration of `kernel` over the recorded steps.  cf_profile_enable(ctx, n)
+ * (re)arms the recorder for n steps; 0 disables.                                                   */
+#define CF_KERNEL_INTERPOLATE 0
+#define CF_KERNEL_AO_FLUXES 1
+#define CF_KERNEL_NET_FLUXES 2
 int cf_profile_enable(cf_ctx* ctx, int max_records);
 int cf_profile_read(cf_ctx* ctx, int kernel, double* avg_ms, int* records);
 
