@@ -38,8 +38,9 @@ struct cf_ctx {
     DevParams dev{};
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    FastConsts fast{};
-    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, nullptr};
+    LoopParams fast{};
+    DevParams* d_params = nullptr;
+    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, nullptr, nullptr};
     double* d_tables = nullptr;
     int tables_kind = -1;
     std::string error;
@@ -173,17 +174,44 @@ static int lower_params(cf_ctx* ctx, const cf_flux_params* p, DevParams* d) {
     return CF_OK;
 }
 
-static FastConsts fast_consts(const cf_flux_params& p) {
-    FastConsts C{};
+static LoopParams loop_params(const cf_flux_params& p, const DevParams& d) {
+    LoopParams C{};
     auto lg = [](double x) { return x > 0 ? std::log(x) : 0.0; };
-    C.log_lm_t = lg(p.temperature_roughness.maximum_length);
-    C.log_A_t = lg(p.temperature_roughness.reynolds_A);
-    C.log_const_t = lg(p.temperature_roughness.constant_length);
-    C.log_lm_q = lg(p.water_vapor_roughness.maximum_length);
-    C.log_A_q = lg(p.water_vapor_roughness.reynolds_A);
-    C.log_const_q = lg(p.water_vapor_roughness.constant_length);
-    C.log_const_m = lg(p.momentum_roughness.constant_length);
-    C.same_scalar = std::memcmp(&p.temperature_roughness, &p.water_vapor_roughness, sizeof(cf_roughness)) == 0;
+    C.kappa = d.kappa;
+    C.beta_gust = d.beta_gust;
+    C.h_bl = d.h_bl;
+    C.min_gust = d.min_gust;
+    C.h_ref = d.h_ref;
+    C.log_h = d.log_h;
+    C.profile_floor = d.profile_floor;
+    C.tol = d.tol;
+    const cf_roughness &m = p.momentum_roughness, &t = p.temperature_roughness, &q = p.water_vapor_roughness;
+    C.lm_m = m.maximum_length;
+    C.const_m = m.constant_length;
+    C.log_const_m = lg(m.constant_length);
+    C.b_q = q.reynolds_b;
+    C.log_A_q = lg(q.reynolds_A);
+    C.log_lm_q = lg(q.maximum_length);
+    C.log_const_q = lg(q.constant_length);
+    C.b_t = t.reynolds_b;
+    C.log_A_t = lg(t.reynolds_A);
+    C.log_lm_t = lg(t.maximum_length);
+    C.log_const_t = lg(t.constant_length);
+    C.maxiter = p.maxiter;
+    C.fixed = p.stop_kind == CF_STOP_FIXED;
+    C.m_kind = m.kind;
+    C.q_kind = q.kind;
+    C.t_kind = t.kind;
+    C.same_scalar = std::memcmp(&t, &q, sizeof(cf_roughness)) == 0;
+    // branch-free instruction streams for the two production configurations (omip_simulation.jl:42-49, :63-69)
+    const bool gusty = p.minimum_gustiness > 0;  // ⇒ U > 0 ⇒ u★ > 0: no division guards needed
+    if (gusty && m.kind != CF_ROUGHNESS_CONSTANT && q.kind == CF_SCALAR_ROUGHNESS_REYNOLDS && C.same_scalar)
+        C.specialization = SOLVER_OCEAN;
+    else if (gusty && m.kind == CF_ROUGHNESS_CONSTANT && q.kind == CF_SCALAR_ROUGHNESS_CONSTANT &&
+             t.kind == CF_SCALAR_ROUGHNESS_CONSTANT)
+        C.specialization = SOLVER_ICE;
+    else
+        C.specialization = SOLVER_GENERIC;
     return C;
 }
 
@@ -204,7 +232,12 @@ static int install_params(cf_ctx* ctx, const cf_flux_params* params) {
     }
     ctx->params = *params;
     ctx->dev = d;
-    ctx->fast = fast_consts(*params);
+    ctx->fast = loop_params(*params, d);
+    if (!ctx->d_params && hipMalloc((void**)&ctx->d_params, sizeof(DevParams)) != hipSuccess)
+        return fail(ctx, CF_ERR_HIP, "hipMalloc of the device parameter block failed");
+    if (hipMemcpy(ctx->d_params, &d, sizeof(DevParams), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(ctx, CF_ERR_HIP, "upload of the device parameter block failed");
+    ctx->launch.d_params = ctx->d_params;
     return CF_OK;
 }
 
@@ -324,6 +357,7 @@ int cf_destroy(cf_ctx* ctx) {
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->own_stream) {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->own_stream);

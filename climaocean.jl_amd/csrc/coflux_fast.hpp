@@ -189,35 +189,70 @@ __device__ __forceinline__ AirState air_state_fast(const DevParams& P, double p,
     return s;
 }
 
-// log-roughness helper for the scalars: returns log ℓ (and ℓ itself when `need_l`)
-__device__ __forceinline__ double scalar_log_roughness(const cf_roughness& r, const double* logt, double log_A,
-                                                       double log_lm, double log_const, double lu, double us,
-                                                       double inv_nu) {
-    if (r.kind == CF_SCALAR_ROUGHNESS_CONSTANT) return log_const;
-    double Rstar = lu * us * inv_nu;
-    double ll = fmin(__builtin_fma(-r.reynolds_b, flog(logt, Rstar), log_A), log_lm);
-    return us == 0.0 ? log_lm : ll;
+// unguarded log for arguments known to be positive and normal (everything inside the iteration)
+__device__ __forceinline__ double flog_pos(const double* logt, double x) {
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    const int e = (hi >> 20) - 1023;
+    const int k = (hi >> 13) & (LOG_SEG - 1);
+    const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
+    const double2 ck = *reinterpret_cast<const double2*>(logt + 2 * k);
+    const double r = __builtin_fma(m, ck.x, -1.0);
+    double q = __builtin_fma(r, -1.0 / 6.0, 1.0 / 5.0);
+    q = __builtin_fma(r, q, -1.0 / 4.0);
+    q = __builtin_fma(r, q, 1.0 / 3.0);
+    q = __builtin_fma(r, q, -1.0 / 2.0);
+    return __builtin_fma((double)e, 0.6931471805599453094, __builtin_fma(r * r, q, r) + ck.y);
 }
 
-struct FastConsts {  // host-precomputed logs of the roughness constants
-    double log_lm_t, log_A_t, log_const_t;
-    double log_lm_q, log_A_q, log_const_q;
-    double log_const_m;
-    int32_t same_scalar;  // temperature and water-vapour roughness blocks are identical
+__device__ __forceinline__ PsiArg psi_arg_pos(const double* logt, double zeta) {
+    PsiArg a;
+    double w = flog_pos(logt, __builtin_fma(PSI_A, fabs(zeta), 1.0));
+    w = fmin(w, PSI_WMAX);
+    const double s = w * (PSI_SEG / PSI_WMAX);
+    int k = (int)s;
+    k = min(k, PSI_SEG - 1);
+    a.k = k;
+    a.t = __builtin_fma(2.0, s - (double)k, -1.0);
+    a.side = zeta < 0.0 ? 0 : 1;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Parameter split.  The iteration touches ~25 uniform scalars; the per-cell prologue touches ~60
+// more.  Passing all of DevParams by value makes the compiler hoist every field into SGPRs and
+// then spill them to VGPR lanes (77 v_readlane per iteration were measured).  So: LoopParams rides
+// in the kernarg segment (SGPRs), and the prologue reads DevParams from an LDS copy.
+// ---------------------------------------------------------------------------------------------
+struct LoopParams {
+    double kappa, beta_gust, h_bl, min_gust, h_ref, log_h, profile_floor, tol;
+    double lm_m, const_m, log_const_m;                          // momentum roughness
+    double b_q, log_A_q, log_lm_q, log_const_q;                 // water-vapour roughness
+    double b_t, log_A_t, log_lm_t, log_const_t;                 // temperature roughness
+    int32_t maxiter, fixed, m_kind, q_kind, t_kind, same_scalar;
+    int32_t specialization;  // SOLVER_OCEAN / SOLVER_ICE / SOLVER_GENERIC (host-selected)
     int32_t pad;
 };
 
-template <bool COARE>
-__device__ __forceinline__ CellFluxes solve_cell_fast(const DevParams& P, const FastConsts& C, const double* tab,
-                                                      double ua, double va, double Ta, double pa, double qa, double uo,
-                                                      double vo, double To, double So, bool wet, bool in_range) {
-    const double* psi = tab;
-    const double* logt = tab + 4 * PSI_TABLE;
-    CellFluxes R;
+constexpr int SOLVER_OCEAN = 0;    // Charnock-type momentum roughness, identical Reynolds-scaled scalars, U_G,min > 0
+constexpr int SOLVER_ICE = 1;      // constant roughness lengths, U_G,min > 0
+constexpr int SOLVER_GENERIC = 2;  // anything else (runtime kinds, u★ = 0 guards)
+
+using FastConsts = LoopParams;  // name kept for the launcher signatures
+
+struct CellConsts {
+    // iteration
+    double gTv, b_theta, b_q, dU2, U_calm, dtheta, dq, alpha_g, lam_nu, inv_nu_q, inv_nu_t;
+    // epilogue
+    double du, dv, dU, rho, cp_m, Lv, Ts;
+};
+
+// Per-cell, iteration-invariant state.  `P` should point at the LDS copy of DevParams.
+__device__ __forceinline__ CellConsts cell_prologue(const DevParams& P, double min_gust, const double* logt, double ua,
+                                                    double va, double Ta, double pa, double qa, double uo, double vo,
+                                                    double To, double So) {
+    CellConsts c;
     const double Ts = To + P.T_offset;
     const double inv_Ta = frcp(Ta), inv_Ts = frcp(Ts);
-
-    // --- iteration-invariant state -------------------------------------------------------------
     const double lam_a = liquid_fraction_fast(P, logt, Ta);
     const double pvs_a = svp_equil_fast(P, logt, Ta, inv_Ta, lam_a);
     const AirState A = air_state_fast(P, pa, Ta, inv_Ta, qa, lam_a, pvs_a);
@@ -226,88 +261,137 @@ __device__ __forceinline__ CellFluxes solve_cell_fast(const DevParams& P, const 
     const double sal = So * 1e-3;
     const double x_h2o = P.sw_inv_w * frcp(__builtin_fma(sal * frcp(1.0 - sal), P.sw_inv_mu, P.sw_inv_w));
     const double qs = x_h2o * pstar_s * frcp(A.rho * P.R_v * Ts);
-    const double dq = A.q_vap - qs;
-    const double dtheta = Ta + P.g * P.h_ref * frcp(A.cp_m) - Ts;
+    c.dq = A.q_vap - qs;
+    c.dtheta = Ta + P.g * P.h_ref * frcp(A.cp_m) - Ts;
     double du = ua, dv = va;
     if (P.velocity_difference == CF_VELOCITY_RELATIVE) {
         du = ua - uo;
         dv = va - vo;
     }
-    const double dU2 = du * du + dv * dv;
-    const double dU = fsqrt(dU2);
+    c.du = du;
+    c.dv = dv;
+    c.dU2 = du * du + dv * dv;
+    c.dU = fsqrt(c.dU2);
+    c.U_calm = fsqrt1(__builtin_fma(min_gust, min_gust, c.dU2));  // U when the gustiness sits at its floor
 
     const double lam_s = liquid_fraction_fast(P, logt, Ts);
     const double pvs_s = (lam_s == 1.0) ? pstar_s : svp_equil_fast(P, logt, Ts, inv_Ts, lam_s);
     const AirState Sfc = air_state_fast(P, pa, Ts, inv_Ts, qs, lam_s, pvs_s);
-    const double g_over_Tv = P.g * frcp(Sfc.T_virtual);
-    const double b_theta = 1.0 + P.delta * Sfc.q_vap;
-    const double b_q = P.delta * Sfc.T_virtual;
+    c.gTv = P.g * frcp(Sfc.T_virtual);
+    c.b_theta = 1.0 + P.delta * Sfc.q_vap;
+    c.b_q = P.delta * Sfc.T_virtual;
 
     const double nu_m = air_viscosity(P.rm, Ts);
-    const double inv_nu_t = frcp(air_viscosity(P.rt, Ts));
-    const double inv_nu_q = frcp(air_viscosity(P.rq, Ts));
+    c.inv_nu_t = frcp(air_viscosity(P.rt, Ts));
+    c.inv_nu_q = frcp(air_viscosity(P.rq, Ts));
     double alpha = P.rm.charnock;
     if (P.rm.kind == CF_ROUGHNESS_WIND_CHARNOCK)
-        alpha = fmax(P.rm.charnock, P.rm.wind_a1 * fmin(dU, P.rm.wind_umax) + P.rm.wind_a2);
-    const double lam_nu = P.rm.laminar * nu_m;
-    const double alpha_g = alpha * P.inv_g;
+        alpha = fmax(P.rm.charnock, P.rm.wind_a1 * fmin(c.dU, P.rm.wind_umax) + P.rm.wind_a2);
+    c.lam_nu = P.rm.laminar * nu_m;
+    c.alpha_g = alpha * P.inv_g;
+    c.rho = A.rho;
+    c.cp_m = A.cp_m;
+    c.Lv = P.LH_v0 + (P.cp_v - P.cp_l) * (Ta - P.T_0);
+    c.Ts = Ts;
+    return c;
+}
 
-    // --- the fixed point -----------------------------------------------------------------------
+// log ℓ of one scalar for the generic path
+__device__ __forceinline__ double scalar_log_roughness(int kind, double b, double log_A, double log_lm, double log_const,
+                                                       const double* logt, double lu, double us, double inv_nu) {
+    if (kind == CF_SCALAR_ROUGHNESS_CONSTANT) return log_const;
+    const double Rstar = lu * us * inv_nu;
+    const double ll = fmin(__builtin_fma(-b, flog(logt, Rstar), log_A), log_lm);
+    return us == 0.0 ? log_lm : ll;
+}
+
+struct Scales {
+    double us, ts, qq;
+    int it;
+};
+
+// The fixed point.  SPEC selects a branch-free instruction stream for the two production
+// configurations; SOLVER_GENERIC keeps every runtime switch and the u★ = 0 guards.
+// All 64 lanes of a wave must call this together (wave64 ballot inside); `active` lanes iterate.
+template <bool COARE, int SPEC>
+__device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellConsts& c, const double* tab, bool active) {
+    const double* psi = tab;
+    const double* logt = tab + 4 * PSI_TABLE;
     double us = 1e-4, ts = 1e-4, qq = 1e-4;
     double drift = 0.0;
     int it = 0;
-    const bool fixed = P.stop_kind == CF_STOP_FIXED;
-    const bool participates = in_range && (fixed || wet);
     for (;;) {
         bool go;
-        if (fixed) {
-            go = participates && it < P.maxiter;
-        } else {
-            go = participates && ((it == 0) || !(drift < P.tol || it >= P.maxiter));
-        }
+        if (L.fixed)
+            go = active && it < L.maxiter;
+        else
+            go = active && ((it == 0) || !(drift < L.tol || it >= L.maxiter));
         if (__ballot(go) == 0ull) break;  // the wave leaves the loop together
         if (go) {
-            const double bstar = g_over_Tv * __builtin_fma(ts, b_theta, b_q * qq);
+            const double bstar = c.gTv * __builtin_fma(ts, c.b_theta, c.b_q * qq);
             const double Jb = -us * bstar;
-            double Ug = P.min_gust;
-            if (P.beta_gust != 0.0) Ug = fmax(P.beta_gust * fcbrt(fmax(Jb, 0.0) * P.h_bl), P.min_gust);
-            const double U = fsqrt1(__builtin_fma(Ug, Ug, dU2));
+            // gustiness: U_G = max(β·cbrt(max(Jᵇ,0)·h_bl), U_G,min); the cube root only where Jᵇ > 0
+            double U = c.U_calm;
+            if (L.beta_gust != 0.0 && __any(Jb > 0.0)) {
+                const double Ug = fmax(L.beta_gust * fcbrt(fmax(Jb, 0.0) * L.h_bl), L.min_gust);
+                const double Uc = fsqrt1(__builtin_fma(Ug, Ug, c.dU2));
+                U = Jb > 0.0 ? Uc : c.U_calm;
+            }
 
             const double inv_us = frcp1(us);
-            double lu, log_lu;
-            if (P.rm.kind == CF_ROUGHNESS_CONSTANT) {
-                lu = P.rm.constant_length;
-                log_lu = C.log_const_m;
+            double lu, log_lu, log_lq, log_lt;
+            if constexpr (SPEC == SOLVER_OCEAN) {
+                lu = fmin(__builtin_fma(c.alpha_g * us, us, c.lam_nu * inv_us), L.lm_m);
+                log_lu = flog_pos(logt, lu);
+                log_lq = fmin(__builtin_fma(-L.b_q, flog_pos(logt, lu * us * c.inv_nu_q), L.log_A_q), L.log_lm_q);
+                log_lt = log_lq;
+            } else if constexpr (SPEC == SOLVER_ICE) {
+                lu = L.const_m;
+                log_lu = L.log_const_m;
+                log_lq = L.log_const_q;
+                log_lt = L.log_const_t;
             } else {
-                const double lm = P.rm.maximum_length;
-                const double lR = (us == 0.0) ? lm : lam_nu * inv_us;
-                lu = fmin(__builtin_fma(alpha_g * us, us, lR), lm);
-                log_lu = flog(logt, lu);
+                if (L.m_kind == CF_ROUGHNESS_CONSTANT) {
+                    lu = L.const_m;
+                    log_lu = L.log_const_m;
+                } else {
+                    const double lR = (us == 0.0) ? L.lm_m : c.lam_nu * inv_us;
+                    lu = fmin(__builtin_fma(c.alpha_g * us, us, lR), L.lm_m);
+                    log_lu = flog(logt, lu);
+                }
+                log_lq = scalar_log_roughness(L.q_kind, L.b_q, L.log_A_q, L.log_lm_q, L.log_const_q, logt, lu, us, c.inv_nu_q);
+                log_lt = L.same_scalar ? log_lq
+                                       : scalar_log_roughness(L.t_kind, L.b_t, L.log_A_t, L.log_lm_t, L.log_const_t, logt,
+                                                              lu, us, c.inv_nu_t);
             }
-            const double log_lq = scalar_log_roughness(P.rq, logt, C.log_A_q, C.log_lm_q, C.log_const_q, lu, us, inv_nu_q);
-            const double log_lt = C.same_scalar ? log_lq
-                                                : scalar_log_roughness(P.rt, logt, C.log_A_t, C.log_lm_t, C.log_const_t,
-                                                                       lu, us, inv_nu_t);
 
             // 1/L★ = −κ b★ / u★²  (0 when b★ = 0)
-            const double inv_L = (bstar == 0.0) ? 0.0 : -(P.kappa * bstar) * (inv_us * inv_us);
-            const PsiArg ah = psi_arg(logt, P.h_ref * inv_L);
-            double Du = P.log_h - log_lu - psi_eval(psi, 0, ah);
+            double inv_L = -(L.kappa * bstar) * (inv_us * inv_us);
+            if constexpr (SPEC == SOLVER_GENERIC) inv_L = (bstar == 0.0) ? 0.0 : inv_L;
+            const PsiArg ah = psi_arg_pos(logt, L.h_ref * inv_L);
+            double Du = L.log_h - log_lu - psi_eval(psi, 0, ah);
             const double psi_hh = psi_eval(psi, 1, ah);
-            double Dq = P.log_h - log_lq - psi_hh;
-            double Dt = P.log_h - log_lt - psi_hh;
+            double Dq = L.log_h - log_lq - psi_hh;
+            double Dt = L.log_h - log_lt - psi_hh;
             if constexpr (!COARE) {
-                Du += psi_eval(psi, 0, psi_arg(logt, lu * inv_L));
-                const double psi_lq = psi_eval(psi, 1, psi_arg(logt, fexp(log_lq) * inv_L));
+                Du += psi_eval(psi, 0, psi_arg_pos(logt, lu * inv_L));
+                const double psi_lq = psi_eval(psi, 1, psi_arg_pos(logt, fexp(log_lq) * inv_L));
                 Dq += psi_lq;
-                Dt += C.same_scalar ? psi_lq : psi_eval(psi, 1, psi_arg(logt, fexp(log_lt) * inv_L));
+                if constexpr (SPEC == SOLVER_OCEAN)
+                    Dt = Dq;
+                else
+                    Dt += (L.same_scalar && SPEC != SOLVER_ICE) ? psi_lq
+                                                                : psi_eval(psi, 1, psi_arg_pos(logt, fexp(log_lt) * inv_L));
             }
-            Du = fmax(Du, P.profile_floor);
-            Dq = fmax(Dq, P.profile_floor);
-            Dt = fmax(Dt, P.profile_floor);
-            const double chi_q = P.kappa * frcp1(Dq);
-            const double chi_t = C.same_scalar ? chi_q : P.kappa * frcp1(Dt);
-            const double un = P.kappa * frcp1(Du) * U, tn = chi_t * dtheta, qn = chi_q * dq;
+            Du = fmax(Du, L.profile_floor);
+            Dq = fmax(Dq, L.profile_floor);
+            const double chi_q = L.kappa * frcp1(Dq);
+            double chi_t = chi_q;
+            if constexpr (SPEC != SOLVER_OCEAN) {
+                Dt = fmax(Dt, L.profile_floor);
+                chi_t = L.kappa * frcp1(Dt);
+            }
+            const double un = L.kappa * frcp1(Du) * U, tn = chi_t * c.dtheta, qn = chi_q * c.dq;
             drift = fabs(un - us) + fabs(tn - ts) + fabs(qn - qq);
             us = un;
             ts = tn;
@@ -315,23 +399,24 @@ __device__ __forceinline__ CellFluxes solve_cell_fast(const DevParams& P, const 
             ++it;
         }
     }
+    return Scales{us, ts, qq, it};
+}
 
-    const bool zero = !wet;
-    if (zero) us = ts = qq = 0.0;
-    const double inv_dU = (dU == 0.0) ? 0.0 : frcp(dU);
-    const double tau = -us * us * inv_dU;
-    const double Lv = P.LH_v0 + (P.cp_v - P.cp_l) * (Ta - P.T_0);
-    const double rho_u = A.rho * us;
-    R.Fv = -rho_u * qq;
-    R.Qv = R.Fv * Lv;
-    R.Qc = -rho_u * A.cp_m * ts;
-    R.rho_tau_x = A.rho * tau * du;
-    R.rho_tau_y = A.rho * tau * dv;
-    R.Ts_ocean = (zero ? 0.0 : Ts) - P.T_offset;
-    R.ustar = us;
-    R.tstar = ts;
-    R.qstar = qq;
-    R.iterations = it;
+__device__ __forceinline__ CellFluxes cell_epilogue(const CellConsts& c, double T_offset, Scales s) {
+    CellFluxes R;
+    const double inv_dU = (c.dU == 0.0) ? 0.0 : frcp(c.dU);
+    const double tau = -s.us * s.us * inv_dU;
+    const double rho_u = c.rho * s.us;
+    R.Fv = -rho_u * s.qq;
+    R.Qv = R.Fv * c.Lv;
+    R.Qc = -rho_u * c.cp_m * s.ts;
+    R.rho_tau_x = c.rho * tau * c.du;
+    R.rho_tau_y = c.rho * tau * c.dv;
+    R.Ts_ocean = c.Ts - T_offset;
+    R.ustar = s.us;
+    R.tstar = s.ts;
+    R.qstar = s.qq;
+    R.iterations = s.it;
     return R;
 }
 

@@ -7,18 +7,19 @@
 
 namespace coflux {
 
-struct FastConsts;
+struct LoopParams;
 
 struct LaunchCfg {
     int solver;              // CF_SOLVER_*
     int interp_cap;          // float2 entries per variable of a wave's LDS-staged JRA55 tile
     int max_blocks;          // reserved (persistent-grid experiments)
     const double* d_tables;  // device copy of the solver tables (coflux_tables.cpp)
+    const DevParams* d_params;  // device copy of DevParams (the solver stages it in LDS)
 };
 
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
                               const cf_interp_weights* w, const cf_exchange_fields* e);
-hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const FastConsts& C,
+hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
                             const cf_interface_fluxes* f);
 hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,

@@ -17,13 +17,14 @@ constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 
 constexpr int AO_BLOCK = 256;
 constexpr int AO_CHUNK = 512;  // cells classified + compacted per pass of a workgroup
-constexpr int AO_LDS_BYTES = TABLE_BYTES + AO_CHUNK * 4 + 16;
+constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + 16;
+constexpr int AO_LDS_BYTES = AO_PARAMS_OFFSET + (int)sizeof(DevParams);
 
 // ---- production solver: LDS tables, persistent workgroups ------------------------------------
-template <bool COARE>
-__global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(DevParams P, FastConsts C, GridDesc G, OceanIn O,
-                                                                Exchange E, FluxOut F,
-                                                                const double* __restrict__ g_tab) {
+template <bool COARE, int SPEC>
+__global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, GridDesc G, OceanIn O, Exchange E,
+                                                                FluxOut F, const double* __restrict__ g_tab,
+                                                                const DevParams* __restrict__ g_params) {
     // Land cells (≈30 % of a global grid) must not occupy lanes for 10–20 iterations: every chunk of
     // AO_CHUNK cells is first compacted to the list of its wet cells (land gets its zeros there and
     // then), and waves then pull 64 list entries at a time from an LDS cursor, so every lane that
@@ -32,13 +33,17 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(DevParams P, Fas
     double* tab = reinterpret_cast<double*>(smem);
     int* list = reinterpret_cast<int*>(smem + TABLE_BYTES);
     int* counters = list + AO_CHUNK;  // [0] wet count, [1] cursor
+    DevParams* lp = reinterpret_cast<DevParams*>(smem + AO_PARAMS_OFFSET);
     const int tid = threadIdx.x, lane = tid & 63;
     stage_tables(tab, g_tab, tid, AO_BLOCK);
+    for (int n = tid; n < (int)(sizeof(DevParams) / sizeof(double)); n += AO_BLOCK)
+        reinterpret_cast<double*>(lp)[n] = reinterpret_cast<const double*>(g_params)[n];
+    const DevParams& P = *lp;  // prologue-only parameters live in LDS, not in SGPRs
+    const double* logt = tab + 4 * PSI_TABLE;
 
     const int wx = G.nx + 2 * G.ring;
     const int ncells = wx * (G.ny + 2 * G.ring);
     const int nchunks = (ncells + AO_CHUNK - 1) / AO_CHUNK;
-    const bool fixed = P.stop_kind == CF_STOP_FIXED;
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         if (tid < 2) counters[tid] = 0;
         __syncthreads();
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(DevParams P, Fas
                 if (!wet) {  // zero_interface_state: all fluxes 0, T = 0 K
                     CellFluxes Z{};
                     Z.Ts_ocean = -P.T_offset;
-                    Z.iterations = fixed ? P.maxiter : 0;
+                    Z.iterations = L.fixed ? L.maxiter : 0;
                     store_fluxes(F, k, Z);
                 }
             }
@@ -81,9 +86,10 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(DevParams P, Fas
             // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
             const double uo = 0.5 * (O.u[k] + O.u[k + 1]);
             const double vo = 0.5 * (O.v[k] + O.v[k + (size_t)G.sj]);
-            CellFluxes R = solve_cell_fast<COARE>(P, C, tab, E.u[k], E.v[k], E.T[k], E.p[k], E.q[k], uo, vo, O.T[k],
-                                                  O.S[k], true, in_range);
-            if (in_range) store_fluxes(F, k, R);
+            const CellConsts c = cell_prologue(P, L.min_gust, logt, E.u[k], E.v[k], E.T[k], E.p[k], E.q[k], uo, vo,
+                                               O.T[k], O.S[k]);
+            const Scales s = mo_iterate<COARE, SPEC>(L, c, tab, in_range);
+            if (in_range) store_fluxes(F, k, cell_epilogue(c, P.T_offset, s));
         }
         __syncthreads();  // list and counters are reused by the next chunk
     }
@@ -123,7 +129,25 @@ __global__ void debug_eval_kernel(int fn, int n, const double* __restrict__ x, d
 }
 
 
-hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const FastConsts& C,
+template <bool COARE>
+static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const LoopParams& C, const GridDesc& G,
+                           const OceanIn& O, const Exchange& E, const FluxOut& F) {
+    switch (C.specialization) {
+        case SOLVER_OCEAN:
+            hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_OCEAN>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O,
+                               E, F, L.d_tables, L.d_params);
+            break;
+        case SOLVER_ICE:
+            hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_ICE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O, E,
+                               F, L.d_tables, L.d_params);
+            break;
+        default:
+            hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_GENERIC>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G,
+                               O, E, F, L.d_tables, L.d_params);
+    }
+}
+
+hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
                             const cf_interface_fluxes* f) {
     if (L.solver == CF_SOLVER_LIBM) return launch_ao_fluxes_libm(st, P, G, o, e, f);
@@ -132,12 +156,12 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     FluxOut F = make_fluxes(f);
     const int ncells = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
     // one workgroup per chunk: the hardware dispatcher is the dynamic load balancer (chunks differ in
-    // their wet fraction and iteration counts); the 34 KB table stage per workgroup comes from L2.
+    // their wet fraction and iteration counts); the 35 KB table/parameter stage per workgroup comes from L2.
     dim3 grid(min((ncells + AO_CHUNK - 1) / AO_CHUNK, 1 << 20));
     if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
-        hipLaunchKernelGGL((ao_flux_fast_kernel<true>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, P, C, G, O, E, F, L.d_tables);
+        launch_ao_spec<true>(st, grid, L, C, G, O, E, F);
     else
-        hipLaunchKernelGGL((ao_flux_fast_kernel<false>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, P, C, G, O, E, F, L.d_tables);
+        launch_ao_spec<false>(st, grid, L, C, G, O, E, F);
     return hipGetLastError();
 }
 
