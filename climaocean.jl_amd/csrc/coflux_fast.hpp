@@ -128,18 +128,32 @@ __device__ __forceinline__ PsiArg psi_arg(const double* logt, double zeta) {
     return a;
 }
 
-// fn: 0 = ψ_m, 1 = ψ_h
+// fn: 0 = ψ_m, 1 = ψ_h.  Table layout: [side][coefficient][segment]{ψ_m, ψ_h} (coflux_tables.cpp).
 __device__ __forceinline__ double psi_eval(const double* psi, int fn, const PsiArg& a) {
-    const double* c = psi + (2 * fn + a.side) * PSI_TABLE + a.k;
-    double p = c[7 * PSI_SEG];
-    p = __builtin_fma(p, a.t, c[6 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[5 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[4 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[3 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[2 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[1 * PSI_SEG]);
+    const double* c = psi + ((size_t)(a.side * (PSI_DEG + 1)) * PSI_SEG + a.k) * 2 + fn;
+    double p = c[7 * 2 * PSI_SEG];
+    p = __builtin_fma(p, a.t, c[6 * 2 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[5 * 2 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[4 * 2 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[3 * 2 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[2 * 2 * PSI_SEG]);
+    p = __builtin_fma(p, a.t, c[1 * 2 * PSI_SEG]);
     p = __builtin_fma(p, a.t, c[0]);
     return p;
+}
+
+// ψ_m and ψ_h at the same argument: eight 16-byte LDS reads feed both Horner chains
+__device__ __forceinline__ double2 psi_eval_pair(const double* psi, const PsiArg& a) {
+    const double2* c = reinterpret_cast<const double2*>(psi) + (size_t)(a.side * (PSI_DEG + 1)) * PSI_SEG + a.k;
+    double2 v = c[7 * PSI_SEG];
+    double pm = v.x, ph = v.y;
+#pragma unroll
+    for (int j = 6; j >= 0; --j) {
+        v = c[j * PSI_SEG];
+        pm = __builtin_fma(pm, a.t, v.x);
+        ph = __builtin_fma(ph, a.t, v.y);
+    }
+    return make_double2(pm, ph);
 }
 
 // Cooperative copy of the tables into LDS (call once per workgroup, then __syncthreads()).
@@ -369,8 +383,9 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
             double inv_L = -(L.kappa * bstar) * (inv_us * inv_us);
             if constexpr (SPEC == SOLVER_GENERIC) inv_L = (bstar == 0.0) ? 0.0 : inv_L;
             const PsiArg ah = psi_arg_pos(logt, L.h_ref * inv_L);
-            double Du = L.log_h - log_lu - psi_eval(psi, 0, ah);
-            const double psi_hh = psi_eval(psi, 1, ah);
+            const double2 psi_h2 = psi_eval_pair(psi, ah);
+            double Du = L.log_h - log_lu - psi_h2.x;
+            const double psi_hh = psi_h2.y;
             double Dq = L.log_h - log_lq - psi_hh;
             double Dt = L.log_h - log_lt - psi_hh;
             if constexpr (!COARE) {

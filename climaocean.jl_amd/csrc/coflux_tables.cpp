@@ -116,8 +116,10 @@ void cheb_fit_monomial(F f, double* out /* PSI_DEG+1 */) {
 
 }  // namespace
 
-// Layout (doubles): table τ ∈ {ψm unstable, ψm stable, ψh unstable, ψh stable}, coefficient-major:
-//   psi[τ * PSI_TABLE + c * PSI_SEG + k],  then the log table  logt[2*k] = 1/c_k, logt[2*k+1] = log c_k.
+// Layout (doubles): side σ ∈ {0: ζ < 0, 1: ζ ≥ 0}, coefficient-major, ψm and ψh interleaved so that one
+// 16-byte LDS read returns the coefficient of both functions:
+//   psi[((σ * (PSI_DEG+1) + c) * PSI_SEG + k) * 2 + fn],   fn = 0: ψm, 1: ψh
+// then the log table  logt[2*k] = 1/c_k, logt[2*k+1] = log c_k.
 std::vector<double> build_solver_tables(int stability_kind) {
     std::vector<double> t(TABLE_DOUBLES, 0.0);
     const long double dw = (long double)PSI_WMAX / PSI_SEG;
@@ -131,7 +133,9 @@ std::vector<double> build_solver_tables(int stability_kind) {
                 return scalar ? psi_h_exact(stability_kind, unstable, az) : psi_m_exact(stability_kind, unstable, az);
             };
             cheb_fit_monomial(f, coef);
-            for (int c = 0; c <= PSI_DEG; ++c) t[(size_t)tau * PSI_TABLE + (size_t)c * PSI_SEG + k] = coef[c];
+            const int side = unstable ? 0 : 1, fn = scalar ? 1 : 0;
+            for (int c = 0; c <= PSI_DEG; ++c)
+                t[(((size_t)side * (PSI_DEG + 1) + c) * PSI_SEG + k) * 2 + fn] = coef[c];
         }
     }
     double* lt = t.data() + 4 * PSI_TABLE;
