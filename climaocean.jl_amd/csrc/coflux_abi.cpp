@@ -40,7 +40,8 @@ struct cf_ctx {
     hipStream_t stream = nullptr;
     LoopParams fast{};
     DevParams* d_params = nullptr;
-    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, nullptr, nullptr};
+    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, nullptr, nullptr, nullptr};
+    uint8_t* d_hint = nullptr;
     double* d_tables = nullptr;
     int tables_kind = -1;
     std::string error;
@@ -344,6 +345,12 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
         cf_destroy(ctx);
         return rc;
     }
+    const size_t hint_bytes = (size_t)ctx->grid.sj * (grid->ny + 2 * grid->hy);
+    if (hipMalloc((void**)&ctx->d_hint, hint_bytes) != hipSuccess || hipMemset(ctx->d_hint, 0, hint_bytes) != hipSuccess) {
+        cf_destroy(ctx);
+        return fail(nullptr, CF_ERR_HIP, "hipMalloc of the trip-count hints failed");
+    }
+    ctx->launch.d_hint = ctx->d_hint;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->launch.max_blocks = ((4 * prop.multiProcessorCount + 7) / 8) * 8;
@@ -357,6 +364,7 @@ int cf_destroy(cf_ctx* ctx) {
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_hint) (void)hipFree(ctx->d_hint);
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->own_stream) {
         hipSetDevice(ctx->device);
@@ -387,6 +395,9 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
         case CF_OPT_MAX_BLOCKS:
             if (value < 8 || value % 8) return fail(ctx, CF_ERR_INVALID, "max blocks %d must be a positive multiple of 8", value);
             ctx->launch.max_blocks = value;
+            return CF_OK;
+        case CF_OPT_TRIP_HINTS:
+            ctx->launch.d_hint = value ? ctx->d_hint : nullptr;
             return CF_OK;
         default: return fail(ctx, CF_ERR_INVALID, "unknown option %d", option);
     }

@@ -15,6 +15,7 @@ struct LaunchCfg {
     int max_blocks;          // reserved (persistent-grid experiments)
     const double* d_tables;  // device copy of the solver tables (coflux_tables.cpp)
     const DevParams* d_params;  // device copy of DevParams (the solver stages it in LDS)
+    uint8_t* d_hint;            // per-cell trip count of the previous call (scheduling hint) or NULL
 };
 
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,

@@ -17,14 +17,16 @@ constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 
 constexpr int AO_BLOCK = 256;
 constexpr int AO_CHUNK = 512;  // cells classified + compacted per pass of a workgroup
-constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + 16;
+constexpr int AO_BINS = 32;     // trip-count bins of the per-chunk counting sort
+constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + 16 + 2 * AO_BINS * 4;
 constexpr int AO_LDS_BYTES = AO_PARAMS_OFFSET + (int)sizeof(DevParams);
 
 // ---- production solver: LDS tables, persistent workgroups ------------------------------------
 template <bool COARE, int SPEC>
 __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, GridDesc G, OceanIn O, Exchange E,
                                                                 FluxOut F, const double* __restrict__ g_tab,
-                                                                const DevParams* __restrict__ g_params) {
+                                                                const DevParams* __restrict__ g_params,
+                                                                uint8_t* __restrict__ hint) {
     // Land cells (≈30 % of a global grid) must not occupy lanes for 10–20 iterations: every chunk of
     // AO_CHUNK cells is first compacted to the list of its wet cells (land gets its zeros there and
     // then), and waves then pull 64 list entries at a time from an LDS cursor, so every lane that
@@ -33,6 +35,8 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
     double* tab = reinterpret_cast<double*>(smem);
     int* list = reinterpret_cast<int*>(smem + TABLE_BYTES);
     int* counters = list + AO_CHUNK;  // [0] wet count, [1] cursor
+    int* hist = counters + 4;
+    int* bin_start = hist + AO_BINS;
     DevParams* lp = reinterpret_cast<DevParams*>(smem + AO_PARAMS_OFFSET);
     const int tid = threadIdx.x, lane = tid & 63;
     stage_tables(tab, g_tab, tid, AO_BLOCK);
@@ -46,30 +50,52 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
     const int nchunks = (ncells + AO_CHUNK - 1) / AO_CHUNK;
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         if (tid < 2) counters[tid] = 0;
+        if (tid < AO_BINS) hist[tid] = 0;
         __syncthreads();
-        // ---- phase 1: classify, zero land, compact wet cells ------------------------------------
+        // ---- phase 1: classify, zero land, counting-sort the wet cells by their trip-count hint ----
+        // (the hint is the cell's iteration count in the previous call — fields evolve slowly from one
+        // coupled step to the next — so lanes of a batch finish together; it only orders the list and
+        // cannot change any result)
         const int begin = chunk * AO_CHUNK, end = min(begin + AO_CHUNK, ncells);
-        for (int base = begin; base < end; base += AO_BLOCK) {
-            const int idx = base + tid;
-            const bool in_range = idx < end;
-            bool wet = false;
-            if (in_range) {
+        constexpr int PER = AO_CHUNK / AO_BLOCK;
+        int my_idx[PER], my_bin[PER], my_rank[PER];
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int idx = begin + p * AO_BLOCK + tid;
+            my_idx[p] = idx;
+            my_bin[p] = -1;
+            my_rank[p] = 0;
+            if (idx < end) {
                 const int jj = idx / wx;
                 const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
-                wet = cell_is_wet(P, O.mask, k);
-                if (!wet) {  // zero_interface_state: all fluxes 0, T = 0 K
+                if (cell_is_wet(P, O.mask, k)) {
+                    const int bin = hint ? min((int)hint[k], AO_BINS - 1) : 0;
+                    my_bin[p] = bin;
+                    my_rank[p] = atomicAdd(&hist[bin], 1);
+                } else {  // zero_interface_state: all fluxes 0, T = 0 K
                     CellFluxes Z{};
                     Z.Ts_ocean = -P.T_offset;
                     Z.iterations = L.fixed ? L.maxiter : 0;
                     store_fluxes(F, k, Z);
                 }
             }
-            const unsigned long long m = __ballot(wet);
-            int wave_base = 0;
-            if (lane == 0 && m) wave_base = atomicAdd(&counters[0], __popcll(m));
-            wave_base = __shfl(wave_base, 0);
-            if (wet) list[wave_base + __popcll(m & ((1ull << lane) - 1ull))] = idx;
         }
+        __syncthreads();
+        if (tid < 64) {  // exclusive scan of the AO_BINS (≤ 64) bin counts by one wave
+            const int v = lane < AO_BINS ? hist[lane] : 0;
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            if (lane < AO_BINS) bin_start[lane] = incl - v;
+            if (lane == 63) counters[0] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PER; ++p)
+            if (my_bin[p] >= 0) list[bin_start[my_bin[p]] + my_rank[p]] = my_idx[p];
         __syncthreads();
         const int nwet = counters[0];
         // ---- phase 2: waves pull 64 wet cells at a time ------------------------------------------
@@ -89,7 +115,10 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
             const CellConsts c = cell_prologue(P, L.min_gust, logt, E.u[k], E.v[k], E.T[k], E.p[k], E.q[k], uo, vo,
                                                O.T[k], O.S[k]);
             const Scales s = mo_iterate<COARE, SPEC>(L, c, tab, in_range);
-            if (in_range) store_fluxes(F, k, cell_epilogue(c, P.T_offset, s));
+            if (in_range) {
+                store_fluxes(F, k, cell_epilogue(c, P.T_offset, s));
+                if (hint) hint[k] = (uint8_t)min(s.it, 255);
+            }
         }
         __syncthreads();  // list and counters are reused by the next chunk
     }
@@ -135,15 +164,15 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
     switch (C.specialization) {
         case SOLVER_OCEAN:
             hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_OCEAN>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O,
-                               E, F, L.d_tables, L.d_params);
+                               E, F, L.d_tables, L.d_params, L.d_hint);
             break;
         case SOLVER_ICE:
             hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_ICE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O, E,
-                               F, L.d_tables, L.d_params);
+                               F, L.d_tables, L.d_params, L.d_hint);
             break;
         default:
             hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_GENERIC>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G,
-                               O, E, F, L.d_tables, L.d_params);
+                               O, E, F, L.d_tables, L.d_params, L.d_hint);
     }
 }
 

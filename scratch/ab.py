@@ -17,6 +17,7 @@ for name, fl in (("default", ic.SimilarityTheoryFluxes()), ("corrected", ic.corr
     atmos = ctx.field_set(EXCHANGE_NAMES); fluxes = ctx.field_set(FLUX_NAMES); net = ctx.field_set(NET_NAMES)
     ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
     res = {}
+    if os.environ.get("HINTS"): ctx.set_option(abi.OPT_TRIP_HINTS, int(os.environ["HINTS"]))
     if os.environ.get("CAP"): ctx.set_option(abi.OPT_INTERP_TILE_CAP, int(os.environ["CAP"]))
     for mb in [int(a) for a in sys.argv[1:]] or [1024]:
         ctx.set_option(abi.OPT_MAX_BLOCKS, mb)

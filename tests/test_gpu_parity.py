@@ -270,3 +270,30 @@ def test_golden_vectors_on_gpu():
     for k in NET_NAMES:
         e = util.rel_err(to.win(got["net"][k], 0), to.win(d["net_ice.default." + k], 0), util.FIELD_SCALE[k])
         assert e < TOL_SOLVER, (k, e)
+
+
+def test_trip_count_hints_only_reorder_work():
+    """The second call of a context sorts each chunk by the first call's iteration counts
+    (CF_OPT_TRIP_HINTS); results must be bitwise identical with hints cold, warm and disabled."""
+    params = ic.flux_params()
+    case = util.build_case(300, 41, 4, 4)
+    ctx = FluxContext(300, 41, 4, 4, params)
+    dev = ctx.to_device
+    ocean = {k: dev(case["ocean"][k]) for k in ("T", "S", "u", "v", "mask")}
+    src = {k: dev(v) for k, v in case["src"].items()}
+    w = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in case["weights"].items()}
+    atmos = ctx.field_set(EXCHANGE_NAMES)
+    ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
+    runs = []
+    for hints in (1, 1, 1, 0):
+        ctx.set_option(abi.OPT_TRIP_HINTS, hints)
+        fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL)
+        fluxes["iterations"] = ctx.zeros(torch.int32)
+        ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
+        torch.cuda.synchronize()
+        runs.append({k: v.cpu().numpy() for k, v in fluxes.items()})
+    for r in runs[1:]:
+        for k in runs[0]:
+            np.testing.assert_array_equal(r[k], runs[0][k], err_msg=k)
+    assert runs[0]["iterations"].max() > 10
+    ctx.close()
