@@ -69,7 +69,7 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
                 const int jj = idx / wx;
                 const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
                 if (cell_is_wet(P, O.mask, k)) {
-                    const int bin = hint ? min((int)hint[k], AO_BINS - 1) : 0;
+                    const int bin = hint ? AO_BINS - 1 - min((int)hint[k], AO_BINS - 1) : 0;  // longest first (LPT)
                     my_bin[p] = bin;
                     my_rank[p] = atomicAdd(&hist[bin], 1);
                 } else {  // zero_interface_state: all fluxes 0, T = 0 K
