@@ -110,7 +110,11 @@ def main():
     atmos = ctx.field_set(EXCHANGE_NAMES)
     fl = ctx.field_set(FLUX_NAMES)
     net = ctx.field_set(NET_NAMES)
-    halo = SlabHaloExchanger(ctx, ny, h, rows=1, backend=a.halo_backend)
+    try:
+        halo = SlabHaloExchanger(ctx, ny, h, rows=1, backend=a.halo_backend)
+    except Exception as exc:  # native RCCL init failed: same exchange through torch.distributed (also RCCL)
+        print(f"[bench] native RCCL halo path unavailable ({exc}); using torch.distributed P2P", file=sys.stderr)
+        halo = SlabHaloExchanger(ctx, ny, h, rows=1, backend="torch")
     halo_fields = [ocean[k] for k in ("T", "S", "u", "v")]
 
     def step():
@@ -147,10 +151,21 @@ def main():
         copy_bytes = 256 << 20
         copy_ms = ctx.time_copy(copy_bytes, 20)
 
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (separate runs, see profiles/);
+        # only valid for the workload they were collected on
+        traffic = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            if (nx, ny, a.flux_configuration, world) == (1440, 560, "default", 1):
+                traffic = {k.split("<")[0]: v["hbm_bytes_per_launch"] for k, v in pmc.items()}
+        except Exception:
+            pass
+
         def roof(name, nbytes, ncells, ms):
             achieved = nbytes * ncells / (ms * 1e-3) / 1e9
             return dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, bytes_per_cell=nbytes, cells_per_launch=ncells,
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic.get(name.split(" ")[0]),
+                        bytes_per_cell=nbytes, cells_per_launch=ncells,
                         avg_launch_ms=ms, launches_timed=nrec, cells_per_s=ncells / (ms * 1e-3))
 
         out = dict(metric="flux-kernel surface cells/s (update_state!: JRA55 interp + similarity-theory fluxes + net fluxes)",
