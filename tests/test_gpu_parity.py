@@ -297,3 +297,21 @@ def test_trip_count_hints_only_reorder_work():
             np.testing.assert_array_equal(r[k], runs[0][k], err_msg=k)
     assert runs[0]["iterations"].max() > 10
     ctx.close()
+
+
+def test_native_rccl_communicator_single_rank():
+    """cf_comm_unique_id / cf_comm_init / cf_halo_exchange_rows through librccl with one rank:
+    no neighbours ⇒ the exchange is a no-op that must leave the halos untouched."""
+    from coflux.runtime import comm_unique_id
+    ctx = FluxContext(64, 16, 3, 3, ic.flux_params())
+    ident = comm_unique_id()
+    assert len(ident) == abi.COMM_ID_BYTES and any(ident)
+    ctx.comm_init(ident, 0, 1)
+    fields = [ctx.to_device(np.random.default_rng(k).normal(size=ctx.shape)) for k in range(4)]
+    before = [f.clone() for f in fields]
+    ctx.halo_exchange_rows(fields, rows=1)
+    ctx.sync()
+    torch.cuda.synchronize()
+    for a, b in zip(fields, before):
+        assert torch.equal(a, b)
+    ctx.close()
