@@ -16,6 +16,7 @@ ROUGHNESS_CONSTANT, ROUGHNESS_CHARNOCK, ROUGHNESS_WIND_CHARNOCK = 0, 1, 2
 SCALAR_ROUGHNESS_CONSTANT, SCALAR_ROUGHNESS_REYNOLDS = 0, 1
 VISCOSITY_CONSTANT, VISCOSITY_TEMPERATURE_DEPENDENT = 0, 1
 STOP_CONVERGENCE, STOP_FIXED = 0, 1
+FORMULATION_SIMILARITY, FORMULATION_LARGE_YEAGER = 0, 1
 VELOCITY_RELATIVE, VELOCITY_WIND = 0, 1
 MASK_NONE, MASK_U8, MASK_BOTTOM_HEIGHT = 0, 1, 2
 ALBEDO_CONSTANT, ALBEDO_LATITUDE_DEPENDENT = 0, 1
@@ -80,7 +81,11 @@ class FluxParams(C.Structure):
                 ("ocean_albedo_kind", C.c_int32), ("penetrating_shortwave", C.c_int32),
                 ("ocean_albedo", C.c_double), ("ocean_albedo_diffuse", C.c_double),
                 ("ocean_albedo_direct", C.c_double), ("ocean_emissivity", C.c_double),
-                ("stefan_boltzmann", C.c_double)]
+                ("stefan_boltzmann", C.c_double),
+                ("flux_formulation", C.c_int32), ("reserved1", C.c_int32),
+                ("ly_minimum_wind", C.c_double), ("ly_zeta_bound", C.c_double), ("ly_cd", C.c_double * 4),
+                ("ly_high_wind", C.c_double), ("ly_cd_high", C.c_double), ("ly_ce", C.c_double),
+                ("ly_ch_stable", C.c_double), ("ly_ch_unstable", C.c_double)]
 
 
 class OceanSurface(C.Structure):

@@ -145,6 +145,35 @@ class SimilarityTheoryFluxes:
     similarity_profile_floor: float = 1.0   # restatement guard, see include/coflux.h
 
 
+@dataclass
+class LargeYeagerTransferCoefficients:
+    """LargeYeagerTransferCoefficients(FT), omip_simulation.jl:88: neutral 10-m coefficients of Large &
+    Yeager (2004, 2009): 10³·Cd_N10 = 2.70/U + 0.142 + 0.0764·U − 3.14807e-10·U⁶ (= 2.34 for U ≥ 33 m/s),
+    10³·Ce_N10 = 34.6·√Cd_N10, 10³·Ch_N10 = 18.0·√Cd_N10 (stable) or 32.7·√Cd_N10 (unstable)."""
+    cd: tuple = (2.70, 0.142, 0.0764, -3.14807e-10)
+    high_wind: float = 33.0
+    cd_high: float = 2.34
+    ce: float = 34.6
+    ch_stable: float = 18.0
+    ch_unstable: float = 32.7
+    minimum_wind: float = 0.5
+    zeta_bound: float = 10.0
+
+
+@dataclass
+class CoefficientBasedFluxes:
+    """CoefficientBasedFluxes(FT; transfer_coefficients, solver_stop_criteria), omip_simulation.jl:86-89."""
+    transfer_coefficients: LargeYeagerTransferCoefficients = field(default_factory=LargeYeagerTransferCoefficients)
+    solver_stop_criteria: object = field(default_factory=lambda: FixedIterations(5))
+    von_karman_constant: float = 0.4
+
+
+def ncar_atmosphere_ocean_fluxes(FT=float):
+    """omip_simulation.jl:79-89: OMIP-2 standard Large & Yeager bulk algorithm, 5 fixed iterations."""
+    return CoefficientBasedFluxes(transfer_coefficients=LargeYeagerTransferCoefficients(),
+                                  solver_stop_criteria=FixedIterations(5))
+
+
 def corrected_atmosphere_ocean_fluxes(FT=float, minimum_gustiness=0.5):
     """omip_simulation.jl:40-50."""
     nu = TemperatureDependentAirViscosity()
@@ -275,6 +304,14 @@ def flux_params(fluxes: Optional[SimilarityTheoryFluxes] = None, *,
                 ocean_minimum_salinity=0.0, stefan_boltzmann_constant=5.67e-8,
                 mask_kind=abi.MASK_U8, penetrating_shortwave=True) -> abi.FluxParams:
     """Lower a flux configuration to the C ABI's cf_flux_params block."""
+    ly = None
+    if isinstance(fluxes, CoefficientBasedFluxes):
+        ly = fluxes
+        # the similarity block still has to be valid; Paulson/−5ζ are the Large–Yeager stability functions
+        fluxes = SimilarityTheoryFluxes(von_karman_constant=ly.von_karman_constant,
+                                        stability_functions=large_yeager_stability_functions(),
+                                        similarity_form=COARELogarithmicSimilarityProfile(),
+                                        solver_stop_criteria=ly.solver_stop_criteria)
     f = fluxes or SimilarityTheoryFluxes()
     th = thermodynamics or AtmosphereThermodynamicsParameters()
     sw = seawater or SeawaterComposition()
@@ -334,4 +371,11 @@ def flux_params(fluxes: Optional[SimilarityTheoryFluxes] = None, *,
     p.penetrating_shortwave = 1 if penetrating_shortwave else 0
     p.ocean_emissivity = rad.emissivity
     p.stefan_boltzmann = stefan_boltzmann_constant
+    tc = ly.transfer_coefficients if ly is not None else LargeYeagerTransferCoefficients()
+    p.flux_formulation = abi.FORMULATION_LARGE_YEAGER if ly is not None else abi.FORMULATION_SIMILARITY
+    p.ly_minimum_wind, p.ly_zeta_bound = tc.minimum_wind, tc.zeta_bound
+    for k in range(4):
+        p.ly_cd[k] = tc.cd[k]
+    p.ly_high_wind, p.ly_cd_high = tc.high_wind, tc.cd_high
+    p.ly_ce, p.ly_ch_stable, p.ly_ch_unstable = tc.ce, tc.ch_stable, tc.ch_unstable
     return p

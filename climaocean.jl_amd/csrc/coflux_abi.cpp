@@ -109,6 +109,14 @@ static int lower_params(cf_ctx* ctx, const cf_flux_params* p, DevParams* d) {
     if (!(p->reference_height > 0) || !(p->von_karman > 0) || !(p->gravitational_acceleration > 0))
         return fail(ctx, CF_ERR_INVALID, "reference_height, von_karman and gravitational_acceleration must be > 0");
 
+    if (p->flux_formulation != CF_FORMULATION_SIMILARITY && p->flux_formulation != CF_FORMULATION_LARGE_YEAGER)
+        return fail(ctx, CF_ERR_INVALID, "Unknown flux_formulation: %d", p->flux_formulation);
+    if (p->flux_formulation == CF_FORMULATION_LARGE_YEAGER) {
+        if (p->stop_kind != CF_STOP_FIXED)
+            return fail(ctx, CF_ERR_INVALID, "CoefficientBasedFluxes needs solver_stop_criteria = FixedIterations(n)");
+        if (!(p->ly_minimum_wind > 0) || !(p->ly_zeta_bound > 0))
+            return fail(ctx, CF_ERR_INVALID, "Large-Yeager minimum wind and zeta bound must be > 0");
+    }
     const cf_thermodynamics& t = p->thermo;
     DevParams D{};
     D.R_d = t.gas_constant / t.dry_air_molar_mass;
@@ -150,7 +158,8 @@ static int lower_params(cf_ctx* ctx, const cf_flux_params* p, DevParams* d) {
     D.inv_g = 1.0 / D.g;
     D.log_h = std::log(D.h_ref);
     D.similarity_form = p->similarity_form;
-    D.stability = p->stability_functions;
+    // the Large–Yeager iteration uses the Paulson / −5ζ functions whatever the similarity block says
+    D.stability = p->flux_formulation == CF_FORMULATION_LARGE_YEAGER ? CF_STABILITY_LARGE_YEAGER : p->stability_functions;
     D.stop_kind = p->stop_kind;
     D.maxiter = p->maxiter;
     D.velocity_difference = p->velocity_difference;
@@ -213,6 +222,22 @@ static LoopParams loop_params(const cf_flux_params& p, const DevParams& d) {
         C.specialization = SOLVER_ICE;
     else
         C.specialization = SOLVER_GENERIC;
+    if (p.flux_formulation == CF_FORMULATION_LARGE_YEAGER) {
+        C.specialization = SOLVER_LY;
+        C.ly_min_wind = p.ly_minimum_wind;
+        C.ly_zeta_bound = p.ly_zeta_bound;
+        C.ly_cd0 = p.ly_cd[0];
+        C.ly_cd1 = p.ly_cd[1];
+        C.ly_cd2 = p.ly_cd[2];
+        C.ly_cd3 = p.ly_cd[3];
+        C.ly_high_wind = p.ly_high_wind;
+        C.ly_cd_high = p.ly_cd_high;
+        C.ly_ce = p.ly_ce;
+        C.ly_ch_s = p.ly_ch_stable;
+        C.ly_ch_u = p.ly_ch_unstable;
+        C.ly_lz = std::log(d.h_ref / 10.0);
+    }
+    C.inv_kappa = 1.0 / d.kappa;
     return C;
 }
 
@@ -309,6 +334,18 @@ int cf_default_flux_params(cf_flux_params* p) {
     p->ocean_albedo_direct = 0.011;
     p->ocean_emissivity = 1.0;
     p->stefan_boltzmann = 5.67e-8;
+    p->flux_formulation = CF_FORMULATION_SIMILARITY;
+    p->ly_minimum_wind = 0.5;
+    p->ly_zeta_bound = 10.0;
+    p->ly_cd[0] = 2.70;
+    p->ly_cd[1] = 0.142;
+    p->ly_cd[2] = 0.0764;
+    p->ly_cd[3] = -3.14807e-10;
+    p->ly_high_wind = 33.0;
+    p->ly_cd_high = 2.34;
+    p->ly_ce = 34.6;
+    p->ly_ch_stable = 18.0;
+    p->ly_ch_unstable = 32.7;
     return CF_OK;
 }
 
@@ -515,6 +552,8 @@ int cf_compute_atmosphere_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocea
     CHECK(check_ocean(ctx, ocean));
     CHECK(check_exchange(ctx, atmos, false));
     CHECK(check_fluxes(ctx, out));
+    if (ctx->launch.solver == CF_SOLVER_LIBM && ctx->params.flux_formulation == CF_FORMULATION_LARGE_YEAGER)
+        return fail(ctx, CF_ERR_INVALID, "CF_SOLVER_LIBM implements SimilarityTheoryFluxes only");
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, out));
     return CF_OK;
 }

@@ -272,8 +272,8 @@ __device__ __forceinline__ CellFluxes solve_cell(const DevParams& P, double ua, 
             double lq = scalar_roughness(P.rq, lu, us, nu_q);
             double lt = scalar_roughness(P.rt, lu, us, nu_t);
 
-            // 1/L★ = −κ b★ / u★²  (L★ = ∞ when b★ = 0)
-            double inv_L = (bstar == 0.0) ? 0.0 : -(P.kappa * bstar) / (us * us);
+            // 1/L★ = κ b★ / u★²  (L★ = ∞ when b★ = 0); b★ < 0 ⇒ ζ < 0 ⇒ unstable
+            double inv_L = (bstar == 0.0) ? 0.0 : (P.kappa * bstar) / (us * us);
             double chi_u = P.kappa / similarity_profile<STAB, COARE>(P.log_h, P.h_ref, lu, inv_L, P.profile_floor, false);
             double chi_t = P.kappa / similarity_profile<STAB, COARE>(P.log_h, P.h_ref, lt, inv_L, P.profile_floor, true);
             double chi_q = P.kappa / similarity_profile<STAB, COARE>(P.log_h, P.h_ref, lq, inv_L, P.profile_floor, true);

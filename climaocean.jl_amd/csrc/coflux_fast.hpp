@@ -243,13 +243,17 @@ struct LoopParams {
     double b_q, log_A_q, log_lm_q, log_const_q;                 // water-vapour roughness
     double b_t, log_A_t, log_lm_t, log_const_t;                 // temperature roughness
     int32_t maxiter, fixed, m_kind, q_kind, t_kind, same_scalar;
-    int32_t specialization;  // SOLVER_OCEAN / SOLVER_ICE / SOLVER_GENERIC (host-selected)
+    int32_t specialization;  // SOLVER_OCEAN / SOLVER_ICE / SOLVER_GENERIC / SOLVER_LY (host-selected)
     int32_t pad;
+    // CoefficientBasedFluxes + LargeYeagerTransferCoefficients
+    double ly_min_wind, ly_zeta_bound, ly_cd0, ly_cd1, ly_cd2, ly_cd3, ly_high_wind, ly_cd_high, ly_ce, ly_ch_s, ly_ch_u;
+    double ly_lz, inv_kappa;  // log(h / 10 m), 1/κ
 };
 
 constexpr int SOLVER_OCEAN = 0;    // Charnock-type momentum roughness, identical Reynolds-scaled scalars, U_G,min > 0
 constexpr int SOLVER_ICE = 1;      // constant roughness lengths, U_G,min > 0
 constexpr int SOLVER_GENERIC = 2;  // anything else (runtime kinds, u★ = 0 guards)
+constexpr int SOLVER_LY = 3;       // CoefficientBasedFluxes: Large & Yeager iteration on (Cd, Ch, Ce)
 
 using FastConsts = LoopParams;  // name kept for the launcher signatures
 
@@ -379,8 +383,8 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
                                                               lu, us, c.inv_nu_t);
             }
 
-            // 1/L★ = −κ b★ / u★²  (0 when b★ = 0)
-            double inv_L = -(L.kappa * bstar) * (inv_us * inv_us);
+            // 1/L★ = κ b★ / u★²  (0 when b★ = 0); b★ < 0 ⇒ ζ < 0 ⇒ unstable
+            double inv_L = (L.kappa * bstar) * (inv_us * inv_us);
             if constexpr (SPEC == SOLVER_GENERIC) inv_L = (bstar == 0.0) ? 0.0 : inv_L;
             const PsiArg ah = psi_arg_pos(logt, L.h_ref * inv_L);
             const double2 psi_h2 = psi_eval_pair(psi, ah);
@@ -415,6 +419,43 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
         }
     }
     return Scales{us, ts, qq, it};
+}
+
+// CoefficientBasedFluxes(transfer_coefficients = LargeYeagerTransferCoefficients, FixedIterations(n))
+// (omip_simulation.jl:86-89): the NCAR bulk algorithm of Large & Yeager (2004, 2009) on this
+// package's Δθ, Δq and buoyancy scale.  Fixed trip count ⇒ no divergence, no ballot.
+__device__ __forceinline__ Scales ly_iterate(const LoopParams& L, const CellConsts& c, const double* tab) {
+    const double* logt = tab + 4 * PSI_TABLE;
+    auto cdn10 = [&](double u) {
+        const double u2 = u * u;
+        const double poly = (L.ly_cd0 * frcp1(u) + L.ly_cd1 + L.ly_cd2 * u + L.ly_cd3 * (u2 * u2 * u2)) * 1e-3;
+        return u >= L.ly_high_wind ? L.ly_cd_high * 1e-3 : poly;
+    };
+    const double U = fmax(c.dU, L.ly_min_wind);
+    double cdn = cdn10(U), rt = fsqrt1(cdn);
+    double cd = cdn, ce = L.ly_ce * rt * 1e-3, ch = (c.dtheta > 0.0 ? L.ly_ch_s : L.ly_ch_u) * rt * 1e-3;
+    for (int it = 0; it < L.maxiter; ++it) {
+        const double cr = fsqrt1(cd), inv_cr = frcp1(cr);
+        const double us = cr * U, ts = ch * inv_cr * c.dtheta, qq = ce * inv_cr * c.dq;  // L-Y eq. 7
+        const double b = c.gTv * __builtin_fma(ts, c.b_theta, c.b_q * qq);
+        double z = L.kappa * b * L.h_ref * frcp1(us * us);                                // 8a
+        z = __builtin_copysign(fmin(fabs(z), L.ly_zeta_bound), z);
+        const double2 ps = psi_eval_pair(tab, psi_arg_pos(logt, z));
+        const double xm = (L.ly_lz - ps.x) * L.inv_kappa;
+        const double u10 = U * frcp1(__builtin_fma(rt, xm, 1.0));                          // 9
+        cdn = cdn10(u10);
+        rt = fsqrt1(cdn);
+        const double inv_rt = frcp1(rt);
+        const double cen = L.ly_ce * rt * 1e-3, chn = (z > 0.0 ? L.ly_ch_s : L.ly_ch_u) * rt * 1e-3;
+        const double den = __builtin_fma(rt, xm, 1.0);
+        cd = cdn * frcp1(den * den);                                                      // 10a
+        const double xh = (L.ly_lz - ps.y) * L.inv_kappa;
+        const double r = fsqrt1(cd * frcp1(cdn));
+        ch = chn * frcp1(__builtin_fma(chn * xh, inv_rt, 1.0)) * r;                        // 10b
+        ce = cen * frcp1(__builtin_fma(cen * xh, inv_rt, 1.0)) * r;                        // 10c
+    }
+    const double cr = fsqrt1(cd), inv_cr = frcp1(cr);
+    return Scales{cr * U, ch * inv_cr * c.dtheta, ce * inv_cr * c.dq, L.maxiter};
 }
 
 __device__ __forceinline__ CellFluxes cell_epilogue(const CellConsts& c, double T_offset, Scales s) {

@@ -114,7 +114,11 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
             const double vo = 0.5 * (O.v[k] + O.v[k + (size_t)G.sj]);
             const CellConsts c = cell_prologue(P, L.min_gust, logt, E.u[k], E.v[k], E.T[k], E.p[k], E.q[k], uo, vo,
                                                O.T[k], O.S[k]);
-            const Scales s = mo_iterate<COARE, SPEC>(L, c, tab, in_range);
+            Scales s;
+            if constexpr (SPEC == SOLVER_LY)
+                s = ly_iterate(L, c, tab);
+            else
+                s = mo_iterate<COARE, SPEC>(L, c, tab, in_range);
             if (in_range) {
                 store_fluxes(F, k, cell_epilogue(c, P.T_offset, s));
                 if (hint) hint[k] = (uint8_t)min(s.it, 255);
@@ -168,6 +172,10 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
             break;
         case SOLVER_ICE:
             hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_ICE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O, E,
+                               F, L.d_tables, L.d_params, L.d_hint);
+            break;
+        case SOLVER_LY:
+            hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_LY>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O, E,
                                F, L.d_tables, L.d_params, L.d_hint);
             break;
         default:

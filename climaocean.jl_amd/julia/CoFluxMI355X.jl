@@ -62,6 +62,9 @@ mutable struct CfFluxParams
     ocean_albedo_kind::Int32; penetrating_shortwave::Int32
     ocean_albedo::Float64; ocean_albedo_diffuse::Float64; ocean_albedo_direct::Float64
     ocean_emissivity::Float64; stefan_boltzmann::Float64
+    flux_formulation::Int32; reserved1::Int32            # 0 SimilarityTheoryFluxes, 1 CoefficientBasedFluxes (Large–Yeager)
+    ly_minimum_wind::Float64; ly_zeta_bound::Float64; ly_cd::NTuple{4, Float64}
+    ly_high_wind::Float64; ly_cd_high::Float64; ly_ce::Float64; ly_ch_stable::Float64; ly_ch_unstable::Float64
     CfFluxParams() = new()
 end
 

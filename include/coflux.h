@@ -88,6 +88,10 @@ typedef struct cf_grid {
 #define CF_VISCOSITY_CONSTANT 0
 #define CF_VISCOSITY_TEMPERATURE_DEPENDENT 1 /* TemperatureDependentAirViscosity(FT), :41 */
 
+/* flux formulation */
+#define CF_FORMULATION_SIMILARITY 0      /* SimilarityTheoryFluxes (iteration on u★, θ★, q★ with roughness lengths) */
+#define CF_FORMULATION_LARGE_YEAGER 1    /* CoefficientBasedFluxes + LargeYeagerTransferCoefficients, omip_simulation.jl:86-89 */
+
 /* solver stop criteria */
 #define CF_STOP_CONVERGENCE 0  /* default: |Δu★|+|Δθ★|+|Δq★| < tolerance or iteration ≥ maxiter */
 #define CF_STOP_FIXED 1        /* FixedIterations(5), omip_simulation.jl:22,89                  */
@@ -182,6 +186,20 @@ typedef struct cf_flux_params {
     double ocean_albedo_direct;   /* 0.011 */
     double ocean_emissivity;      /* 1.0  */
     double stefan_boltzmann;      /* 5.67e-8 */
+
+    /* CoefficientBasedFluxes(FT; transfer_coefficients = LargeYeagerTransferCoefficients(FT),
+     * solver_stop_criteria = FixedIterations(5)) — omip_simulation.jl:79-89 (":ncar", OMIP-2): the
+     * iteration runs on the transfer coefficients (Cd, Ch, Ce), not on roughness lengths.            */
+    int32_t flux_formulation;     /* CF_FORMULATION_* */
+    int32_t reserved1;
+    double ly_minimum_wind;       /* 0.5 m/s floor on |Δu| (NCAR/CORE convention)                       */
+    double ly_zeta_bound;         /* |ζ| ≤ 10                                                           */
+    double ly_cd[4];              /* 10³·Cd_N10 = c0/U + c1 + c2·U + c3·U⁶: 2.7, 0.142, 0.0764, −3.14807e-10 */
+    double ly_high_wind;          /* U ≥ 33 m/s ⇒ 10³·Cd_N10 = ly_cd_high (Large & Yeager 2009)         */
+    double ly_cd_high;            /* 2.34 */
+    double ly_ce;                 /* 10³·Ce_N10 = 34.6·√Cd_N10 */
+    double ly_ch_stable;          /* 10³·Ch_N10 = 18.0·√Cd_N10 (ζ > 0) */
+    double ly_ch_unstable;        /* 32.7·√Cd_N10 (ζ ≤ 0) */
 } cf_flux_params;
 
 /* Fill `p` with the ":default" configuration (omip_simulation.jl:128-132, :263). */

@@ -342,6 +342,23 @@ static cell_result solve_cell(const cf_flux_params* P, double ua, double va, dou
         double delta = d.eps - 1.0;
 
         double up = ustar, tp = tstar, qp = qstar;
+        /* CoefficientBasedFluxes + LargeYeagerTransferCoefficients (omip_simulation.jl:86-89): the NCAR
+           bulk algorithm of Large & Yeager (2004, 2009) — iterate on (Cd, Ch, Ce) at height h, restated
+           on this package's Δθ, Δq, buoyancy scale and L★. */
+        double ly_cd = 0, ly_ch = 0, ly_ce = 0, ly_cdn_rt = 0, ly_U = 0;
+        if (P->flux_formulation == CF_FORMULATION_LARGE_YEAGER) {
+            double dU0 = sqrt(du * du + dv * dv);
+            ly_U = fmax(dU0, P->ly_minimum_wind);
+            double u10 = ly_U;
+            double cdn = (u10 >= P->ly_high_wind)
+                             ? P->ly_cd_high * 1e-3
+                             : (P->ly_cd[0] / u10 + P->ly_cd[1] + P->ly_cd[2] * u10 + P->ly_cd[3] * pow(u10, 6)) * 1e-3;
+            ly_cdn_rt = sqrt(cdn);
+            double stab = (dtheta > 0.0) ? 1.0 : 0.0; /* 0.5 + sign(0.5, t − ts) */
+            ly_cd = cdn;
+            ly_ce = P->ly_ce * ly_cdn_rt * 1e-3;
+            ly_ch = (P->ly_ch_stable * stab + P->ly_ch_unstable * (1.0 - stab)) * ly_cdn_rt * 1e-3;
+        }
         for (;;) {
             /* iterating(Ψⁿ, Ψ⁻, iteration, criteria) */
             int go;
@@ -359,6 +376,35 @@ static cell_result solve_cell(const cf_flux_params* P, double ua, double va, dou
             tp = tstar;
             qp = qstar;
 
+            if (P->flux_formulation == CF_FORMULATION_LARGE_YEAGER) {
+                double cd_rt = sqrt(ly_cd);
+                ustar = cd_rt * ly_U;                /* L-Y eq. 7a */
+                tstar = ly_ch / cd_rt * dtheta;      /* 7b */
+                qstar = ly_ce / cd_rt * dq;          /* 7c */
+                double bs = g / Tv * (tstar * (1.0 + delta * qv_s) + delta * Tv * qstar);
+                double zeta = kappa * bs * h / (ustar * ustar); /* 8a: ζ = h/L★, L★ = u★²/(κ b★); ζ > 0 stable */
+                zeta = copysign(fmin(fabs(zeta), P->ly_zeta_bound), zeta);
+                double psi_m = psi_momentum(CF_STABILITY_LARGE_YEAGER, zeta);
+                double psi_h = psi_scalar(CF_STABILITY_LARGE_YEAGER, zeta);
+                double lz = log(h / 10.0);
+                double u10 = ly_U / (1.0 + ly_cdn_rt * (lz - psi_m) / kappa); /* 9 */
+                double cdn = (u10 >= P->ly_high_wind)
+                                 ? P->ly_cd_high * 1e-3
+                                 : (P->ly_cd[0] / u10 + P->ly_cd[1] + P->ly_cd[2] * u10 + P->ly_cd[3] * pow(u10, 6)) * 1e-3;
+                ly_cdn_rt = sqrt(cdn);
+                double cen = P->ly_ce * ly_cdn_rt * 1e-3;
+                double stab = (zeta > 0.0) ? 1.0 : 0.0;
+                double chn = (P->ly_ch_stable * stab + P->ly_ch_unstable * (1.0 - stab)) * ly_cdn_rt * 1e-3;
+                double xx = (lz - psi_m) / kappa;
+                double den = 1.0 + ly_cdn_rt * xx;
+                ly_cd = cdn / (den * den);           /* 10a */
+                xx = (lz - psi_h) / kappa;
+                double rt = sqrt(ly_cd / cdn);
+                ly_ch = chn / (1.0 + chn * xx / ly_cdn_rt) * rt; /* 10b */
+                ly_ce = cen / (1.0 + cen * xx / ly_cdn_rt) * rt; /* 10c */
+                ++iters;
+                continue;
+            }
             /* iterate_interface_fluxes */
             double bstar = g / Tv * (tstar * (1.0 + delta * qv_s) + delta * Tv * qstar);
             double Jb = -ustar * bstar;
@@ -371,7 +417,9 @@ static cell_result solve_cell(const cf_flux_params* P, double ua, double va, dou
             double lq = scalar_roughness(&P->water_vapor_roughness, lu, ustar, Ts);
             double lt = scalar_roughness(&P->temperature_roughness, lu, ustar, Ts);
 
-            double L = (bstar == 0.0) ? INFINITY : -ustar * ustar / (kappa * bstar);
+            /* Obukhov length: buoyancy flux Jᵇ = −u★b★, L★ = −u★³/(κJᵇ) = u★²/(κb★); b★ < 0 (air colder /
+               drier than the surface) ⇒ L★ < 0 ⇒ ζ < 0 ⇒ unstable branch of ψ. */
+            double L = (bstar == 0.0) ? INFINITY : ustar * ustar / (kappa * bstar);
             double chi_u = kappa / similarity_profile(P->similarity_form, P->stability_functions, 0, h, lu, L, P->similarity_profile_floor);
             double chi_t = kappa / similarity_profile(P->similarity_form, P->stability_functions, 1, h, lt, L, P->similarity_profile_floor);
             double chi_q = kappa / similarity_profile(P->similarity_form, P->stability_functions, 1, h, lq, L, P->similarity_profile_floor);
@@ -382,6 +430,12 @@ static cell_result solve_cell(const cf_flux_params* P, double ua, double va, dou
             ++iters;
         }
 
+        if (P->flux_formulation == CF_FORMULATION_LARGE_YEAGER) {
+            double cd_rt = sqrt(ly_cd);   /* fluxes from the coefficients of the last iteration */
+            ustar = cd_rt * ly_U;
+            tstar = ly_ch / cd_rt * dtheta;
+            qstar = ly_ce / cd_rt * dq;
+        }
         if (!wet) { /* FixedIterations on land: zeroed afterwards */
             ustar = tstar = qstar = 0.0;
             Ts = 0.0;

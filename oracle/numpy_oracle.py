@@ -210,6 +210,9 @@ def atmosphere_ocean_fluxes(fluxes, ocean, atmos, *, hx, hy, ring, thermodynamic
     Tv, qv = th.T_virtual(Sfc), th.q_vapor(Sfc)
     delta = th.eps - 1.0
     kap = fluxes.von_karman_constant
+    if isinstance(fluxes, ic.CoefficientBasedFluxes):
+        us, ts, qq, its = _large_yeager(fluxes, du, dv, dth, dq, Tv, qv, delta, kap, g, h, wet)
+        return _pack_fluxes(th, A, Ta, Ts, du, dv, us, ts, qq, its, wet, ocean, ocean_properties, W)
     stab = fluxes.stability_functions.name
     coare = isinstance(fluxes.similarity_form, ic.COARELogarithmicSimilarityProfile)
     sc = fluxes.solver_stop_criteria
@@ -232,7 +235,7 @@ def atmosphere_ocean_fluxes(fluxes, ocean, atmos, *, hx, hy, ring, thermodynamic
         lq = scalar_length(fluxes.water_vapor_roughness_length, lu, us, Ts)
         lt = scalar_length(fluxes.temperature_roughness_length, lu, us, Ts)
         with np.errstate(divide="ignore", invalid="ignore"):
-            L = np.where(b == 0, np.inf, -us * us / (kap * b))
+            L = np.where(b == 0, np.inf, us * us / (kap * b))  # L★ = u★²/(κ b★): b★ < 0 ⇒ unstable
 
         def prof(psi, l):
             r = np.log(h / l) - psi(stab, h / L)
@@ -251,6 +254,49 @@ def atmosphere_ocean_fluxes(fluxes, ocean, atmos, *, hx, hy, ring, thermodynamic
         if not fixed:
             active = active & ~(drift < sc.tolerance)
 
+    dU = None
+    return _pack_fluxes(th, A, Ta, Ts, du, dv, us, ts, qq, its, wet, ocean, ocean_properties, W)
+
+
+def _large_yeager(fluxes, du, dv, dth, dq, Tv, qv, delta, kap, g, h, wet):
+    """Large & Yeager (2004, 2009) / NCAR ncar_ocean_fluxes on this package's Δθ, Δq and buoyancy scale."""
+    tc = fluxes.transfer_coefficients
+    n = fluxes.solver_stop_criteria.iterations
+
+    def cdn10(u):
+        poly = (tc.cd[0] / u + tc.cd[1] + tc.cd[2] * u + tc.cd[3] * u ** 6) * 1e-3
+        return np.where(u >= tc.high_wind, tc.cd_high * 1e-3, poly)
+
+    U = np.maximum(np.sqrt(du * du + dv * dv), tc.minimum_wind)
+    cdn = cdn10(U)
+    rt = np.sqrt(cdn)
+    cd = cdn
+    ce = tc.ce * rt * 1e-3
+    ch = np.where(dth > 0, tc.ch_stable, tc.ch_unstable) * rt * 1e-3
+    lz = np.log(h / 10.0)
+    for _ in range(n):
+        cr = np.sqrt(cd)
+        us, ts, qq = cr * U, ch / cr * dth, ce / cr * dq
+        b = g / Tv * (ts * (1 + delta * qv) + delta * Tv * qq)
+        z = kap * b * h / (us * us)
+        z = np.sign(z) * np.minimum(np.abs(z), tc.zeta_bound)
+        pm, ph = psi_m("large_yeager", z), psi_h("large_yeager", z)
+        u10 = U / (1 + rt * (lz - pm) / kap)
+        cdn = cdn10(u10)
+        rt = np.sqrt(cdn)
+        cen = tc.ce * rt * 1e-3
+        chn = np.where(z > 0, tc.ch_stable, tc.ch_unstable) * rt * 1e-3
+        cd = cdn / (1 + rt * (lz - pm) / kap) ** 2
+        xx = (lz - ph) / kap
+        r = np.sqrt(cd / cdn)
+        ch = chn / (1 + chn * xx / rt) * r
+        ce = cen / (1 + cen * xx / rt) * r
+    cr = np.sqrt(cd)
+    return cr * U, ch / cr * dth, ce / cr * dq, np.full(du.shape, n, np.int32)
+
+
+def _pack_fluxes(th, A, Ta, Ts, du, dv, us, ts, qq, its, wet, ocean, ocean_properties, W):
+    dU = np.sqrt(du * du + dv * dv)
     zero = ~wet
     us, ts, qq = (np.where(zero, 0.0, a) for a in (us, ts, qq))
     with np.errstate(divide="ignore", invalid="ignore"):

@@ -38,7 +38,7 @@ def test_struct_layout_matches_library():
     q = ic.flux_params()
     for name, _ in abi.FluxParams._fields_:
         a, b = getattr(p, name), getattr(q, name)
-        if isinstance(a, C.Structure):
+        if isinstance(a, (C.Structure, C.Array)):
             assert bytes(a) == bytes(b), name
         else:
             assert a == b, name

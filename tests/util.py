@@ -20,6 +20,7 @@ CONFIGS = {
     "corrected_wind": lambda: (ic.corrected_atmosphere_ocean_fluxes(), ic.WindVelocity()),
     "sea_ice_corrected": lambda: (ic.corrected_atmosphere_sea_ice_fluxes(), None),
     "sea_ice_ncar": lambda: (ic.ncar_atmosphere_sea_ice_fluxes(), None),
+    "ncar": lambda: (ic.ncar_atmosphere_ocean_fluxes(), None),
     "fixed5": lambda: (ic.SimilarityTheoryFluxes(solver_stop_criteria=ic.FixedIterations(5)), None),
 }
 
