@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--halo", type=int, default=7)  # README.md:58 halo=(7,7,7)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--halo-backend", choices=("rccl", "torch"), default="rccl")
-    ap.add_argument("--flux-configuration", choices=("default", "corrected"), default="default")
+    ap.add_argument("--flux-configuration", choices=("default", "corrected", "ncar"), default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     return ap.parse_args()
@@ -94,7 +94,8 @@ def main():
         j0, j1 = slab_bounds(a.ny, rank, world)
     nx, ny = a.nx, j1 - j0
 
-    fluxes_cfg = ic.SimilarityTheoryFluxes() if a.flux_configuration == "default" else ic.corrected_atmosphere_ocean_fluxes()
+    fluxes_cfg = {"default": ic.SimilarityTheoryFluxes, "corrected": ic.corrected_atmosphere_ocean_fluxes,
+                  "ncar": ic.ncar_atmosphere_ocean_fluxes}[a.flux_configuration]()
     params = ic.flux_params(fluxes_cfg, ocean_surface=ic.SurfaceRadiationProperties(0.06, 1.0))
 
     # ---- synthetic inputs, resident in HBM before the timed region ---------------------------------

@@ -9,7 +9,7 @@ nx, ny, h = 1440, 560, 7
 ocean_np = syn.ocean_state(nx, ny, h, h)
 src_np = syn.jra55_snapshots(2)
 fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h)
-for name, fl in (("default", ic.SimilarityTheoryFluxes()), ("corrected", ic.corrected_atmosphere_ocean_fluxes())):
+for name, fl in (("default", ic.SimilarityTheoryFluxes()), ("corrected", ic.corrected_atmosphere_ocean_fluxes()), ("ncar", ic.ncar_atmosphere_ocean_fluxes())):
     ctx = FluxContext(nx, ny, h, h, ic.flux_params(fl))
     ocean = {k: ctx.to_device(ocean_np[k]) for k in ("T", "S", "u", "v", "mask")}
     src = {k: ctx.to_device(v) for k, v in src_np.items()}
