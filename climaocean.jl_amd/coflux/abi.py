@@ -134,7 +134,7 @@ EXPORTED_SYMBOLS = (
     "cf_set_flux_params", "cf_set_stream", "cf_set_option", "cf_debug_eval", "cf_sync",
     "cf_device_alloc", "cf_device_free", "cf_h2d", "cf_d2h",
     "cf_interpolate_atmosphere_state", "cf_compute_atmosphere_ocean_fluxes",
-    "cf_compute_net_ocean_fluxes", "cf_update_state",
+    "cf_compute_net_ocean_fluxes", "cf_update_state", "cf_normalize_salinity_flux",
     "cf_time_stage", "cf_time_copy", "cf_profile_enable", "cf_profile_read",
     "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
 )
@@ -189,6 +189,7 @@ def load_library(path=None):
         vp, C.POINTER(AtmosSource), C.POINTER(InterpWeights), C.POINTER(OceanSurface),
         C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes), C.POINTER(SeaIceFields),
         C.POINTER(NetOceanFluxes)]
+    lib.cf_normalize_salinity_flux.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cf_time_stage.argtypes = [
         vp, C.c_int, C.c_int, C.POINTER(AtmosSource), C.POINTER(InterpWeights),
         C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes),

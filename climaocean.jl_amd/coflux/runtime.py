@@ -202,6 +202,11 @@ class FluxContext:
                     "cf_time_copy")
         return ms.value
 
+    def normalize_salinity_flux(self, flux, mask, additional=None, area=None, mean_out=None):
+        """NormalizeSalinity (omip_simulation.jl:182-220): flux -= area-weighted mean over wet cells."""
+        self._check(self.lib.cf_normalize_salinity_flux(self._h, _ptr(flux), _ptr(additional), _ptr(area), _ptr(mask),
+                                                        _ptr(mean_out)), "cf_normalize_salinity_flux")
+
     def profile_enable(self, max_records):
         self._check(self.lib.cf_profile_enable(self._h, max_records), "cf_profile_enable")
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -29,6 +30,7 @@ struct RcclApi {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 };
 
 struct cf_ctx {
@@ -42,6 +44,7 @@ struct cf_ctx {
     DevParams* d_params = nullptr;
     LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, nullptr, nullptr, nullptr};
     uint8_t* d_hint = nullptr;
+    double* d_reduce = nullptr;  // [2·SALINITY_PARTIAL_BLOCKS partial sums][2 totals]
     double* d_tables = nullptr;
     int tables_kind = -1;
     std::string error;
@@ -402,6 +405,7 @@ int cf_destroy(cf_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->d_hint) (void)hipFree(ctx->d_hint);
+    if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->own_stream) {
         hipSetDevice(ctx->device);
@@ -694,6 +698,7 @@ static int load_rccl(cf_ctx* ctx) {
     SYM(Send, "ncclSend");
     SYM(Recv, "ncclRecv");
     SYM(GetErrorString, "ncclGetErrorString");
+    SYM(AllReduce, "ncclAllReduce");
 #undef SYM
     g_rccl.handle = h;
     return CF_OK;
@@ -733,6 +738,23 @@ int cf_comm_destroy(cf_ctx* ctx) {
         NCCL_TRY(ctx, g_rccl.CommDestroy(ctx->comm));
         ctx->comm = nullptr;
     }
+    return CF_OK;
+}
+
+int cf_normalize_salinity_flux(cf_ctx* ctx, double* d_flux, const double* d_additional, const double* d_area,
+                               const void* d_mask, double* d_mean_out) {
+    if (!ctx || !d_flux) return fail(ctx, CF_ERR_INVALID, "cf_normalize_salinity_flux: bad arguments");
+    if (ctx->dev.mask_kind != CF_MASK_NONE && !d_mask)
+        return fail(ctx, CF_ERR_INVALID, "mask_kind = %d but the mask is NULL", ctx->dev.mask_kind);
+    if (!ctx->d_reduce) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_reduce, sizeof(double) * (2 * SALINITY_PARTIAL_BLOCKS + 2)));
+    double* sums = ctx->d_reduce + 2 * SALINITY_PARTIAL_BLOCKS;
+    const int ncells = ctx->grid.nx * ctx->grid.ny;
+    const int nblocks = std::max(1, std::min(SALINITY_PARTIAL_BLOCKS, (ncells + 255) / 256));
+    HIP_TRY(ctx, launch_salinity_partial_sums(ctx->stream, ctx->dev, ctx->grid, d_flux, d_additional, d_area, d_mask,
+                                              ctx->d_reduce, nblocks, sums));
+    if (ctx->comm && ctx->nranks > 1)  // the only collective near the path: two doubles
+        NCCL_TRY(ctx, g_rccl.AllReduce(sums, sums, 2, ncclFloat64, ncclSum, ctx->comm, ctx->stream));
+    HIP_TRY(ctx, launch_salinity_subtract(ctx->stream, ctx->grid, d_flux, sums, d_mean_out));
     return CF_OK;
 }
 

@@ -28,6 +28,11 @@ hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridD
 hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_exchange_fields* e, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
                              const cf_interp_weights* w, const cf_net_ocean_fluxes* n);
+constexpr int SALINITY_PARTIAL_BLOCKS = 512;
+hipError_t launch_salinity_partial_sums(hipStream_t st, const DevParams& P, const GridDesc& G, const double* flux,
+                                        const double* additional, const double* area, const void* mask, double* partial,
+                                        int nblocks, double* sums);
+hipError_t launch_salinity_subtract(hipStream_t st, const GridDesc& G, double* flux, const double* sums, double* mean_out);
 hipError_t launch_debug_eval(hipStream_t st, const LaunchCfg& L, int fn, int n, const double* x, double* y);
 hipError_t launch_copy(hipStream_t st, void* dst, const void* src, size_t bytes);
 

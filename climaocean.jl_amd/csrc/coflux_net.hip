@@ -83,6 +83,88 @@ hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc&
     return hipGetLastError();
 }
 
+// =============================================================================================
+// NormalizeSalinity: area-weighted mean over wet interior cells, then subtract from the whole parent
+// =============================================================================================
+constexpr int RED_BLOCK = 256;
+
+// stage 1: per-workgroup partial sums (Σ J·A, Σ A) in a fixed order ⇒ bitwise reproducible
+__global__ __launch_bounds__(RED_BLOCK) void salinity_partial_sums_kernel(DevParams P, GridDesc G, const double* __restrict__ flux,
+                                                                           const double* __restrict__ additional,
+                                                                           const double* __restrict__ area, const void* mask,
+                                                                           double2* __restrict__ partial) {
+    __shared__ double2 red[RED_BLOCK / 64];
+    const int ncells = G.nx * G.ny;
+    double sj = 0.0, sa = 0.0;
+    for (int idx = (int)blockIdx.x * RED_BLOCK + (int)threadIdx.x; idx < ncells; idx += (int)gridDim.x * RED_BLOCK) {
+        const int j = idx / G.nx, i = idx - j * G.nx;
+        const size_t k = cell_index(G, i, j);
+        if (cell_is_wet(P, mask, k)) {
+            const double a = area ? area[k] : 1.0;
+            const double v = flux[k] + (additional ? additional[k] : 0.0);
+            sj = __builtin_fma(v, a, sj);
+            sa += a;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        sj += __shfl_xor(sj, m);
+        sa += __shfl_xor(sa, m);
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_double2(sj, sa);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 t = red[0];
+        for (int w = 1; w < RED_BLOCK / 64; ++w) {
+            t.x += red[w].x;
+            t.y += red[w].y;
+        }
+        partial[blockIdx.x] = t;
+    }
+}
+
+// stage 2: one wave adds the partials in index order → sums[0] = Σ J·A, sums[1] = Σ A
+__global__ void salinity_final_sums_kernel(const double2* __restrict__ partial, int n, double* __restrict__ sums) {
+    double sj = 0.0, sa = 0.0;
+    for (int k = threadIdx.x; k < n; k += 64) {
+        sj += partial[k].x;
+        sa += partial[k].y;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        sj += __shfl_xor(sj, m);
+        sa += __shfl_xor(sa, m);
+    }
+    if (threadIdx.x == 0) {
+        sums[0] = sj;
+        sums[1] = sa;
+    }
+}
+
+// stage 3: parent(flux) .-= mean over the whole parent array (halos and land included)
+__global__ void salinity_subtract_kernel(double* __restrict__ flux, size_t n, const double* __restrict__ sums,
+                                         double* __restrict__ mean_out) {
+    const double mean = sums[1] > 0.0 ? sums[0] / sums[1] : 0.0;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) flux[k] -= mean;
+    if (mean_out && blockIdx.x == 0 && threadIdx.x == 0) *mean_out = mean;
+}
+
+hipError_t launch_salinity_partial_sums(hipStream_t st, const DevParams& P, const GridDesc& G, const double* flux,
+                                        const double* additional, const double* area, const void* mask, double* partial,
+                                        int nblocks, double* sums) {
+    hipLaunchKernelGGL(salinity_partial_sums_kernel, dim3(nblocks), dim3(RED_BLOCK), 0, st, P, G, flux, additional, area, mask,
+                       reinterpret_cast<double2*>(partial));
+    hipLaunchKernelGGL(salinity_final_sums_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<const double2*>(partial), nblocks,
+                       sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_salinity_subtract(hipStream_t st, const GridDesc& G, double* flux, const double* sums, double* mean_out) {
+    const size_t n = (size_t)G.sj * (G.ny + 2 * G.hy);
+    hipLaunchKernelGGL(salinity_subtract_kernel, dim3(512), dim3(256), 0, st, flux, n, sums, mean_out);
+    return hipGetLastError();
+}
+
 __global__ void copy_kernel(double2* __restrict__ dst, const double2* __restrict__ src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;

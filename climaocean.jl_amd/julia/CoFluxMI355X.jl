@@ -150,6 +150,12 @@ update_state!(b::CoFluxBackend, src, w, ocean, atmos, fluxes, ice, net) =
                         Ref{CfInterfaceFluxes}, Ptr{CfSeaIceFields}, Ref{CfNetOceanFluxes}),
                        b.ctx, src, w, ocean, atmos, fluxes, ice === nothing ? C_NULL : Ref(ice), net))
 
+# NormalizeSalinity callback (src/OMIPConfigurations/omip_simulation.jl:182-220): flux .-= ⟨flux + additional⟩_A,wet
+normalize_salinity_flux!(b::CoFluxBackend, flux::Ptr{Float64}, additional, area, mask, mean_out = C_NULL) =
+    check(b.ctx, ccall((:cf_normalize_salinity_flux, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Float64}),
+                       b.ctx, flux, additional, area, mask, mean_out))
+
 # ---- latitude-slab halo rows over RCCL (Distributed(GPU(), partition = Partition(1, R))) -------
 comm_unique_id() = (id = zeros(UInt8, 128); ccall((:cf_comm_unique_id, libcoflux), Cint, (Ptr{UInt8},), id); id)
 comm_init!(b, id::Vector{UInt8}, rank, nranks) =   # `id` is MPI.bcast from rank 0

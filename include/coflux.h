@@ -371,6 +371,17 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
                     const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice,
                     const cf_net_ocean_fluxes* net);
 
+/* NormalizeSalinity callback (src/OMIPConfigurations/omip_simulation.jl:182-220, added at :385-388):
+ * subtract the global, area-weighted mean over wet cells of (salinity flux [+ additional flux]) from
+ * the salinity-flux field — `compute!(mean_total); parent(flux_field) .-= mean_total`, so the constant
+ * is subtracted from the whole parent array, halos and land included.  `d_area` are the horizontal cell
+ * areas Az in ocean-grid layout (NULL ⇒ uniform); `d_additional` is the materialised additional top
+ * flux (SurfaceFluxRestoring …) or NULL.  With an initialised communicator (cf_comm_init) the two sums
+ * are all-reduced over the ranks (one RCCL all-reduce of two doubles) so that every slab subtracts the
+ * same global mean.  The mean is also written to d_mean_out (device double, may be NULL).            */
+int cf_normalize_salinity_flux(cf_ctx* ctx, double* d_flux, const double* d_additional, const double* d_area,
+                               const void* d_mask, double* d_mean_out);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement helper: run `launches` back-to-back launches of one stage on the context's stream
  * bracketed by HIP events ON THAT STREAM and return the average milliseconds per launch.

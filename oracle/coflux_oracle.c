@@ -637,6 +637,26 @@ int oracle_compute_net_ocean_fluxes(const cf_grid* g, const cf_flux_params* P, c
     return 0;
 }
 
+/* NormalizeSalinity (src/OMIPConfigurations/omip_simulation.jl:182-220): `compute!(mean_total)` is
+ * Oceananigans' Average over dims (1,2) — area weighted, immersed cells excluded — and
+ * `parent(flux_field) .-= mean_total` subtracts it from the whole parent array. */
+double oracle_normalize_salinity_flux(const cf_grid* g, const cf_flux_params* P, double* flux, const double* additional,
+                                      const double* area, const void* mask) {
+    double sj = 0.0, sa = 0.0;
+    for (int j = 0; j < g->ny; ++j)
+        for (int i = 0; i < g->nx; ++i) {
+            size_t k = IDX(g, i, j);
+            if (!is_wet(P, g, mask, i, j)) continue;
+            double a = area ? area[k] : 1.0;
+            sj += (flux[k] + (additional ? additional[k] : 0.0)) * a;
+            sa += a;
+        }
+    double mean = sa > 0.0 ? sj / sa : 0.0;
+    size_t n = (size_t)(g->nx + 2 * g->hx) * (size_t)(g->ny + 2 * g->hy);
+    for (size_t k = 0; k < n; ++k) flux[k] -= mean;
+    return mean;
+}
+
 /* scalar hooks for known-answer tests */
 double oracle_psi_momentum(int kind, double zeta) { return psi_momentum(kind, zeta); }
 double oracle_psi_scalar(int kind, double zeta) { return psi_scalar(kind, zeta); }

@@ -180,6 +180,18 @@ def compute_net_ocean_fluxes(g, params, ocean, atmos, fluxes, ice=None, weights=
     return out
 
 
+def normalize_salinity_flux(g, params, flux, mask, additional=None, area=None):
+    """Returns (normalised flux copy, mean)."""
+    lib = load()
+    lib.oracle_normalize_salinity_flux.restype = C.c_double
+    f = _f64(flux).copy()
+    add = None if additional is None else _f64(additional)
+    ar = None if area is None else _f64(area)
+    m = np.ascontiguousarray(mask)
+    mean = lib.oracle_normalize_salinity_flux(C.byref(g), C.byref(params), _ptr(f), _ptr(add), _ptr(ar), _ptr(m))
+    return f, mean
+
+
 def solve_cell(params, ua, va, Ta, pa, qa, uo, vo, To, So, wet=1):
     lib = load()
     out = (C.c_double * 10)()

@@ -315,3 +315,36 @@ def test_native_rccl_communicator_single_rank():
     for a, b in zip(fields, before):
         assert torch.equal(a, b)
     ctx.close()
+
+
+def test_normalize_salinity_flux_matches_oracle():
+    """cf_normalize_salinity_flux (NormalizeSalinity, omip_simulation.jl:182-220) vs the oracle; the
+    reduction is two-stage and fixed-order, so repeated calls are bitwise reproducible."""
+    for (nx, ny) in ((300, 41), (1, 1), (1440, 70)):
+        case = util.build_case(nx, ny, 4, 4)
+        g = orc.make_grid(nx, ny, 4, 4, 1)
+        P = ic.flux_params()
+        rng = np.random.default_rng(nx)
+        shape = case["ocean"]["T"].shape
+        flux = rng.normal(size=shape) * 1e-6 + 3e-7
+        add = rng.normal(size=shape) * 1e-7
+        area = np.cos(np.deg2rad(case["ocean"]["latitude"])) * 1e9
+        mask = case["ocean"]["mask"]
+        ref, mean = orc.normalize_salinity_flux(g, P, flux, mask, add, area)
+        ctx = FluxContext(nx, ny, 4, 4, P)
+        outs = []
+        for _ in range(2):
+            f = ctx.to_device(flux)
+            m = ctx.zeros()
+            ctx.normalize_salinity_flux(f, ctx.to_device(mask), ctx.to_device(add), ctx.to_device(area), m)
+            torch.cuda.synchronize()
+            outs.append((f.cpu().numpy(), float(m.flatten()[0])))
+        assert abs(outs[0][1] - mean) <= 1e-13 * max(abs(mean), 1e-7)
+        np.testing.assert_allclose(outs[0][0], ref, rtol=0, atol=1e-19)
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
+        f = ctx.to_device(flux)
+        ctx.normalize_salinity_flux(f, ctx.to_device(mask))  # uniform areas, no additional flux
+        torch.cuda.synchronize()
+        ref2, _ = orc.normalize_salinity_flux(g, P, flux, mask)
+        np.testing.assert_allclose(f.cpu().numpy(), ref2, rtol=0, atol=1e-19)
+        ctx.close()
