@@ -348,3 +348,23 @@ def test_normalize_salinity_flux_matches_oracle():
         ref2, _ = orc.normalize_salinity_flux(g, P, flux, mask)
         np.testing.assert_allclose(f.cpu().numpy(), ref2, rtol=0, atol=1e-19)
         ctx.close()
+
+
+def test_c_driver_through_the_abi(tmp_path):
+    """A plain-C host (what the Julia ccall stub amounts to): no torch, device memory through
+    cf_device_alloc/cf_h2d/cf_d2h, update_state on uniform fields, error path."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "climaocean.jl_amd", "csrc")
+    exe = str(tmp_path / "c_abi_driver")
+    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(root, "tests", "c_abi_driver.c"),
+                           "-L" + lib_dir, "-lcoflux", "-lm", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.startswith("OK "), out.stdout
+    # the same uniform case through the oracle's scalar entry
+    lh = float(out.stdout.split()[1])
+    f32 = lambda x: float(np.float32(x))  # the JRA55 window is Float32  # noqa: E731
+    ref = orc.solve_cell(ic.flux_params(), 6.0, 2.0, f32(288.15), 101325.0, f32(0.008), 0.1, -0.05, 18.0, 35.0)
+    assert abs(lh - ref["Qv"]) < 1e-9 * abs(ref["Qv"])
