@@ -45,6 +45,11 @@ struct cf_ctx {
     LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, nullptr, nullptr, nullptr};
     uint8_t* d_hint = nullptr;
     double* d_reduce = nullptr;  // [2·SALINITY_PARTIAL_BLOCKS partial sums][2 totals]
+    // halo rows travel on their own stream so that they overlap the interpolation kernel, which
+    // does not read the ocean state; consumers of the ocean fields wait on ev_comm_done
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_main_idle = nullptr, ev_comm_done = nullptr;
+    bool comm_pending = false;
     double* d_tables = nullptr;
     int tables_kind = -1;
     std::string error;
@@ -76,6 +81,8 @@ static int fail(cf_ctx* ctx, int code, const char* fmt, ...) {
         if (e_ != hipSuccess)                                                                           \
             return fail(ctx, CF_ERR_HIP, "%s:%d: %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
     } while (0)
+
+static int wait_for_halos(cf_ctx* ctx);
 
 static bool roughness_ok(const cf_roughness& r, bool scalar) {
     if (scalar) {
@@ -404,6 +411,12 @@ int cf_destroy(cf_ctx* ctx) {
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->comm_stream) {
+        (void)hipStreamSynchronize(ctx->comm_stream);
+        (void)hipStreamDestroy(ctx->comm_stream);
+        (void)hipEventDestroy(ctx->ev_main_idle);
+        (void)hipEventDestroy(ctx->ev_comm_done);
+    }
     if (ctx->d_hint) (void)hipFree(ctx->d_hint);
     if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
     if (ctx->d_params) (void)hipFree(ctx->d_params);
@@ -452,12 +465,16 @@ int cf_debug_eval(cf_ctx* ctx, int function, int n, const double* d_x, double* d
 
 int cf_set_stream(cf_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (hip_stream == CF_STREAM_LEGACY)
+        ctx->stream = nullptr;  // the null stream handle: legacy default-stream semantics in every HIP call
+    else
+        ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return CF_OK;
 }
 
 int cf_sync(cf_ctx* ctx) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    if (int rc = wait_for_halos(ctx)) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CF_OK;
 }
@@ -534,6 +551,15 @@ static int check_net(cf_ctx* ctx, const cf_net_ocean_fluxes* n, const cf_interp_
     return CF_OK;
 }
 
+// Ocean-reading kernels must see the halo rows of a preceding cf_halo_exchange_rows.
+static int wait_for_halos(cf_ctx* ctx) {
+    if (ctx->comm_pending) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm_done, 0));
+        ctx->comm_pending = false;
+    }
+    return CF_OK;
+}
+
 #define CHECK(call)            \
     do {                       \
         int rc_ = (call);      \
@@ -556,6 +582,7 @@ int cf_compute_atmosphere_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocea
     CHECK(check_ocean(ctx, ocean));
     CHECK(check_exchange(ctx, atmos, false));
     CHECK(check_fluxes(ctx, out));
+    CHECK(wait_for_halos(ctx));
     if (ctx->launch.solver == CF_SOLVER_LIBM && ctx->params.flux_formulation == CF_FORMULATION_LARGE_YEAGER)
         return fail(ctx, CF_ERR_INVALID, "CF_SOLVER_LIBM implements SimilarityTheoryFluxes only");
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, out));
@@ -570,6 +597,7 @@ int cf_compute_net_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean, cons
     CHECK(check_exchange(ctx, atmos, true));
     CHECK(check_fluxes(ctx, fluxes));
     CHECK(check_net(ctx, out, w));
+    CHECK(wait_for_halos(ctx));
     HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, out));
     return CF_OK;
 }
@@ -592,6 +620,7 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
     HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+    CHECK(wait_for_halos(ctx));  // the interpolation above overlapped the halo rows
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net));
@@ -765,6 +794,16 @@ int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int
     if (rows <= 0 || rows > G.hy || rows > G.ny) return fail(ctx, CF_ERR_INVALID, "rows = %d outside [1, min(hy, ny)]", rows);
     const size_t count = (size_t)rows * G.sj;  // whole rows, x-halos included
     const int south = ctx->rank - 1, north = ctx->rank + 1;
+    if (!ctx->comm_stream) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main_idle, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_comm_done, hipEventDisableTiming));
+    }
+    // the rows may only be overwritten once everything already queued on the main stream has read them
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_main_idle, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_main_idle, 0));
+    hipStream_t cs = ctx->comm_stream;
     NCCL_TRY(ctx, g_rccl.GroupStart());
     for (int f = 0; f < nfields; ++f) {
         double* base = d_fields[f];
@@ -773,15 +812,17 @@ int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int
         double* south_halo = base + (size_t)(G.hy - rows) * G.sj;
         double* north_halo = base + (size_t)(G.hy + G.ny) * G.sj;
         if (south >= 0) {
-            NCCL_TRY(ctx, g_rccl.Send(first_interior, count, ncclFloat64, south, ctx->comm, ctx->stream));
-            NCCL_TRY(ctx, g_rccl.Recv(south_halo, count, ncclFloat64, south, ctx->comm, ctx->stream));
+            NCCL_TRY(ctx, g_rccl.Send(first_interior, count, ncclFloat64, south, ctx->comm, cs));
+            NCCL_TRY(ctx, g_rccl.Recv(south_halo, count, ncclFloat64, south, ctx->comm, cs));
         }
         if (north < ctx->nranks) {
-            NCCL_TRY(ctx, g_rccl.Send(last_interior, count, ncclFloat64, north, ctx->comm, ctx->stream));
-            NCCL_TRY(ctx, g_rccl.Recv(north_halo, count, ncclFloat64, north, ctx->comm, ctx->stream));
+            NCCL_TRY(ctx, g_rccl.Send(last_interior, count, ncclFloat64, north, ctx->comm, cs));
+            NCCL_TRY(ctx, g_rccl.Recv(north_halo, count, ncclFloat64, north, ctx->comm, cs));
         }
     }
     NCCL_TRY(ctx, g_rccl.GroupEnd());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_done, cs));
+    ctx->comm_pending = true;  // consumed by the next ocean-reading launch (or cf_sync)
     return CF_OK;
 }
 
