@@ -109,6 +109,18 @@ class SeaIceFields(C.Structure):
                 ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")]
 
 
+class SeaIceParams(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32),
+                ("conductivity", C.c_double), ("consolidation_thickness", C.c_double),
+                ("maximum_temperature_change", C.c_double), ("ice_salinity", C.c_double),
+                ("liquidus_slope", C.c_double), ("freshwater_melting_temperature", C.c_double),
+                ("albedo", C.c_double), ("emissivity", C.c_double), ("temperature_offset", C.c_double)]
+
+
+class SeaIceState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("concentration", "thickness", "top_temperature", "u", "v", "albedo")]
+
+
 class NetOceanFluxes(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("u", "v", "T", "S", "shortwave_surface_flux", "upwelling_longwave",
@@ -135,6 +147,7 @@ EXPORTED_SYMBOLS = (
     "cf_device_alloc", "cf_device_free", "cf_h2d", "cf_d2h",
     "cf_interpolate_atmosphere_state", "cf_compute_atmosphere_ocean_fluxes",
     "cf_compute_net_ocean_fluxes", "cf_update_state", "cf_normalize_salinity_flux",
+    "cf_default_sea_ice_params", "cf_set_sea_ice_formulation", "cf_compute_atmosphere_sea_ice_fluxes",
     "cf_time_stage", "cf_time_copy", "cf_profile_enable", "cf_profile_read",
     "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
 )
@@ -190,6 +203,10 @@ def load_library(path=None):
         C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes), C.POINTER(SeaIceFields),
         C.POINTER(NetOceanFluxes)]
     lib.cf_normalize_salinity_flux.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.cf_default_sea_ice_params.argtypes = [C.POINTER(SeaIceParams)]
+    lib.cf_set_sea_ice_formulation.argtypes = [vp, C.POINTER(FluxParams), C.POINTER(SeaIceParams)]
+    lib.cf_compute_atmosphere_sea_ice_fluxes.argtypes = [
+        vp, C.POINTER(SeaIceState), C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes)]
     lib.cf_time_stage.argtypes = [
         vp, C.c_int, C.c_int, C.POINTER(AtmosSource), C.POINTER(InterpWeights),
         C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes),

@@ -261,6 +261,31 @@ class LatitudeDependentAlbedo:
     direct: float = 0.011
 
 
+@dataclass
+class SeaIceInterfaceProperties:
+    """SkinTemperature(ConductiveFlux) + SurfaceRadiationProperties(sea_ice_albedo, 1.0) of the
+    atmosphere–sea-ice interface (atmosphere.jl:34-44).  Values marked UNVERIFIED are ClimaSeaIce /
+    NumericalEarth defaults as recalled."""
+    conductivity: float = 2.0                    # UNVERIFIED
+    consolidation_thickness: float = 0.05        # UNVERIFIED
+    maximum_temperature_change: float = 5.0      # UNVERIFIED
+    ice_salinity: float = 4.0                    # UNVERIFIED
+    liquidus_slope: float = 0.054
+    freshwater_melting_temperature: float = 273.15
+    albedo: float = 0.7
+    emissivity: float = 1.0                      # atmosphere.jl:44
+    temperature_offset: float = 273.15
+
+    def to_params(self):
+        import ctypes
+        p = abi.SeaIceParams()
+        p.struct_size = ctypes.sizeof(abi.SeaIceParams)
+        for name in ("conductivity", "consolidation_thickness", "maximum_temperature_change", "ice_salinity",
+                     "liquidus_slope", "freshwater_melting_temperature", "albedo", "emissivity", "temperature_offset"):
+            setattr(p, name, getattr(self, name))
+        return p
+
+
 def _roughness_block(r, scalar):
     b = abi.Roughness()
     if isinstance(r, (int, float)):

@@ -159,6 +159,23 @@ class FluxContext:
         self._check(self.lib.cf_compute_atmosphere_ocean_fluxes(self._h, C.byref(o), C.byref(e), C.byref(f)),
                     "cf_compute_atmosphere_ocean_fluxes")
 
+    def set_sea_ice_formulation(self, ice_flux_params, sea_ice_params=None):
+        """atmosphere_sea_ice_fluxes + SkinTemperature(ConductiveFlux) properties of the
+        atmosphere–sea-ice interface (ComponentInterfaces, omip_simulation.jl:139-158)."""
+        if sea_ice_params is None:
+            sea_ice_params = abi.SeaIceParams()
+            self._check(self.lib.cf_default_sea_ice_params(C.byref(sea_ice_params)), "cf_default_sea_ice_params")
+        self._check(self.lib.cf_set_sea_ice_formulation(self._h, C.byref(ice_flux_params), C.byref(sea_ice_params)),
+                    "cf_set_sea_ice_formulation")
+
+    def compute_atmosphere_sea_ice_fluxes(self, ice_state, ocean, atmos, fluxes):
+        st = self._struct(abi.SeaIceState, ice_state,
+                          ("concentration", "thickness", "top_temperature", "u", "v", "albedo"))
+        o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
+        self._check(self.lib.cf_compute_atmosphere_sea_ice_fluxes(self._h, C.byref(st), C.byref(o), C.byref(e),
+                                                                  C.byref(f)),
+                    "cf_compute_atmosphere_sea_ice_fluxes")
+
     def compute_net_ocean_fluxes(self, ocean, atmos, fluxes, net, ice=None, weights=None):
         o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
         i = self.ice_struct(ice)

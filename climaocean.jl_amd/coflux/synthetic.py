@@ -10,7 +10,7 @@ SEED = 20260612
 
 _FIELD_IDS = {name: k + 1 for k, name in enumerate(
     ["To", "So", "uo", "vo", "land", "ice", "Ta", "pa", "qa", "ua", "va", "Qs", "Ql", "rain",
-     "snow", "rot", "Qio", "Jsio", "txio", "tyio"])}
+     "snow", "rot", "Qio", "Jsio", "txio", "tyio", "hi", "Tsi", "ui", "vi", "ai"])}
 
 
 def splitmix64(x):
@@ -105,6 +105,21 @@ def ocean_state(nx, ny, hx, hy, *, ny_global=None, j_offset=0, latitude=(-70.0, 
                ice_x_stress=ice * 1e-5 * normal("txio", i, j, seed=seed),
                ice_y_stress=ice * 1e-5 * normal("tyio", i, j, seed=seed),
                longitude=lam, latitude=phi)
+    return {k: np.ascontiguousarray(a) for k, a in out.items()}
+
+
+def sea_ice_state(nx, ny, hx, hy, *, ny_global=None, j_offset=0, latitude=(-70.0, 70.0), seed=SEED):
+    """Synthetic ClimaSeaIce surface state on the ocean grid: thickness [m] (including ice thinner than the
+    consolidation thickness), previous top temperature [°C], ice drift, per-cell albedo."""
+    nyg = ny_global or ny
+    i, j = ocean_indices(nx, ny, hx, hy, j_offset)
+    lam, phi = ocean_latlon(nx, nyg, i, j, latitude)
+    lam, phi = np.broadcast_arrays(lam, phi)
+    h = np.clip(0.02 + 1.5 * uniform("hi", i, j, seed=seed) ** 2 + 0.0 * phi, 0.0, 4.0)
+    Ts = np.minimum(0.0, -8.0 + 6.0 * normal("Tsi", i, j, seed=seed) + 0.0 * phi)
+    out = dict(thickness=h, top_temperature=Ts, u=0.05 * normal("ui", i, j, seed=seed) + 0.0 * phi,
+               v=0.05 * normal("vi", i, j, seed=seed) + 0.0 * phi,
+               albedo=np.clip(0.65 + 0.1 * normal("ai", i, j, seed=seed) + 0.0 * phi, 0.3, 0.9))
     return {k: np.ascontiguousarray(a) for k, a in out.items()}
 
 

@@ -45,6 +45,15 @@ struct cf_ctx {
     LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, nullptr, nullptr, nullptr};
     uint8_t* d_hint = nullptr;
     double* d_reduce = nullptr;  // [2·SALINITY_PARTIAL_BLOCKS partial sums][2 totals]
+    // atmosphere–sea-ice formulation (cf_set_sea_ice_formulation)
+    bool ice_ready = false;
+    cf_flux_params ice_params{};
+    cf_sea_ice_params ice_props{};
+    DevParams ice_dev{};
+    LoopParams ice_loop{};
+    IceParams ice_kernel{};
+    double* d_ice_tables = nullptr;
+    DevParams* d_ice_params = nullptr;
     // halo rows travel on their own stream so that they overlap the interpolation kernel, which
     // does not read the ocean state; consumers of the ocean fields wait on ev_comm_done
     hipStream_t comm_stream = nullptr;
@@ -418,6 +427,8 @@ int cf_destroy(cf_ctx* ctx) {
         (void)hipEventDestroy(ctx->ev_comm_done);
     }
     if (ctx->d_hint) (void)hipFree(ctx->d_hint);
+    if (ctx->d_ice_tables) (void)hipFree(ctx->d_ice_tables);
+    if (ctx->d_ice_params) (void)hipFree(ctx->d_ice_params);
     if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->own_stream) {
@@ -767,6 +778,77 @@ int cf_comm_destroy(cf_ctx* ctx) {
         NCCL_TRY(ctx, g_rccl.CommDestroy(ctx->comm));
         ctx->comm = nullptr;
     }
+    return CF_OK;
+}
+
+int cf_default_sea_ice_params(cf_sea_ice_params* p) {
+    if (!p) return fail(nullptr, CF_ERR_INVALID, "params is NULL");
+    std::memset(p, 0, sizeof *p);
+    p->struct_size = (int32_t)sizeof *p;
+    p->conductivity = 2.0;
+    p->consolidation_thickness = 0.05;
+    p->maximum_temperature_change = 5.0;
+    p->ice_salinity = 4.0;
+    p->liquidus_slope = 0.054;
+    p->freshwater_melting_temperature = 273.15;
+    p->albedo = 0.7;
+    p->emissivity = 1.0;
+    p->temperature_offset = 273.15;
+    return CF_OK;
+}
+
+int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, const cf_sea_ice_params* ice) {
+    if (!ctx || !ice) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation: NULL argument");
+    if (ice->struct_size != (int32_t)sizeof(cf_sea_ice_params))
+        return fail(ctx, CF_ERR_INVALID, "cf_sea_ice_params.struct_size = %d, library expects %zu", ice->struct_size,
+                    sizeof(cf_sea_ice_params));
+    if (!(ice->conductivity > 0) || !(ice->maximum_temperature_change > 0))
+        return fail(ctx, CF_ERR_INVALID, "sea-ice conductivity and maximum temperature change must be > 0");
+    DevParams d;
+    int rc = lower_params(ctx, ice_fluxes, &d);
+    if (rc != CF_OK) return rc;
+    if (ice_fluxes->flux_formulation != CF_FORMULATION_SIMILARITY)
+        return fail(ctx, CF_ERR_INVALID, "the atmosphere-sea-ice interface takes SimilarityTheoryFluxes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->d_ice_tables) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ice_tables, sizeof(double) * TABLE_DOUBLES));
+    if (!ctx->d_ice_params) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ice_params, sizeof(DevParams)));
+    std::vector<double> t = build_solver_tables(d.stability);
+    HIP_TRY(ctx, hipMemcpy(ctx->d_ice_tables, t.data(), sizeof(double) * TABLE_DOUBLES, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_ice_params, &d, sizeof(DevParams), hipMemcpyHostToDevice));
+    ctx->ice_params = *ice_fluxes;
+    ctx->ice_props = *ice;
+    ctx->ice_dev = d;
+    ctx->ice_loop = loop_params(*ice_fluxes, d);
+    IceParams K{};
+    K.inv_k = 1.0 / ice->conductivity;
+    K.hk_min = ice->consolidation_thickness / ice->conductivity;
+    K.dT_max = ice->maximum_temperature_change;
+    K.T_melt = ice->freshwater_melting_temperature;
+    K.T_fw = ice->freshwater_melting_temperature;
+    K.liquidus_slope = ice->liquidus_slope;
+    K.emissivity = ice->emissivity;
+    K.eps_sigma = ice->emissivity * ice_fluxes->stefan_boltzmann;
+    K.albedo = ice->albedo;
+    K.T_offset = ice->temperature_offset;
+    ctx->ice_kernel = K;
+    ctx->ice_ready = true;
+    return CF_OK;
+}
+
+int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, const cf_ocean_surface* ocean,
+                                         const cf_exchange_fields* atmos, const cf_interface_fluxes* out) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
+    if (!ice || !ice->thickness || !ice->top_temperature)
+        return fail(ctx, CF_ERR_INVALID, "sea-ice thickness and top temperature are NULL");
+    if (!ocean || !ocean->S) return fail(ctx, CF_ERR_INVALID, "ocean salinity is NULL");
+    if (ctx->ice_dev.mask_kind != CF_MASK_NONE && !ocean->mask) return fail(ctx, CF_ERR_INVALID, "ocean mask is NULL");
+    CHECK(check_exchange(ctx, atmos, true));
+    CHECK(check_fluxes(ctx, out));
+    CHECK(wait_for_halos(ctx));
+    HIP_TRY(ctx, launch_ai_fluxes(ctx->stream, ctx->launch, ctx->ice_dev, ctx->ice_loop, ctx->ice_kernel, ctx->grid, ice, ocean,
+                                  atmos, out, ctx->d_ice_tables, ctx->d_ice_params));
     return CF_OK;
 }
 

@@ -458,6 +458,109 @@ __device__ __forceinline__ Scales ly_iterate(const LoopParams& L, const CellCons
     return Scales{cr * U, ch * inv_cr * c.dtheta, ce * inv_cr * c.dq, L.maxiter};
 }
 
+// ---------------------------------------------------------------------------------------------
+// Atmosphere–sea-ice interface: the same iteration with a skin temperature inside the loop
+// (SkinTemperature(ConductiveFlux): surface energy balance against conduction through the ice,
+// limited to ±ΔTmax per iteration and capped at the freshwater melting point), saturation over ice,
+// sublimation enthalpy.  The surface state changes every iteration, so its thermodynamics cannot
+// be hoisted; roughness lengths follow the runtime kinds (constant in the production presets).
+// ---------------------------------------------------------------------------------------------
+struct IceParams {  // kernarg
+    double hk_min;      // consolidation thickness / conductivity
+    double inv_k;       // 1 / conductivity
+    double dT_max, T_melt, T_fw, liquidus_slope, eps_sigma, emissivity, albedo, T_offset;
+};
+
+struct IceConsts {
+    double rho, cp, qav, Ls, Ti, hk, Qd, theta_a, pa, du, dv, dU2, dU, alpha_g;
+};
+
+__device__ __forceinline__ double svp_ice_fast(const DevParams& P, const double* logt, double T, double inv_T) {
+    const double dcp = P.cp_v - P.cp_i;
+    const double a = dcp * P.inv_R_v, b = (P.LH_s0 - dcp * P.T_0) * P.inv_R_v;
+    return P.p_triple * fexp(__builtin_fma(a, flog(logt, T * P.inv_T_triple), b * (P.inv_T_triple - inv_T)));
+}
+
+template <bool COARE>
+__device__ __forceinline__ Scales ice_iterate(const DevParams& P, const LoopParams& L, const IceParams& I,
+                                              const IceConsts& c, const double* tab, bool active, double& Ts) {
+    const double* logt = tab + 4 * PSI_TABLE;
+    double us = 1e-4, ts = 1e-4, qq = 1e-4, drift = 0.0;
+    int it = 0;
+    for (;;) {
+        bool go;
+        if (L.fixed)
+            go = active && it < L.maxiter;
+        else
+            go = active && ((it == 0) || !(drift < L.tol || it >= L.maxiter));
+        if (__ballot(go) == 0ull) break;
+        if (go) {
+            // skin temperature from the energy balance with the previous scales
+            const double T2 = Ts * Ts;
+            const double rho_u = c.rho * us;
+            const double Qnet = -rho_u * c.Ls * qq + I.eps_sigma * T2 * T2 - rho_u * c.cp * ts + c.Qd;
+            double Tstar = __builtin_fma(-Qnet, c.hk, c.Ti);
+            Tstar = (Tstar != Tstar) ? Ts : Tstar;
+            const double dT = fmin(fmax(Tstar - Ts, -I.dT_max), I.dT_max);
+            Ts = fmin(Ts + dT, I.T_melt);
+            const double inv_Ts = frcp(Ts);
+            const double qs = svp_ice_fast(P, logt, Ts, inv_Ts) * frcp(c.rho * P.R_v * Ts);
+            const double dq = c.qav - qs, dtheta = c.theta_a - Ts;
+            const double lam_s = liquid_fraction_fast(P, logt, Ts);
+            const double pvs_s = svp_equil_fast(P, logt, Ts, inv_Ts, lam_s);
+            const AirState Sfc = air_state_fast(P, c.pa, Ts, inv_Ts, qs, lam_s, pvs_s);
+            const double gTv = P.g * frcp(Sfc.T_virtual);
+
+            const double bstar = gTv * __builtin_fma(ts, 1.0 + P.delta * Sfc.q_vap, P.delta * Sfc.T_virtual * qq);
+            const double Jb = -us * bstar;
+            double Ug = L.min_gust;
+            if (L.beta_gust != 0.0) Ug = fmax(L.beta_gust * fcbrt(fmax(Jb, 0.0) * L.h_bl), L.min_gust);
+            const double U = fsqrt1(__builtin_fma(Ug, Ug, c.dU2));
+
+            const double inv_us = frcp1(us);
+            double lu, log_lu;
+            if (L.m_kind == CF_ROUGHNESS_CONSTANT) {
+                lu = L.const_m;
+                log_lu = L.log_const_m;
+            } else {
+                const double lam_nu = P.rm.laminar * air_viscosity(P.rm, Ts);
+                const double lR = (us == 0.0) ? L.lm_m : lam_nu * inv_us;
+                lu = fmin(__builtin_fma(c.alpha_g * us, us, lR), L.lm_m);
+                log_lu = flog(logt, lu);
+            }
+            double log_lq = L.log_const_q, log_lt = L.log_const_t;
+            if (L.q_kind != CF_SCALAR_ROUGHNESS_CONSTANT)
+                log_lq = scalar_log_roughness(L.q_kind, L.b_q, L.log_A_q, L.log_lm_q, L.log_const_q, logt, lu, us,
+                                              frcp(air_viscosity(P.rq, Ts)));
+            if (L.t_kind != CF_SCALAR_ROUGHNESS_CONSTANT)
+                log_lt = L.same_scalar ? log_lq
+                                       : scalar_log_roughness(L.t_kind, L.b_t, L.log_A_t, L.log_lm_t, L.log_const_t, logt,
+                                                              lu, us, frcp(air_viscosity(P.rt, Ts)));
+
+            const double inv_L = (bstar == 0.0) ? 0.0 : (L.kappa * bstar) * (inv_us * inv_us);
+            const double2 psi_h2 = psi_eval_pair(tab, psi_arg_pos(logt, L.h_ref * inv_L));
+            double Du = L.log_h - log_lu - psi_h2.x;
+            double Dq = L.log_h - log_lq - psi_h2.y;
+            double Dt = L.log_h - log_lt - psi_h2.y;
+            if constexpr (!COARE) {
+                Du += psi_eval(tab, 0, psi_arg_pos(logt, lu * inv_L));
+                Dq += psi_eval(tab, 1, psi_arg_pos(logt, fexp(log_lq) * inv_L));
+                Dt += psi_eval(tab, 1, psi_arg_pos(logt, fexp(log_lt) * inv_L));
+            }
+            Du = fmax(Du, L.profile_floor);
+            Dq = fmax(Dq, L.profile_floor);
+            Dt = fmax(Dt, L.profile_floor);
+            const double un = L.kappa * frcp1(Du) * U, tn = L.kappa * frcp1(Dt) * dtheta, qn = L.kappa * frcp1(Dq) * dq;
+            drift = fabs(un - us) + fabs(tn - ts) + fabs(qn - qq);
+            us = un;
+            ts = tn;
+            qq = qn;
+            ++it;
+        }
+    }
+    return Scales{us, ts, qq, it};
+}
+
 __device__ __forceinline__ CellFluxes cell_epilogue(const CellConsts& c, double T_offset, Scales s) {
     CellFluxes R;
     const double inv_dU = (c.dU == 0.0) ? 0.0 : frcp(c.dU);

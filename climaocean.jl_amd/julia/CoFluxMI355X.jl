@@ -156,6 +156,34 @@ normalize_salinity_flux!(b::CoFluxBackend, flux::Ptr{Float64}, additional, area,
                        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Float64}),
                        b.ctx, flux, additional, area, mask, mean_out))
 
+# ---- atmosphere–sea-ice interface: compute_atmosphere_sea_ice_fluxes!(coupled_model) ---------------
+# SkinTemperature(ConductiveFlux) + SurfaceRadiationProperties(sea_ice_albedo, 1.0) (atmosphere.jl:34-44)
+mutable struct CfSeaIceParams
+    struct_size::Int32; reserved::Int32
+    conductivity::Float64; consolidation_thickness::Float64; maximum_temperature_change::Float64
+    ice_salinity::Float64; liquidus_slope::Float64; freshwater_melting_temperature::Float64
+    albedo::Float64; emissivity::Float64; temperature_offset::Float64
+    CfSeaIceParams() = new()
+end
+struct CfSeaIceState   # sea_ice.model.{ice_concentration, ice_thickness, top_surface_temperature, velocities}
+    concentration::Ptr{Float64}; thickness::Ptr{Float64}; top_temperature::Ptr{Float64}
+    u::Ptr{Float64}; v::Ptr{Float64}; albedo::Ptr{Float64}
+end
+function default_sea_ice_params()
+    p = CfSeaIceParams()
+    ccall((:cf_default_sea_ice_params, libcoflux), Cint, (Ref{CfSeaIceParams},), p)
+    return p
+end
+# `ice_fluxes` = corrected_atmosphere_sea_ice_fluxes(FT) / ncar_atmosphere_sea_ice_fluxes(FT) lowered to CfFluxParams
+set_sea_ice_formulation!(b::CoFluxBackend, ice_fluxes::CfFluxParams, ice::CfSeaIceParams = default_sea_ice_params()) =
+    check(b.ctx, ccall((:cf_set_sea_ice_formulation, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfFluxParams}, Ref{CfSeaIceParams}), b.ctx, ice_fluxes, ice))
+compute_atmosphere_sea_ice_fluxes!(b::CoFluxBackend, ice::CfSeaIceState, ocean::CfOceanSurface,
+                                   atmos::CfExchangeFields, out::CfInterfaceFluxes) =
+    check(b.ctx, ccall((:cf_compute_atmosphere_sea_ice_fluxes, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfSeaIceState}, Ref{CfOceanSurface}, Ref{CfExchangeFields}, Ref{CfInterfaceFluxes}),
+                       b.ctx, ice, ocean, atmos, out))
+
 # ---- latitude-slab halo rows over RCCL (Distributed(GPU(), partition = Partition(1, R))) -------
 comm_unique_id() = (id = zeros(UInt8, 128); ccall((:cf_comm_unique_id, libcoflux), Cint, (Ptr{UInt8},), id); id)
 comm_init!(b, id::Vector{UInt8}, rank, nranks) =   # `id` is MPI.bcast from rank 0

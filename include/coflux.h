@@ -371,6 +371,47 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
                     const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice,
                     const cf_net_ocean_fluxes* net);
 
+/* ------------------------------------------------------------------------------------------
+ * Atmosphere–sea-ice interface (config sites omip_simulation.jl:62-69 ":corrected",
+ * :105-113 ":ncar", atmosphere.jl:34-44).  Same Monin–Obukhov iteration, but the interface temperature is
+ * a skin temperature found inside the loop from the surface energy balance against the conductive flux
+ * through the ice (SkinTemperature(ConductiveFlux)), humidity saturates over ice, latent heat is that of
+ * sublimation.  The ice state itself (ClimaSeaIce) is prescribed input.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cf_sea_ice_params {
+    int32_t struct_size;                   /* sizeof(cf_sea_ice_params) */
+    int32_t reserved;
+    double conductivity;                   /* 2.0 W m⁻¹ K⁻¹  (ClimaSeaIce ConductiveFlux)          */
+    double consolidation_thickness;        /* 0.05 m: thinner ice conducts as if this thick          */
+    double maximum_temperature_change;     /* 5 K per iteration (SkinTemperature limiter)            */
+    double ice_salinity;                   /* reserved (the skin is capped at the FRESHWATER melting point) */
+    double liquidus_slope;                 /* 0.054 K per g/kg: ice bottom at T_fw − m·S_ocean           */
+    double freshwater_melting_temperature; /* 273.15 K                                               */
+    double albedo;                         /* 0.7 unless cf_sea_ice_state.albedo is given            */
+    double emissivity;                     /* 1.0, SurfaceRadiationProperties(sea_ice_albedo, 1.0), atmosphere.jl:44 */
+    double temperature_offset;             /* 273.15: top_surface_temperature is in °C, atmosphere.jl:38 */
+} cf_sea_ice_params;
+
+int cf_default_sea_ice_params(cf_sea_ice_params* p);
+
+/* sea_ice.model.{ice_concentration, ice_thickness, ice_thermodynamics.top_surface_temperature, velocities}
+ * (atmosphere.jl:34-39, src/ClimaOcean.jl:62-63); all at cell centres, ocean-grid layout. */
+typedef struct cf_sea_ice_state {
+    const double* concentration;    /* ℵ                                                             */
+    const double* thickness;        /* hᵢ [m]                                                        */
+    const double* top_temperature;  /* previous skin temperature [°C]: initial guess of the iteration */
+    const double* u;                /* ice velocity [m/s] or NULL (⇒ 0)                              */
+    const double* v;
+    const double* albedo;           /* per-cell albedo (SeaIceAlbedo(hi, hs, Ts), atmosphere.jl:39) or NULL */
+} cf_sea_ice_state;
+
+/* `ice_fluxes` = the atmosphere_sea_ice_fluxes formulation (e.g. corrected_atmosphere_sea_ice_fluxes). */
+int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, const cf_sea_ice_params* ice);
+/* compute_atmosphere_sea_ice_fluxes!(coupled_model): out.temperature receives the new skin temperature
+ * [°C]; latent_heat uses the sublimation enthalpy.  Needs exchange fields Qs, Ql as well. */
+int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, const cf_ocean_surface* ocean,
+                                         const cf_exchange_fields* atmos, const cf_interface_fluxes* out);
+
 /* NormalizeSalinity callback (src/OMIPConfigurations/omip_simulation.jl:182-220, added at :385-388):
  * subtract the global, area-weighted mean over wet cells of (salinity flux [+ additional flux]) from
  * the salinity-flux field — `compute!(mean_total); parent(flux_field) .-= mean_total`, so the constant

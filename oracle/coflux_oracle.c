@@ -637,6 +637,139 @@ int oracle_compute_net_ocean_fluxes(const cf_grid* g, const cf_flux_params* P, c
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Atmosphere–sea-ice interface: compute_atmosphere_sea_ice_fluxes! with
+ * SkinTemperature(ConductiveFlux) (restated from ClimaOcean ≤ v0.8 atmosphere_sea_ice_fluxes.jl /
+ * interface_states.jl; parameters omip_simulation.jl:62-69, atmosphere.jl:34-44).  PARITY UNPINNED.
+ * ---------------------------------------------------------------------------------------- */
+static double svp_ice(const cf_thermodynamics* t, const thermo_derived* d, double T) {
+    return svp_general(t, d, T, t->LH_s0, t->cp_v - t->cp_i);
+}
+
+static cell_result solve_ice_cell(const cf_flux_params* P, const cf_sea_ice_params* I, double ua, double va, double Ta,
+                                  double pa, double qa, double Qs, double Ql, double ui, double vi, double So,
+                                  double hi, double Ts_prev, double albedo, int wet) {
+    cell_result R;
+    memset(&R, 0, sizeof R);
+    const cf_thermodynamics* t = &P->thermo;
+    thermo_derived d = derive(t);
+    const double g = P->gravitational_acceleration, kappa = P->von_karman, h = P->reference_height;
+    int skip = (!wet) && (P->stop_kind == CF_STOP_CONVERGENCE);
+    double ustar = 1e-4, tstar = 1e-4, qstar = 1e-4;
+    double Ts = Ts_prev + I->temperature_offset;
+    int iters = 0;
+    if (skip) {
+        R.Ts_ocean_units = 0.0 - I->temperature_offset;
+        return R;
+    }
+    thermo_state Qa_ = phase_equil_pTq(t, &d, pa, Ta, qa);
+    const double rho_a = Qa_.rho, cp = cp_m(t, &d, &Qa_), qa_v = vapor_specific_humidity(t, &d, &Qa_);
+    const double Ls = t->LH_s0 + (t->cp_v - t->cp_i) * (Ta - t->T_0); /* latent_heat_sublim */
+    /* bottom of the ice at the melting temperature of the liquidus at the ocean salinity; the skin is
+       capped at the freshwater melting temperature under heating fluxes */
+    const double Ti = I->freshwater_melting_temperature - I->liquidus_slope * So;
+    const double Tm = I->freshwater_melting_temperature;
+    const double heff = fmax(hi, I->consolidation_thickness);
+    const double delta = d.eps - 1.0;
+    double du = ua - ui, dv = va - vi;
+    if (P->velocity_difference == CF_VELOCITY_WIND) {
+        du = ua;
+        dv = va;
+    }
+    const double dU = sqrt(du * du + dv * dv);
+    double up = ustar, tp = tstar, qp = qstar;
+    for (;;) {
+        int go;
+        if (P->stop_kind == CF_STOP_FIXED) {
+            go = iters < P->maxiter;
+        } else {
+            double drift = fabs(ustar - up) + fabs(tstar - tp) + fabs(qstar - qp);
+            go = (!((drift < P->tolerance) | (iters >= P->maxiter))) | (iters == 0);
+        }
+        if (!go) break;
+        up = ustar;
+        tp = tstar;
+        qp = qstar;
+        /* compute_interface_temperature(::SkinTemperature): surface energy balance with the scales of the
+           previous iterate, upwelling longwave at the previous skin temperature */
+        double Qu = I->emissivity * P->stefan_boltzmann * Ts * Ts * Ts * Ts;
+        double Qd = -(1.0 - albedo) * Qs - I->emissivity * Ql;
+        double Qc = -rho_a * cp * ustar * tstar;
+        double Qv = -rho_a * Ls * ustar * qstar;
+        double Qnet = Qv + Qu + Qc + Qd;
+        double Tstar = Ti - Qnet * heff / I->conductivity; /* flux_balance_temperature(ConductiveFlux) */
+        if (isnan(Tstar)) Tstar = Ts;
+        double dT = fmin(fmax(Tstar - Ts, -I->maximum_temperature_change), I->maximum_temperature_change);
+        Ts = fmin(Ts + dT, Tm);
+        double qs = svp_ice(t, &d, Ts) / (rho_a * d.R_v * Ts);
+        double dq = qa_v - qs;
+        double dtheta = Ta + g * h / cp - Ts;
+        thermo_state Sf = phase_equil_pTq(t, &d, pa, Ts, qs);
+        double Tv = virtual_temperature(t, &d, &Sf), qv_s = vapor_specific_humidity(t, &d, &Sf);
+        /* iterate_interface_fluxes */
+        double bstar = g / Tv * (tstar * (1.0 + delta * qv_s) + delta * Tv * qstar);
+        double Jb = -ustar * bstar;
+        double Ug = fmax(P->gustiness_parameter * cbrt(fmax(Jb, 0.0) * P->boundary_layer_height), P->minimum_gustiness);
+        double U = sqrt(du * du + dv * dv + Ug * Ug);
+        double lu = momentum_roughness(&P->momentum_roughness, g, ustar, dU, Ts);
+        double lq = scalar_roughness(&P->water_vapor_roughness, lu, ustar, Ts);
+        double lt = scalar_roughness(&P->temperature_roughness, lu, ustar, Ts);
+        double L = (bstar == 0.0) ? INFINITY : ustar * ustar / (kappa * bstar);
+        double chi_u = kappa / similarity_profile(P->similarity_form, P->stability_functions, 0, h, lu, L, P->similarity_profile_floor);
+        double chi_t = kappa / similarity_profile(P->similarity_form, P->stability_functions, 1, h, lt, L, P->similarity_profile_floor);
+        double chi_q = kappa / similarity_profile(P->similarity_form, P->stability_functions, 1, h, lq, L, P->similarity_profile_floor);
+        ustar = chi_u * U;
+        tstar = chi_t * dtheta;
+        qstar = chi_q * dq;
+        ++iters;
+    }
+    if (!wet) {
+        ustar = tstar = qstar = 0.0;
+        Ts = 0.0;
+    }
+    double taux = (dU == 0.0) ? 0.0 : -ustar * ustar * du / dU;
+    double tauy = (dU == 0.0) ? 0.0 : -ustar * ustar * dv / dU;
+    R.Qv = -rho_a * ustar * qstar * Ls;
+    R.Qc = -rho_a * cp * ustar * tstar;
+    R.Fv = -rho_a * ustar * qstar;
+    R.rho_tau_x = rho_a * taux;
+    R.rho_tau_y = rho_a * tauy;
+    R.Ts_ocean_units = Ts - I->temperature_offset;
+    R.ustar = ustar;
+    R.theta_star = tstar;
+    R.q_star = qstar;
+    R.iterations = iters;
+    return R;
+}
+
+int oracle_compute_atmosphere_sea_ice_fluxes(const cf_grid* g, const cf_flux_params* P, const cf_sea_ice_params* I,
+                                             const cf_sea_ice_state* ice, const cf_ocean_surface* o,
+                                             const cf_exchange_fields* a, const cf_interface_fluxes* out) {
+    int r = g->ring;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int j = -r; j < g->ny + r; ++j)
+        for (int i = -r; i < g->nx + r; ++i) {
+            size_t k = IDX(g, i, j);
+            cell_result R = solve_ice_cell(P, I, a->u[k], a->v[k], a->T[k], a->p[k], a->q[k], a->Qs[k], a->Ql[k],
+                                           ice->u ? ice->u[k] : 0.0, ice->v ? ice->v[k] : 0.0, o->S[k],
+                                           ice->thickness[k], ice->top_temperature[k],
+                                           ice->albedo ? ice->albedo[k] : I->albedo, is_wet(P, g, o->mask, i, j));
+            out->sensible_heat[k] = R.Qc;
+            out->latent_heat[k] = R.Qv;
+            out->water_vapor[k] = R.Fv;
+            out->x_momentum[k] = R.rho_tau_x;
+            out->y_momentum[k] = R.rho_tau_y;
+            out->temperature[k] = R.Ts_ocean_units;
+            if (out->friction_velocity) out->friction_velocity[k] = R.ustar;
+            if (out->temperature_scale) out->temperature_scale[k] = R.theta_star;
+            if (out->humidity_scale) out->humidity_scale[k] = R.q_star;
+            if (out->iterations) out->iterations[k] = R.iterations;
+        }
+    return 0;
+}
+
 /* NormalizeSalinity (src/OMIPConfigurations/omip_simulation.jl:182-220): `compute!(mean_total)` is
  * Oceananigans' Average over dims (1,2) — area weighted, immersed cells excluded — and
  * `parent(flux_field) .-= mean_total` subtracts it from the whole parent array. */

@@ -295,6 +295,92 @@ def _large_yeager(fluxes, du, dv, dth, dq, Tv, qv, delta, kap, g, h, wet):
     return cr * U, ch / cr * dth, ce / cr * dq, np.full(du.shape, n, np.int32)
 
 
+def atmosphere_sea_ice_fluxes(fluxes, iprops, ice, ocean, atmos, *, hx, hy, ring, thermodynamics, ocean_properties,
+                              velocity_difference="relative", h=10.0, h_bl=600.0, g=9.81, sigma=5.67e-8):
+    """Atmosphere–sea-ice interface with SkinTemperature(ConductiveFlux); second, independent restatement."""
+    from coflux import interface_computations as ic
+    th = Thermo(thermodynamics)
+    ny, nx = ocean["T"].shape[0] - 2 * hy, ocean["T"].shape[1] - 2 * hx
+    W = (slice(hy - ring, hy + ny + ring), slice(hx - ring, hx + nx + ring))
+    Ti = iprops.freshwater_melting_temperature - iprops.liquidus_slope * ocean["S"][W]  # ice bottom on the liquidus
+    wet = ocean["mask"][W] != 0 if ocean.get("mask") is not None else np.ones(Ti.shape, bool)
+    ua, va, Ta, pa, qa, Qs, Ql = (atmos[k][W] for k in ("u", "v", "T", "p", "q", "Qs", "Ql"))
+    ui = ice["u"][W] if ice.get("u") is not None else 0.0
+    vi = ice["v"][W] if ice.get("v") is not None else 0.0
+    alb = ice["albedo"][W] if ice.get("albedo") is not None else iprops.albedo
+    hi = ice["thickness"][W]
+    Ts = ice["top_temperature"][W] + iprops.temperature_offset
+    A = th.state_pTq(pa, Ta, qa)
+    rho, cp, qav = A["rho"], th.cp_m(A), th.q_vapor(A)
+    Ls = th.Ls0 + (th.cpv - th.cpi) * (Ta - th.T0)
+    Tm = iprops.freshwater_melting_temperature
+    heff = np.maximum(hi, iprops.consolidation_thickness)
+    if velocity_difference == "relative":
+        du, dv = ua - ui, va - vi
+    else:
+        du, dv = ua + 0 * Ti, va + 0 * Ti
+    dU = np.sqrt(du * du + dv * dv)
+    delta, kap = th.eps - 1.0, fluxes.von_karman_constant
+    stab = fluxes.stability_functions.name
+    coare = isinstance(fluxes.similarity_form, ic.COARELogarithmicSimilarityProfile)
+    sc = fluxes.solver_stop_criteria
+    fixed = isinstance(sc, ic.FixedIterations)
+    maxit = sc.iterations if fixed else sc.maxiter
+    us = np.full(Ti.shape, 1e-4)
+    ts, qq = us.copy(), us.copy()
+    its = np.zeros(Ti.shape, np.int32)
+    active = np.ones(Ti.shape, bool) if fixed else wet.copy()
+    it = 0
+    while active.any() and it < maxit:
+        Qnet = -rho * Ls * us * qq + iprops.emissivity * sigma * Ts ** 4 - rho * cp * us * ts \
+            - (1 - alb) * Qs - iprops.emissivity * Ql
+        Tstar = Ti - Qnet * heff / iprops.conductivity
+        Tn = np.minimum(Ts + np.clip(Tstar - Ts, -iprops.maximum_temperature_change, iprops.maximum_temperature_change), Tm)
+        qs = th.svp(Tn, th.Ls0, th.cpv - th.cpi) / (rho * th.Rv * Tn)
+        dq, dth = qav - qs, Ta + g * h / cp - Tn
+        S = th.state_pTq(pa, Tn, qs)
+        Tv, qv = th.T_virtual(S), th.q_vapor(S)
+        b = g / Tv * (ts * (1 + delta * qv) + delta * Tv * qq)
+        Ug = np.maximum(fluxes.gustiness_parameter * np.cbrt(np.maximum(-us * b, 0.0) * h_bl), fluxes.minimum_gustiness)
+        U = np.sqrt(du * du + dv * dv + Ug * Ug)
+        lu = momentum_length(fluxes.momentum_roughness_length, g, us, dU, Tn)
+        lq = scalar_length(fluxes.water_vapor_roughness_length, lu, us, Tn)
+        lt = scalar_length(fluxes.temperature_roughness_length, lu, us, Tn)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            L = np.where(b == 0, np.inf, us * us / (kap * b))
+
+            def prof(psi, l):
+                r = np.log(h / l) - psi(stab, h / L)
+                r = r if coare else r + psi(stab, l / L)
+                return np.maximum(r, fluxes.similarity_profile_floor)
+
+            nus, nts, nqs = kap / prof(psi_m, lu) * U, kap / prof(psi_h, lt) * dth, kap / prof(psi_h, lq) * dq
+        drift = np.abs(nus - us) + np.abs(nts - ts) + np.abs(nqs - qq)
+        us, ts, qq, Ts = (np.where(active, n_, o_) for n_, o_ in ((nus, us), (nts, ts), (nqs, qq), (Tn, Ts)))
+        its += active
+        it += 1
+        if not fixed:
+            active = active & ~(drift < sc.tolerance)
+    zero = ~wet
+    us, ts, qq = (np.where(zero, 0.0, a) for a in (us, ts, qq))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tx = np.where(dU == 0, 0.0, -us * us * du / dU)
+        ty = np.where(dU == 0, 0.0, -us * us * dv / dU)
+    res = dict(sensible_heat=-rho * cp * us * ts, latent_heat=-rho * us * qq * Ls, water_vapor=-rho * us * qq,
+               x_momentum=rho * tx, y_momentum=rho * ty,
+               temperature=np.where(zero, 0.0, Ts) - iprops.temperature_offset,
+               friction_velocity=us, temperature_scale=ts, humidity_scale=qq)
+    out = {}
+    for k, a in res.items():
+        full = np.zeros(ocean["T"].shape)
+        full[W] = np.where(a == 0, 0.0, a)
+        out[k] = full
+    full = np.zeros(ocean["T"].shape, np.int32)
+    full[W] = its
+    out["iterations"] = full
+    return out
+
+
 def _pack_fluxes(th, A, Ta, Ts, du, dv, us, ts, qq, its, wet, ocean, ocean_properties, W):
     dU = np.sqrt(du * du + dv * dv)
     zero = ~wet

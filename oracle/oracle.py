@@ -180,6 +180,31 @@ def compute_net_ocean_fluxes(g, params, ocean, atmos, fluxes, ice=None, weights=
     return out
 
 
+def compute_atmosphere_sea_ice_fluxes(g, params, ice_params, ice, ocean, atmos):
+    """ice: dict with thickness, top_temperature (°C) and optionally u, v, albedo, concentration."""
+    lib, keep = load(), []
+    names = ["sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum", "temperature",
+             "friction_velocity", "temperature_scale", "humidity_scale"]
+    out = {n: np.zeros(_shape(g)) for n in names}
+    out["iterations"] = np.zeros(_shape(g), np.int32)
+    o = _ocean_struct(ocean, keep)
+    a = {n: _f64(atmos[n]) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
+    e = _exchange_struct(a)
+    st = abi.SeaIceState()
+    for n in ("concentration", "thickness", "top_temperature", "u", "v", "albedo"):
+        if ice.get(n) is not None:
+            arr = _f64(ice[n])
+            keep.append(arr)
+            setattr(st, n, _ptr(arr))
+    f = abi.InterfaceFluxes()
+    for n, arr in out.items():
+        setattr(f, n, _ptr(arr))
+    rc = lib.oracle_compute_atmosphere_sea_ice_fluxes(C.byref(g), C.byref(params), C.byref(ice_params), C.byref(st),
+                                                      C.byref(o), C.byref(e), C.byref(f))
+    assert rc == 0
+    return out
+
+
 def normalize_salinity_flux(g, params, flux, mask, additional=None, area=None):
     """Returns (normalised flux copy, mean)."""
     lib = load()

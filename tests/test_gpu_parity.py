@@ -368,3 +368,77 @@ def test_c_driver_through_the_abi(tmp_path):
     f32 = lambda x: float(np.float32(x))  # the JRA55 window is Float32  # noqa: E731
     ref = orc.solve_cell(ic.flux_params(), 6.0, 2.0, f32(288.15), 101325.0, f32(0.008), 0.1, -0.05, 18.0, 35.0)
     assert abs(lh - ref["Qv"]) < 1e-9 * abs(ref["Qv"])
+
+
+# ---------------------------------------------------------------------------------------------
+# atmosphere–sea-ice interface (cf_compute_atmosphere_sea_ice_fluxes)
+# ---------------------------------------------------------------------------------------------
+TOL_ICE = 1e-9  # cells converging within 40 iterations; slower ones 1e-6 (util.compare_ice_fluxes)
+
+
+def run_ice(case, config, *, ring=1, albedo=True, drift=True, atmos_override=None):
+    nx, ny, hx, hy = case["nx"], case["ny"], case["hx"], case["hy"]
+    fluxes_f, vd = util.ICE_CONFIGS[config]()
+    ice_params = ic.flux_params(fluxes_f, velocity_difference=vd)
+    props = ic.SeaIceInterfaceProperties()
+    g = orc.make_grid(nx, ny, hx, hy, ring)
+    at = util.polar_atmosphere(orc.interpolate_atmosphere_state(g, case["src"], case["weights"], 0, 1, 0.37))
+    if atmos_override:
+        at.update(atmos_override)
+    state = dict(case["ice_state"])
+    if not albedo:
+        state["albedo"] = None
+    if not drift:
+        state["u"] = state["v"] = None
+    ref = orc.compute_atmosphere_sea_ice_fluxes(g, ice_params, props.to_params(), state, case["ocean"], at)
+
+    ctx = FluxContext(nx, ny, hx, hy, ic.flux_params(), ring=ring)   # the ocean formulation is independent
+    ctx.set_sea_ice_formulation(ice_params, props.to_params())
+    dev = ctx.to_device
+    ocean = {k: dev(case["ocean"][k]) for k in ("T", "S", "u", "v", "mask")}
+    atmos = {k: dev(at[k]) for k in EXCHANGE_NAMES}
+    st = {k: dev(v) for k, v in state.items() if v is not None}
+    out = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL)
+    out["iterations"] = ctx.zeros(torch.int32)
+    ctx.compute_atmosphere_sea_ice_fluxes(st, ocean, atmos, out)
+    ctx.sync()
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    ctx.close()
+    W = lambda a: util.window(a, hx, hy, nx, ny, ring)
+    return {k: W(v) for k, v in got.items()}, {k: W(v) for k, v in ref.items()}
+
+
+@pytest.mark.parametrize("config", list(util.ICE_CONFIGS))
+def test_sea_ice_interface_90x40_all_formulations(config):
+    got, ref = run_ice(util.build_case(90, 40), config)
+    worst = util.compare_ice_fluxes(got, ref, TOL_ICE)
+    print(config, worst)
+
+
+def test_sea_ice_interface_defaults_and_ragged_size():
+    """Constant albedo, ice at rest, a surface that is no multiple of the chunk or the wave size."""
+    got, ref = run_ice(util.build_case(131, 67), "sea_ice_corrected", albedo=False, drift=False)
+    util.compare_ice_fluxes(got, ref, TOL_ICE)
+
+
+def test_sea_ice_interface_melting_cap_and_land():
+    case = util.build_case(90, 40)
+    shape = case["ocean"]["T"].shape
+    got, ref = run_ice(case, "sea_ice_corrected",
+                       atmos_override=dict(Qs=np.full(shape, 900.0), T=np.full(shape, 283.15)))
+    util.compare_ice_fluxes(got, ref, TOL_ICE)
+    land = util.window(case["ocean"]["mask"], 3, 3, 90, 40, 1) == 0
+    assert np.all(got["sensible_heat"][land] == 0.0) and np.all(got["temperature"][land] == -273.15)
+    conv = ~land & (ref["iterations"] < 100)
+    assert np.all(got["temperature"][conv] <= 0.0) and np.any(got["temperature"][conv] == 0.0)
+
+
+def test_sea_ice_interface_requires_formulation():
+    from coflux.runtime import CofluxError
+    ctx = FluxContext(16, 8, 2, 2, ic.flux_params())
+    z = ctx.field_set(("thickness", "top_temperature") + tuple(EXCHANGE_NAMES) + ("T_", "S"))
+    with pytest.raises(CofluxError, match="cf_set_sea_ice_formulation"):
+        ctx.compute_atmosphere_sea_ice_fluxes(dict(thickness=z["thickness"], top_temperature=z["top_temperature"]),
+                                              dict(T=z["T_"], S=z["S"]), {k: z[k] for k in EXCHANGE_NAMES},
+                                              ctx.field_set(FLUX_NAMES))
+    ctx.close()

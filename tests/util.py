@@ -25,6 +25,19 @@ CONFIGS = {
 }
 
 
+def _fixed(fluxes, n):
+    fluxes.solver_stop_criteria = ic.FixedIterations(n)
+    return fluxes
+
+
+ICE_CONFIGS = {
+    "sea_ice_corrected": lambda: (ic.corrected_atmosphere_sea_ice_fluxes(), ic.RelativeVelocity()),
+    "sea_ice_ncar": lambda: (ic.ncar_atmosphere_sea_ice_fluxes(), ic.WindVelocity()),
+    "sea_ice_default": lambda: (ic.SimilarityTheoryFluxes(), None),
+    "sea_ice_fixed5": lambda: (_fixed(ic.corrected_atmosphere_sea_ice_fluxes(), 5), None),
+}
+
+
 def build_case(nx, ny, hx=3, hy=3, *, weights="latlon", land=True, n_levels=2, ny_global=None, j_offset=0):
     ocean = syn.ocean_state(nx, ny, hx, hy, ny_global=ny_global, j_offset=j_offset, land_fraction=land)
     src = syn.jra55_snapshots(n_levels)
@@ -36,7 +49,21 @@ def build_case(nx, ny, hx=3, hy=3, *, weights="latlon", land=True, n_levels=2, n
         w = dict(separable=False, fi=fi, fj=fj, cos_rot=c, sin_rot=s, latitude=phi)
     ice = dict(concentration=ocean["ice_concentration"], interface_heat=ocean["ice_interface_heat"],
                salt_flux=ocean["ice_salt_flux"], x_stress=ocean["ice_x_stress"], y_stress=ocean["ice_y_stress"])
-    return dict(nx=nx, ny=ny, hx=hx, hy=hy, ocean=ocean, src=src, weights=w, ice=ice)
+    ice_state = syn.sea_ice_state(nx, ny, hx, hy, ny_global=ny_global, j_offset=j_offset)
+    ice_state["concentration"] = ocean["ice_concentration"]
+    return dict(nx=nx, ny=ny, hx=hx, hy=hy, ocean=ocean, src=src, weights=w, ice=ice, ice_state=ice_state)
+
+
+def polar_atmosphere(at):
+    """Turn the interpolated (mostly warm) synthetic atmosphere into a polar one so that the sea-ice
+    skin temperature sits below the melting point on most cells: T 252–267 K, q at 80 % of
+    saturation, weak shortwave, 200 W/m² longwave."""
+    out = {k: np.array(v, dtype=np.float64, copy=True) for k, v in at.items()}
+    out["T"] = 253.0 + 0.5 * (at["T"] - 273.15)
+    out["q"] = 0.8 * syn._qsat_tetens(out["T"], out["p"]) * (0.9 + 0.1 * at["q"] / np.max(at["q"]))
+    out["Qs"] = 0.3 * at["Qs"]
+    out["Ql"] = 200.0 + 0.5 * (at["Ql"] - 350.0)
+    return out
 
 
 def window(a, hx, hy, nx, ny, ring):
@@ -47,3 +74,33 @@ def rel_err(got, ref, scale):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     return float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), scale)))
+
+
+ICE_FLUX_FIELDS = ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum", "temperature",
+                   "friction_velocity", "temperature_scale", "humidity_scale")
+
+
+def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=1e-3, maxiter=100, tol_slow=1e-6, slow=40):
+    """Sea-ice interface comparison, same-shape windows.  The explicit skin-temperature balance does not
+    contract for thick ice (gain ≈ (h/k)·∂Q/∂T > 1): those cells orbit under the ±ΔTmax limiter until
+    `maxiter`, and the orbit amplifies rounding differences by ≈1.3× per iteration (two CPU restatements
+    already differ by 1e-5 there).  Cells the reference leaves unconverged are therefore held to
+    `tol_unconverged`; cells that do converge but need more than `slow` iterations (a weakly contracting
+    orbit, same amplification) to the north-star `tol_slow` = 1e-6; every other cell to `tol_converged`."""
+    unconv = np.asarray(ref["iterations"]) >= maxiter
+    # collapsed turbulence (u★ → 1e-11 on the −5ζ branch): ζ leaves the ψ tables' range |ζ| ≤ 1.6e9, where the
+    # device clamps ψ; u★ then differs by ≈4e-11 m/s in absolute terms, all fluxes are < 1e-9 of their scale
+    collapsed = np.asarray(ref["friction_velocity"]) < 1e-8
+    slowc = ((np.asarray(ref["iterations"]) > slow) | collapsed) & ~unconv
+    fast = ~unconv & ~slowc
+    assert np.array_equal(np.asarray(got["iterations"])[~unconv], np.asarray(ref["iterations"])[~unconv])
+    worst = {}
+    for k in ICE_FLUX_FIELDS:
+        g, r = np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64)
+        err = np.abs(g - r) / np.maximum(np.abs(r), FIELD_SCALE[k])
+        worst[k] = (float(err[fast].max(initial=0.0)), float(err[slowc].max(initial=0.0)),
+                    float(err[unconv].max(initial=0.0)))
+        assert worst[k][0] <= tol_converged, (k, worst[k])
+        assert worst[k][1] <= max(tol_slow, tol_converged), (k, worst[k])
+        assert worst[k][2] <= tol_unconverged, (k, worst[k])
+    return worst
