@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -42,8 +43,17 @@ struct cf_ctx {
     hipStream_t stream = nullptr;
     LoopParams fast{};
     DevParams* d_params = nullptr;
-    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, nullptr, nullptr, nullptr};
+    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, 0, 256, nullptr, nullptr, nullptr, nullptr, 0};
     uint8_t* d_hint = nullptr;
+    // cost-balanced chunk table of the solver, rebuilt when the wet mask (pointer / kind / surface z) changes
+    int* d_chunk_sums = nullptr;
+    int* d_chunk_begins = nullptr;
+    int* d_chunk_meta = nullptr;
+    const void* chunk_mask = nullptr;
+    int chunk_mask_kind = -1;
+    double chunk_z_surface = 0.0;
+    int chunk_wet = 0;      // wet cells per chunk actually used
+    bool chunk_valid = false;
     double* d_reduce = nullptr;  // [2·SALINITY_PARTIAL_BLOCKS partial sums][2 totals]
     // atmosphere–sea-ice formulation (cf_set_sea_ice_formulation)
     bool ice_ready = false;
@@ -261,6 +271,37 @@ static LoopParams loop_params(const cf_flux_params& p, const DevParams& d) {
 }
 
 // (Re)build the LDS tables for the configured stability functions and upload them.
+// The solver's chunk table depends on the wet mask only (coflux_solver.hip).  Built on the first call and
+// whenever the mask pointer, its kind or the surface z changes; costs three tiny kernels and two 4-byte
+// read-backs.  A mask rewritten in place keeps the old table — slower at worst, never wrong.
+static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
+    const DevParams& d = ctx->dev;
+    const void* key = d.mask_kind == CF_MASK_NONE ? nullptr : mask;
+    if (ctx->chunk_valid && ctx->chunk_mask == key && ctx->chunk_mask_kind == d.mask_kind &&
+        ctx->chunk_z_surface == d.z_surface)
+        return CF_OK;
+    const int ncells = (ctx->grid.nx + 2 * ctx->grid.ring) * (ctx->grid.ny + 2 * ctx->grid.ring);
+    if (!ctx->d_chunk_sums) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_sums, sizeof(int) * chunk_sums_capacity(ncells)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_begins, sizeof(int) * chunk_table_capacity(ncells)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_meta, sizeof(int) * 4));
+    }
+    int wet = 0, n = 0;
+    HIP_TRY(ctx, build_chunk_table(ctx->stream, ctx->d_params, ctx->grid, mask, ctx->launch.cu_count, ctx->launch.ao_chunk,
+                                   ctx->d_chunk_sums, ctx->d_chunk_begins, ctx->d_chunk_meta, &wet, &n));
+    if (n <= 0 || n + 1 > chunk_table_capacity(ncells)) return fail(ctx, CF_ERR_HIP, "chunk table of %d entries is invalid", n);
+    ctx->chunk_mask = key;
+    ctx->chunk_mask_kind = d.mask_kind;
+    ctx->chunk_z_surface = d.z_surface;
+    ctx->chunk_wet = wet;
+    ctx->chunk_valid = true;
+    ctx->launch.d_chunk_begins = ctx->d_chunk_begins;
+    ctx->launch.n_chunks = n;
+    if (std::getenv("COFLUX_DEBUG"))
+        std::fprintf(stderr, "[coflux] chunk table: %d chunks of %d wet cells (%d CUs)\n", n, wet, ctx->launch.cu_count);
+    return CF_OK;
+}
+
 static int install_params(cf_ctx* ctx, const cf_flux_params* params) {
     DevParams d;
     int rc = lower_params(ctx, params, &d);
@@ -283,6 +324,7 @@ static int install_params(cf_ctx* ctx, const cf_flux_params* params) {
     if (hipMemcpy(ctx->d_params, &d, sizeof(DevParams), hipMemcpyHostToDevice) != hipSuccess)
         return fail(ctx, CF_ERR_HIP, "upload of the device parameter block failed");
     ctx->launch.d_params = ctx->d_params;
+    ctx->chunk_valid = false;
     return CF_OK;
 }
 
@@ -408,8 +450,10 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
     }
     ctx->launch.d_hint = ctx->d_hint;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         ctx->launch.max_blocks = ((4 * prop.multiProcessorCount + 7) / 8) * 8;
+        ctx->launch.cu_count = prop.multiProcessorCount;
+    }
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return CF_OK;
@@ -427,6 +471,9 @@ int cf_destroy(cf_ctx* ctx) {
         (void)hipEventDestroy(ctx->ev_comm_done);
     }
     if (ctx->d_hint) (void)hipFree(ctx->d_hint);
+    if (ctx->d_chunk_sums) (void)hipFree(ctx->d_chunk_sums);
+    if (ctx->d_chunk_begins) (void)hipFree(ctx->d_chunk_begins);
+    if (ctx->d_chunk_meta) (void)hipFree(ctx->d_chunk_meta);
     if (ctx->d_ice_tables) (void)hipFree(ctx->d_ice_tables);
     if (ctx->d_ice_params) (void)hipFree(ctx->d_ice_params);
     if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
@@ -463,6 +510,12 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             return CF_OK;
         case CF_OPT_TRIP_HINTS:
             ctx->launch.d_hint = value ? ctx->d_hint : nullptr;
+            return CF_OK;
+        case CF_OPT_AO_CHUNK:
+            if (value != 0 && value != 256 && value != 512 && value != 768)
+                return fail(ctx, CF_ERR_INVALID, "solver chunk %d: wet cells per workgroup must be 0 (automatic), 256, 512 or 768", value);
+            ctx->launch.ao_chunk = value;
+            ctx->chunk_valid = false;
             return CF_OK;
         default: return fail(ctx, CF_ERR_INVALID, "unknown option %d", option);
     }
@@ -596,6 +649,7 @@ int cf_compute_atmosphere_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocea
     CHECK(wait_for_halos(ctx));
     if (ctx->launch.solver == CF_SOLVER_LIBM && ctx->params.flux_formulation == CF_FORMULATION_LARGE_YEAGER)
         return fail(ctx, CF_ERR_INVALID, "CF_SOLVER_LIBM implements SimilarityTheoryFluxes only");
+    CHECK(ensure_chunk_table(ctx, ocean->mask));
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, out));
     return CF_OK;
 }
@@ -626,6 +680,7 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     // interpolate → solver → net fluxes, stream-ordered.  (Fusing the interpolation into the solver
     // saves the 40 B/cell re-read of the atmosphere state — ≈ 6 µs — but ties the FP64-issue-bound
     // solver to the interpolation's tile geometry and LDS footprint; measured slower, see DESIGN.md.)
+    CHECK(ensure_chunk_table(ctx, ocean->mask));
     const bool rec = ctx->prof_count < ctx->prof_capacity;
     hipEvent_t* ev = rec ? &ctx->prof_events[4 * (size_t)ctx->prof_count] : nullptr;
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));

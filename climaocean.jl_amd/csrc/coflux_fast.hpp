@@ -3,14 +3,15 @@
 // Same iteration, same initial guess and same stop rule as the reference path (see
 // coflux_device.hpp::solve_cell, which is kept as the libm cross-check), but every
 // transcendental is replaced by something CDNA4 can issue cheaply in FP64:
-//   * ψ_m, ψ_h  : degree-7 piecewise polynomials in w = log(1 + 16|ζ|) staged in LDS
-//                 (coflux_tables.cpp); one instruction stream for both signs of ζ;
+//   * ψ_m, ψ_h  : degree-9 piecewise polynomials in x = 1 + 16|ζ| staged in LDS, the segment taken from
+//                 the exponent and top mantissa bits of x — no logarithm (coflux_tables.cpp); one
+//                 instruction stream for both signs of ζ;
 //   * log       : 128-entry mantissa table in LDS + degree-6 log1p polynomial;
 //   * exp       : Cody–Waite reduction + degree-12 polynomial (v_ldexp_f64 to rebuild);
 //   * cbrt      : v_log_f32 / v_exp_f32 seed + one FP64 Halley step;
 //   * sqrt, 1/x : v_rsq_f64 / v_rcp_f64 + Newton steps, no IEEE division sequences.
-// Everything is accurate to a few ulp (≤ 2e-13 for ψ), far inside the 1e-9 parity tolerance,
-// and an iteration costs ≈ 300 FP64 instructions instead of ≈ 2200 with ocml.
+// Everything is accurate to a few ulp (≤ 3e-14 for ψ), far inside the 1e-9 parity tolerance,
+// and an iteration costs ≈ 200 VALU instructions instead of ≈ 2200 with ocml.
 #pragma once
 #include "coflux_device.hpp"
 #include "coflux_tables.h"
@@ -110,20 +111,19 @@ __device__ __forceinline__ double fcbrt(double x) {  // x ≥ 0
 // tabulated stability functions
 // ---------------------------------------------------------------------------------------------
 struct PsiArg {
-    int k;       // segment
-    double t;    // position in the segment, [-1, 1]
+    int k;       // segment: 4·(binade of x) + top two mantissa bits, x = 1 + 16|ζ|
+    double t;    // u = x − (segment start) ≥ 0: the polynomial variable (an exact subtraction)
     int side;    // 0: ζ < 0 (unstable table), 1: ζ ≥ 0
 };
 
-__device__ __forceinline__ PsiArg psi_arg(const double* logt, double zeta) {
+// No logarithm: the table is indexed by the floating-point representation of x itself.
+// |ζ| > 4.3e9 (never a converged state) and NaN are evaluated at the table edge.
+__device__ __forceinline__ PsiArg psi_arg(double zeta) {
     PsiArg a;
-    double w = flog(logt, __builtin_fma(PSI_A, fabs(zeta), 1.0));
-    w = fmin(w, PSI_WMAX);  // |ζ| > 1.65e9 is evaluated at the table edge (never a converged state)
-    const double s = w * (PSI_SEG / PSI_WMAX);
-    int k = (int)s;
-    k = min(k, PSI_SEG - 1);
-    a.k = k;
-    a.t = __builtin_fma(2.0, s - (double)k, -1.0);
+    const double x = fmin(__builtin_fma(PSI_A, fabs(zeta), 1.0), 0x1.fffffffffffffp35);
+    const int hi = __double2hiint(x);
+    a.k = (hi >> 18) - (1023 << 2);
+    a.t = x - __hiloint2double(hi & (int)0xfffc0000, 0);
     a.side = zeta < 0.0 ? 0 : 1;
     return a;
 }
@@ -131,29 +131,43 @@ __device__ __forceinline__ PsiArg psi_arg(const double* logt, double zeta) {
 // fn: 0 = ψ_m, 1 = ψ_h.  Table layout: [side][coefficient][segment]{ψ_m, ψ_h} (coflux_tables.cpp).
 __device__ __forceinline__ double psi_eval(const double* psi, int fn, const PsiArg& a) {
     const double* c = psi + ((size_t)(a.side * (PSI_DEG + 1)) * PSI_SEG + a.k) * 2 + fn;
-    double p = c[7 * 2 * PSI_SEG];
-    p = __builtin_fma(p, a.t, c[6 * 2 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[5 * 2 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[4 * 2 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[3 * 2 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[2 * 2 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[1 * 2 * PSI_SEG]);
-    p = __builtin_fma(p, a.t, c[0]);
+    double p = c[PSI_DEG * 2 * PSI_SEG];
+#pragma unroll
+    for (int j = PSI_DEG - 1; j >= 0; --j) p = __builtin_fma(p, a.t, c[j * 2 * PSI_SEG]);
     return p;
 }
 
-// ψ_m and ψ_h at the same argument: eight 16-byte LDS reads feed both Horner chains
+// ψ_m and ψ_h at the same argument: 16-byte LDS reads feed both Horner chains
 __device__ __forceinline__ double2 psi_eval_pair(const double* psi, const PsiArg& a) {
     const double2* c = reinterpret_cast<const double2*>(psi) + (size_t)(a.side * (PSI_DEG + 1)) * PSI_SEG + a.k;
-    double2 v = c[7 * PSI_SEG];
+    double2 v = c[PSI_DEG * PSI_SEG];
     double pm = v.x, ph = v.y;
 #pragma unroll
-    for (int j = 6; j >= 0; --j) {
+    for (int j = PSI_DEG - 1; j >= 0; --j) {
         v = c[j * PSI_SEG];
         pm = __builtin_fma(pm, a.t, v.x);
         ph = __builtin_fma(ph, a.t, v.y);
     }
     return make_double2(pm, ph);
+}
+
+// ψ_m(a) and ψ_h(b) for two arguments of the same sign.  The roughness-length arguments ℓ/L★ are ≪ 1, so both
+// almost always fall into the same table segment: then one chain of 16-byte reads feeds both (half the LDS time
+// of two 8-byte chains).  The branch is wave-uniform; all active lanes must call this together.
+__device__ __forceinline__ double2 psi_eval_mh(const double* psi, const PsiArg& a, const PsiArg& b) {
+    if (__all(a.k == b.k)) {
+        const double2* c = reinterpret_cast<const double2*>(psi) + (size_t)(a.side * (PSI_DEG + 1)) * PSI_SEG + a.k;
+        double2 v = c[PSI_DEG * PSI_SEG];
+        double pm = v.x, ph = v.y;
+#pragma unroll
+        for (int j = PSI_DEG - 1; j >= 0; --j) {
+            v = c[j * PSI_SEG];
+            pm = __builtin_fma(pm, a.t, v.x);
+            ph = __builtin_fma(ph, b.t, v.y);
+        }
+        return make_double2(pm, ph);
+    }
+    return make_double2(psi_eval(psi, 0, a), psi_eval(psi, 1, b));
 }
 
 // Cooperative copy of the tables into LDS (call once per workgroup, then __syncthreads()).
@@ -216,19 +230,6 @@ __device__ __forceinline__ double flog_pos(const double* logt, double x) {
     q = __builtin_fma(r, q, 1.0 / 3.0);
     q = __builtin_fma(r, q, -1.0 / 2.0);
     return __builtin_fma((double)e, 0.6931471805599453094, __builtin_fma(r * r, q, r) + ck.y);
-}
-
-__device__ __forceinline__ PsiArg psi_arg_pos(const double* logt, double zeta) {
-    PsiArg a;
-    double w = flog_pos(logt, __builtin_fma(PSI_A, fabs(zeta), 1.0));
-    w = fmin(w, PSI_WMAX);
-    const double s = w * (PSI_SEG / PSI_WMAX);
-    int k = (int)s;
-    k = min(k, PSI_SEG - 1);
-    a.k = k;
-    a.t = __builtin_fma(2.0, s - (double)k, -1.0);
-    a.side = zeta < 0.0 ? 0 : 1;
-    return a;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -386,21 +387,21 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
             // 1/L★ = κ b★ / u★²  (0 when b★ = 0); b★ < 0 ⇒ ζ < 0 ⇒ unstable
             double inv_L = (L.kappa * bstar) * (inv_us * inv_us);
             if constexpr (SPEC == SOLVER_GENERIC) inv_L = (bstar == 0.0) ? 0.0 : inv_L;
-            const PsiArg ah = psi_arg_pos(logt, L.h_ref * inv_L);
+            const PsiArg ah = psi_arg(L.h_ref * inv_L);
             const double2 psi_h2 = psi_eval_pair(psi, ah);
             double Du = L.log_h - log_lu - psi_h2.x;
             const double psi_hh = psi_h2.y;
             double Dq = L.log_h - log_lq - psi_hh;
             double Dt = L.log_h - log_lt - psi_hh;
             if constexpr (!COARE) {
-                Du += psi_eval(psi, 0, psi_arg_pos(logt, lu * inv_L));
-                const double psi_lq = psi_eval(psi, 1, psi_arg_pos(logt, fexp(log_lq) * inv_L));
+                Du += psi_eval(psi, 0, psi_arg(lu * inv_L));
+                const double psi_lq = psi_eval(psi, 1, psi_arg(fexp(log_lq) * inv_L));
                 Dq += psi_lq;
                 if constexpr (SPEC == SOLVER_OCEAN)
                     Dt = Dq;
                 else
                     Dt += (L.same_scalar && SPEC != SOLVER_ICE) ? psi_lq
-                                                                : psi_eval(psi, 1, psi_arg_pos(logt, fexp(log_lt) * inv_L));
+                                                                : psi_eval(psi, 1, psi_arg(fexp(log_lt) * inv_L));
             }
             Du = fmax(Du, L.profile_floor);
             Dq = fmax(Dq, L.profile_floor);
@@ -425,7 +426,6 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
 // (omip_simulation.jl:86-89): the NCAR bulk algorithm of Large & Yeager (2004, 2009) on this
 // package's Δθ, Δq and buoyancy scale.  Fixed trip count ⇒ no divergence, no ballot.
 __device__ __forceinline__ Scales ly_iterate(const LoopParams& L, const CellConsts& c, const double* tab) {
-    const double* logt = tab + 4 * PSI_TABLE;
     auto cdn10 = [&](double u) {
         const double u2 = u * u;
         const double poly = (L.ly_cd0 * frcp1(u) + L.ly_cd1 + L.ly_cd2 * u + L.ly_cd3 * (u2 * u2 * u2)) * 1e-3;
@@ -440,7 +440,7 @@ __device__ __forceinline__ Scales ly_iterate(const LoopParams& L, const CellCons
         const double b = c.gTv * __builtin_fma(ts, c.b_theta, c.b_q * qq);
         double z = L.kappa * b * L.h_ref * frcp1(us * us);                                // 8a
         z = __builtin_copysign(fmin(fabs(z), L.ly_zeta_bound), z);
-        const double2 ps = psi_eval_pair(tab, psi_arg_pos(logt, z));
+        const double2 ps = psi_eval_pair(tab, psi_arg(z));
         const double xm = (L.ly_lz - ps.x) * L.inv_kappa;
         const double u10 = U * frcp1(__builtin_fma(rt, xm, 1.0));                          // 9
         cdn = cdn10(u10);
@@ -538,14 +538,14 @@ __device__ __forceinline__ Scales ice_iterate(const DevParams& P, const LoopPara
                                                               lu, us, frcp(air_viscosity(P.rt, Ts)));
 
             const double inv_L = (bstar == 0.0) ? 0.0 : (L.kappa * bstar) * (inv_us * inv_us);
-            const double2 psi_h2 = psi_eval_pair(tab, psi_arg_pos(logt, L.h_ref * inv_L));
+            const double2 psi_h2 = psi_eval_pair(tab, psi_arg(L.h_ref * inv_L));
             double Du = L.log_h - log_lu - psi_h2.x;
             double Dq = L.log_h - log_lq - psi_h2.y;
             double Dt = L.log_h - log_lt - psi_h2.y;
             if constexpr (!COARE) {
-                Du += psi_eval(tab, 0, psi_arg_pos(logt, lu * inv_L));
-                Dq += psi_eval(tab, 1, psi_arg_pos(logt, fexp(log_lq) * inv_L));
-                Dt += psi_eval(tab, 1, psi_arg_pos(logt, fexp(log_lt) * inv_L));
+                Du += psi_eval(tab, 0, psi_arg(lu * inv_L));
+                Dq += psi_eval(tab, 1, psi_arg(fexp(log_lq) * inv_L));
+                Dt += psi_eval(tab, 1, psi_arg(fexp(log_lt) * inv_L));
             }
             Du = fmax(Du, L.profile_floor);
             Dq = fmax(Dq, L.profile_floor);

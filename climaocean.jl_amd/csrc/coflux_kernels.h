@@ -14,9 +14,13 @@ struct LaunchCfg {
     int solver;              // CF_SOLVER_*
     int interp_cap;          // float2 entries per variable of a wave's LDS-staged JRA55 tile
     int max_blocks;          // reserved (persistent-grid experiments)
+    int ao_chunk;            // wet cells per solver workgroup: 256 / 512 / 768 (0 = automatic)
+    int cu_count;            // compute units of the device (sizes the automatic chunk)
     const double* d_tables;  // device copy of the solver tables (coflux_tables.cpp)
     const DevParams* d_params;  // device copy of DevParams (the solver stages it in LDS)
     uint8_t* d_hint;            // per-cell trip count of the previous call (scheduling hint) or NULL
+    const int* d_chunk_begins;  // cost-balanced chunk table of the solver (coflux_solver.hip), n_chunks + 1 entries
+    int n_chunks;
 };
 
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
@@ -33,6 +37,11 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
                             const GridDesc& G, const cf_sea_ice_state* ice, const cf_ocean_surface* o,
                             const cf_exchange_fields* e, const cf_interface_fluxes* f, const double* d_tables,
                             const DevParams* d_params);
+hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
+                             int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
+                             int* nchunks_out);
+int chunk_table_capacity(int ncells);
+int chunk_sums_capacity(int ncells);
 constexpr int SALINITY_PARTIAL_BLOCKS = 512;
 hipError_t launch_salinity_partial_sums(hipStream_t st, const DevParams& P, const GridDesc& G, const double* flux,
                                         const double* additional, const double* area, const void* mask, double* partial,

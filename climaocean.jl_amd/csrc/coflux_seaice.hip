@@ -15,6 +15,7 @@ constexpr int AI_BLOCK = 256;
 constexpr int AI_CHUNK = 512;
 constexpr int AI_PARAMS_OFFSET = TABLE_BYTES + AI_CHUNK * 4 + 16;
 constexpr int AI_LDS_BYTES = AI_PARAMS_OFFSET + (int)sizeof(DevParams);
+static_assert(AI_LDS_BYTES <= 53760, "three workgroups must fit the CU's 160 KB of LDS");
 
 struct IceStateIn {
     const double* thickness;

@@ -16,21 +16,155 @@ namespace coflux {
 constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 
 constexpr int AO_BLOCK = 256;
-constexpr int AO_CHUNK = 512;  // cells classified + compacted per pass of a workgroup
-constexpr int AO_BINS = 32;     // trip-count bins of the per-chunk counting sort
+constexpr int AO_CHUNK = 768;  // capacity of a workgroup's wet-cell list = the most wet cells a chunk can hold
+constexpr int AO_BINS = 32;    // trip-count bins of the per-chunk counting sort
 constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + 16 + 2 * AO_BINS * 4;
 constexpr int AO_LDS_BYTES = AO_PARAMS_OFFSET + (int)sizeof(DevParams);
+static_assert(AO_LDS_BYTES <= 53760, "three solver workgroups must fit the CU's 160 KB of LDS");
 
-// ---- production solver: LDS tables, persistent workgroups ------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Chunk table.  A workgroup's four waves pull 64-cell batches of wet cells, so a chunk is only used
+// well if it holds a multiple of 256 wet cells: 512 surface cells with ≈ 370 wet ones give six batches for
+// four waves — two waves (and, with the same wave→SIMD placement in every workgroup, two SIMDs of the
+// CU) sit idle for the second half.  The wet mask is static, so the surface is cut ONCE per mask into
+// chunks of equal cost with wet = AO_WET_COST, land = 1: an open-ocean chunk holds exactly `wet_per_chunk`
+// wet cells (256, 512 or 768: whichever fills the device's 3·CU workgroup slots in whole rounds), a coastal
+// chunk slightly fewer, a land chunk at most 16× as many cells (it only writes zeros).  The table only
+// steers scheduling: the solver re-classifies every cell of its range on every call and falls back to
+// smaller pieces if a range holds more wet cells than the list (a mask changed in place), so a stale
+// table can cost time, never correctness.
+// ---------------------------------------------------------------------------------------------
+constexpr int AO_WET_COST = 16;
+constexpr int CT_CELLS = 1024;  // cells per block of the table builder (4 per thread)
+
+__device__ __forceinline__ int cell_cost(const DevParams& P, const GridDesc& G, const void* mask, int idx, int ncells) {
+    if (idx >= ncells) return 0;
+    const int wx = G.nx + 2 * G.ring;
+    const int jj = idx / wx;
+    return cell_is_wet(P, mask, cell_index(G, idx - jj * wx - G.ring, jj - G.ring)) ? AO_WET_COST : 1;
+}
+
+__global__ __launch_bounds__(256) void chunk_block_costs_kernel(const DevParams* __restrict__ g_params, GridDesc G,
+                                                                const void* mask, int ncells, int* __restrict__ sums) {
+    __shared__ int wave_sum[4];
+    const DevParams& P = *g_params;
+    const int base = blockIdx.x * CT_CELLS + threadIdx.x * 4;
+    int c = 0;
+    for (int n = 0; n < 4; ++n) c += cell_cost(P, G, mask, base + n, ncells);
+    for (int d = 32; d; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+// exclusive scan of the block sums by one wave (a few hundred to a few thousand entries)
+__global__ __launch_bounds__(64) void chunk_scan_kernel(int nblocks, int* __restrict__ sums) {
+    int carry = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 64) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < nblocks ? sums[b] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        if (b < nblocks) sums[b] = carry + incl - v;
+        carry += __shfl(incl, 63);
+    }
+    if (threadIdx.x == 0) sums[nblocks] = carry;
+}
+
+// chunk id of a cell = floor(exclusive cost prefix / chunk cost); a cell whose id exceeds its predecessor's
+// begins a chunk.  meta[0] = number of chunks.
+__global__ __launch_bounds__(256) void chunk_begins_kernel(const DevParams* __restrict__ g_params, GridDesc G,
+                                                           const void* mask, int ncells, const int* __restrict__ sums,
+                                                           int chunk_cost, int* __restrict__ begins, int* __restrict__ meta) {
+    __shared__ int wave_sum[4];
+    const DevParams& P = *g_params;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = blockIdx.x * CT_CELLS + threadIdx.x * 4;
+    int c[4], mine = 0;
+    for (int n = 0; n < 4; ++n) {
+        c[n] = cell_cost(P, G, mask, base + n, ncells);
+        mine += c[n];
+    }
+    int incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int prefix = sums[blockIdx.x] + incl - mine;
+    for (int w = 0; w < wave; ++w) prefix += wave_sum[w];
+    int prev_cost = base > 0 ? cell_cost(P, G, mask, base - 1, ncells) : 0;
+    for (int n = 0; n < 4; ++n) {
+        const int idx = base + n;
+        if (idx < ncells) {
+            const int id = prefix / chunk_cost;
+            if (idx == 0)
+                begins[0] = 0;
+            else if (id != (prefix - prev_cost) / chunk_cost)
+                begins[id] = idx;
+            if (idx == ncells - 1) {
+                begins[id + 1] = ncells;
+                meta[0] = id + 1;
+            }
+        }
+        prefix += c[n];
+        prev_cost = c[n];
+    }
+}
+
+hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
+                             int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
+                             int* nchunks_out) {
+    const int ncells = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
+    const int nblocks = (ncells + CT_CELLS - 1) / CT_CELLS;
+    hipLaunchKernelGGL(chunk_block_costs_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(64), 0, st, nblocks, d_sums);
+    int total = 0;
+    hipError_t e = hipMemcpyAsync(&total, d_sums + nblocks, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (wet_per_chunk <= 0) {
+        // whole dispatch rounds over the 3·CU resident workgroups; larger chunks on ties (fewer table stages)
+        const int slots = 3 * (cu_count > 0 ? cu_count : 256);
+        double best = -1.0;
+        for (int w = 768; w >= 256; w -= 256) {
+            const long n = ((long)total + (long)w * AO_WET_COST - 1) / ((long)w * AO_WET_COST);
+            const long rounds = (n + slots - 1) / slots;
+            const double eff = (double)n / (double)(rounds * slots);
+            if (eff > best + 0.02) {
+                best = eff;
+                wet_per_chunk = w;
+            }
+        }
+    }
+    hipLaunchKernelGGL(chunk_begins_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums,
+                       wet_per_chunk * AO_WET_COST, d_begins, d_meta);
+    int n = 0;
+    if ((e = hipMemcpyAsync(&n, d_meta, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    *wet_per_chunk_out = wet_per_chunk;
+    *nchunks_out = n;
+    return hipGetLastError();
+}
+
+int chunk_table_capacity(int ncells) { return ncells / 256 + 8; }
+int chunk_sums_capacity(int ncells) { return (ncells + CT_CELLS - 1) / CT_CELLS + 1; }
+
+// ---- production solver: LDS tables, one workgroup per chunk of the table above -----------------
 template <bool COARE, int SPEC>
 __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, GridDesc G, OceanIn O, Exchange E,
                                                                 FluxOut F, const double* __restrict__ g_tab,
                                                                 const DevParams* __restrict__ g_params,
-                                                                uint8_t* __restrict__ hint) {
-    // Land cells (≈30 % of a global grid) must not occupy lanes for 10–20 iterations: every chunk of
-    // AO_CHUNK cells is first compacted to the list of its wet cells (land gets its zeros there and
-    // then), and waves then pull 64 list entries at a time from an LDS cursor, so every lane that
-    // enters the solver holds an ocean cell.
+                                                                uint8_t* __restrict__ hint,
+                                                                const int* __restrict__ chunk_begins) {
+    // Land cells (≈30 % of a global grid) must not occupy lanes for 10–20 iterations: the chunk is first
+    // compacted to the list of its wet cells (land gets its zeros there and then), counting-sorted by the
+    // trip-count hint, and waves then pull 64 list entries at a time from an LDS cursor, so every lane that
+    // enters the solver holds an ocean cell and the lanes of a batch finish together.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tab = reinterpret_cast<double*>(smem);
     int* list = reinterpret_cast<int*>(smem + TABLE_BYTES);
@@ -46,38 +180,26 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
     const double* logt = tab + 4 * PSI_TABLE;
 
     const int wx = G.nx + 2 * G.ring;
-    const int ncells = wx * (G.ny + 2 * G.ring);
-    const int nchunks = (ncells + AO_CHUNK - 1) / AO_CHUNK;
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int range_end = chunk_begins[blockIdx.x + 1];
+    int begin = chunk_begins[blockIdx.x], end = range_end;
+    for (;;) {
         if (tid < 2) counters[tid] = 0;
         if (tid < AO_BINS) hist[tid] = 0;
         __syncthreads();
-        // ---- phase 1: classify, zero land, counting-sort the wet cells by their trip-count hint ----
+        // ---- phase 1: classify, zero land, histogram of the trip-count hints -----------------------
         // (the hint is the cell's iteration count in the previous call — fields evolve slowly from one
-        // coupled step to the next — so lanes of a batch finish together; it only orders the list and
-        // cannot change any result)
-        const int begin = chunk * AO_CHUNK, end = min(begin + AO_CHUNK, ncells);
-        constexpr int PER = AO_CHUNK / AO_BLOCK;
-        int my_idx[PER], my_bin[PER], my_rank[PER];
-#pragma unroll
-        for (int p = 0; p < PER; ++p) {
-            const int idx = begin + p * AO_BLOCK + tid;
-            my_idx[p] = idx;
-            my_bin[p] = -1;
-            my_rank[p] = 0;
-            if (idx < end) {
-                const int jj = idx / wx;
-                const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
-                if (cell_is_wet(P, O.mask, k)) {
-                    const int bin = hint ? AO_BINS - 1 - min((int)hint[k], AO_BINS - 1) : 0;  // longest first (LPT)
-                    my_bin[p] = bin;
-                    my_rank[p] = atomicAdd(&hist[bin], 1);
-                } else {  // zero_interface_state: all fluxes 0, T = 0 K
-                    CellFluxes Z{};
-                    Z.Ts_ocean = -P.T_offset;
-                    Z.iterations = L.fixed ? L.maxiter : 0;
-                    store_fluxes(F, k, Z);
-                }
+        // coupled step to the next; it only orders the list and cannot change any result)
+        for (int idx = begin + tid; idx < end; idx += AO_BLOCK) {
+            const int jj = idx / wx;
+            const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+            if (cell_is_wet(P, O.mask, k)) {
+                const int bin = hint ? AO_BINS - 1 - min((int)hint[k], AO_BINS - 1) : 0;  // longest first (LPT)
+                atomicAdd(&hist[bin], 1);
+            } else {  // zero_interface_state: all fluxes 0, T = 0 K
+                CellFluxes Z{};
+                Z.Ts_ocean = -P.T_offset;
+                Z.iterations = L.fixed ? L.maxiter : 0;
+                store_fluxes(F, k, Z);
             }
         }
         __syncthreads();
@@ -93,12 +215,25 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
             if (lane == 63) counters[0] = incl;
         }
         __syncthreads();
-#pragma unroll
-        for (int p = 0; p < PER; ++p)
-            if (my_bin[p] >= 0) list[bin_start[my_bin[p]] + my_rank[p]] = my_idx[p];
-        __syncthreads();
         const int nwet = counters[0];
-        // ---- phase 2: waves pull 64 wet cells at a time ------------------------------------------
+        if (nwet > AO_CHUNK) {  // only with a stale chunk table: retry on a piece that cannot overflow the list
+            end = begin + AO_CHUNK;
+            __syncthreads();
+            continue;
+        }
+        // ---- phase 2: scatter the wet cells into their bins ----------------------------------------
+        for (int idx = begin + tid; idx < end; idx += AO_BLOCK) {
+            const int jj = idx / wx;
+            const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+            if (cell_is_wet(P, O.mask, k)) {
+                const int bin = hint ? AO_BINS - 1 - min((int)hint[k], AO_BINS - 1) : 0;
+                list[atomicAdd(&bin_start[bin], 1)] = idx;
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: waves pull 64 wet cells at a time --------------------------------------------
+        // (requesting the next batch's inputs before iterating the current one was tried: +20 VGPRs cost the
+        // third wave per SIMD or spills, 107 → 122–142 µs)
         for (;;) {
             int start = 0;
             if (lane == 0) start = atomicAdd(&counters[1], 64);
@@ -124,7 +259,10 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
                 if (hint) hint[k] = (uint8_t)min(s.it, 255);
             }
         }
-        __syncthreads();  // list and counters are reused by the next chunk
+        if (end >= range_end) break;
+        begin = end;  // stale-table path: the rest of the range
+        end = range_end;
+        __syncthreads();  // list and counters are reused
     }
 }
 
@@ -147,8 +285,8 @@ __global__ void debug_eval_kernel(int fn, int n, const double* __restrict__ x, d
             case 2: r = fcbrt(v); break;
             case 3: r = fsqrt(v); break;
             case 4: r = frcp(v); break;
-            case 5: r = psi_eval(tab, 0, psi_arg(logt, v)); break;
-            case 6: r = psi_eval(tab, 1, psi_arg(logt, v)); break;
+            case 5: r = psi_eval(tab, 0, psi_arg(v)); break;
+            case 6: r = psi_eval(tab, 1, psi_arg(v)); break;
             case 7: r = __builtin_amdgcn_rcp(v); break;  // raw v_rcp_f64
             case 8: r = __builtin_amdgcn_rsq(v); break;  // raw v_rsq_f64
             case 9: {
@@ -168,19 +306,19 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
     switch (C.specialization) {
         case SOLVER_OCEAN:
             hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_OCEAN>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O,
-                               E, F, L.d_tables, L.d_params, L.d_hint);
+                               E, F, L.d_tables, L.d_params, L.d_hint, L.d_chunk_begins);
             break;
         case SOLVER_ICE:
             hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_ICE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O, E,
-                               F, L.d_tables, L.d_params, L.d_hint);
+                               F, L.d_tables, L.d_params, L.d_hint, L.d_chunk_begins);
             break;
         case SOLVER_LY:
             hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_LY>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O, E,
-                               F, L.d_tables, L.d_params, L.d_hint);
+                               F, L.d_tables, L.d_params, L.d_hint, L.d_chunk_begins);
             break;
         default:
             hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_GENERIC>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G,
-                               O, E, F, L.d_tables, L.d_params, L.d_hint);
+                               O, E, F, L.d_tables, L.d_params, L.d_hint, L.d_chunk_begins);
     }
 }
 
@@ -191,10 +329,9 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     OceanIn O = make_ocean(o);
     Exchange E = make_exchange(e);
     FluxOut F = make_fluxes(f);
-    const int ncells = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
-    // one workgroup per chunk: the hardware dispatcher is the dynamic load balancer (chunks differ in
-    // their wet fraction and iteration counts); the 35 KB table/parameter stage per workgroup comes from L2.
-    dim3 grid(min((ncells + AO_CHUNK - 1) / AO_CHUNK, 1 << 20));
+    // one workgroup per chunk of the cost-balanced table: the hardware dispatcher is the dynamic load balancer
+    if (!L.d_chunk_begins || L.n_chunks <= 0) return hipErrorInvalidValue;
+    dim3 grid(L.n_chunks);
     if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
         launch_ao_spec<true>(st, grid, L, C, G, O, E, F);
     else

@@ -3,11 +3,13 @@
 // The Monin–Obukhov iteration spends its time in ψ_m(ζ), ψ_h(ζ) and log().  On CDNA4 an FP64
 // libm call costs 40–120 instructions (double-double arithmetic), and the stability functions
 // need 3 log + 2 atan + cbrt + 2 sqrt each.  Instead, every ψ is tabulated once per context as
-// piecewise degree-7 polynomials in  w = log(1 + 16|ζ|)  (128 segments on w ∈ [0, 24], i.e.
-// |ζ| ≤ 1.6e9; one table per sign of ζ), which reproduces the analytic functions to ≤ 2e-13
-// relative to max(|ψ|, 1) — four orders below the 1e-9 parity tolerance — at the price of one
-// log and 8 LDS reads + 7 FMAs.  Both signs share one instruction stream, so waves that mix
-// stable and unstable cells no longer execute both branches.
+// piecewise degree-9 polynomials in  x = 1 + 16|ζ|  (every binade of x ∈ [1, 2^36) cut into 4 equal
+// pieces ⇒ 144 segments, |ζ| ≤ 4.3e9; one table per sign of ζ), which reproduces the analytic functions
+// to ≤ 3e-14 relative to max(|ψ|, 1) — five orders below the 1e-9 parity tolerance.  The segment index is
+// the exponent and the two top mantissa bits of x and the polynomial variable is u = x − (segment start)
+// (an exact subtraction), so an evaluation costs ≈ 10 integer/FP64 instructions + 10 LDS reads + 9 FMAs and
+// no logarithm.  Both signs share one instruction stream, so waves that mix stable and unstable cells no
+// longer execute both branches.
 //
 // log() itself uses a 128-entry (1/c, log c) table on the mantissa.
 #include <cmath>
@@ -89,7 +91,7 @@ long double psi_h_exact(int kind, bool unstable, long double az) {
 
 // Degree-(PSI_DEG) Chebyshev interpolant of f on [-1, 1], returned as monomial coefficients.
 template <class F>
-void cheb_fit_monomial(F f, double* out /* PSI_DEG+1 */) {
+void cheb_fit_monomial_ld(F f, long double* out /* PSI_DEG+1 */) {
     constexpr int N = PSI_DEG + 1;
     long double fx[N], c[N];
     for (int k = 0; k < N; ++k) fx[k] = f(cosl(PI_L * (k + 0.5L) / N));
@@ -111,7 +113,28 @@ void cheb_fit_monomial(F f, double* out /* PSI_DEG+1 */) {
             Tm1[i] = T[i];
         }
     }
-    for (int i = 0; i < N; ++i) out[i] = (double)m[i];
+    for (int i = 0; i < N; ++i) out[i] = m[i];
+}
+
+// The same interpolant re-expanded in u ∈ [0, 2/alpha):  t = alpha·u − 1.
+template <class F>
+void cheb_fit_shifted(F f, long double alpha, double* out /* PSI_DEG+1 */) {
+    constexpr int N = PSI_DEG + 1;
+    long double m[N];
+    cheb_fit_monomial_ld(f, m);
+    // Σ m_i (αu − 1)^i = Σ_j u^j α^j Σ_{i≥j} m_i C(i,j) (−1)^{i−j}
+    long double binom[N][N] = {};
+    for (int i = 0; i < N; ++i) {
+        binom[i][0] = 1;
+        for (int j = 1; j <= i; ++j) binom[i][j] = binom[i - 1][j - 1] + (j <= i - 1 ? binom[i - 1][j] : 0);
+    }
+    long double apow = 1;
+    for (int j = 0; j < N; ++j) {
+        long double s = 0;
+        for (int i = j; i < N; ++i) s += m[i] * binom[i][j] * (((i - j) & 1) ? -1.0L : 1.0L);
+        out[j] = (double)(s * apow);
+        apow *= alpha;
+    }
 }
 
 }  // namespace
@@ -122,17 +145,17 @@ void cheb_fit_monomial(F f, double* out /* PSI_DEG+1 */) {
 // then the log table  logt[2*k] = 1/c_k, logt[2*k+1] = log c_k.
 std::vector<double> build_solver_tables(int stability_kind) {
     std::vector<double> t(TABLE_DOUBLES, 0.0);
-    const long double dw = (long double)PSI_WMAX / PSI_SEG;
     for (int tau = 0; tau < 4; ++tau) {
         const bool scalar = tau >= 2, unstable = (tau % 2) == 0;
         for (int k = 0; k < PSI_SEG; ++k) {
             double coef[PSI_DEG + 1];
+            const long double width = ldexpl(1.0L, k / PSI_SUB) / PSI_SUB;                  // Δ of the segment
+            const long double x0 = ldexpl(1.0L, k / PSI_SUB) + (k % PSI_SUB) * width;       // its start
             auto f = [&](long double tt) {
-                long double w = dw * (k + 0.5L * (tt + 1.0L));
-                long double az = expm1l(w) / (long double)PSI_A;
+                long double az = (x0 - 1.0L + 0.5L * (tt + 1.0L) * width) / (long double)PSI_A;
                 return scalar ? psi_h_exact(stability_kind, unstable, az) : psi_m_exact(stability_kind, unstable, az);
             };
-            cheb_fit_monomial(f, coef);
+            cheb_fit_shifted(f, 2.0L / width, coef);
             const int side = unstable ? 0 : 1, fn = scalar ? 1 : 0;
             for (int c = 0; c <= PSI_DEG; ++c)
                 t[(((size_t)side * (PSI_DEG + 1) + c) * PSI_SEG + k) * 2 + fn] = coef[c];

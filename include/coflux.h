@@ -325,6 +325,7 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 #define CF_OPT_MAX_BLOCKS 2       /* reserved for persistent-grid experiments (multiple of 8)        */
 #define CF_OPT_TRIP_HINTS 3       /* 1 (default): order each chunk's cells by their iteration count in the
                                      previous call so that the lanes of a wave finish together; scheduling only */
+#define CF_OPT_AO_CHUNK 4         /* wet cells per workgroup of the flux solver: 256, 512, 768 or 0 = automatic */
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path, LDS-tabulated ψ/log, ≤1e-12 of libm */
 #define CF_SOLVER_LIBM 1    /* same iteration on ocml's libm (slow; cross-check)                     */
 int cf_set_option(cf_ctx* ctx, int option, int value);

@@ -18,6 +18,7 @@ for name, fl in (("default", ic.SimilarityTheoryFluxes()), ("corrected", ic.corr
     ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
     res = {}
     if os.environ.get("HINTS"): ctx.set_option(abi.OPT_TRIP_HINTS, int(os.environ["HINTS"]))
+    if os.environ.get("CHUNK"): ctx.set_option(abi.OPT_AO_CHUNK, int(os.environ["CHUNK"]))
     if os.environ.get("CAP"): ctx.set_option(abi.OPT_INTERP_TILE_CAP, int(os.environ["CAP"]))
     for mb in [int(a) for a in sys.argv[1:]] or [1024]:
         ctx.set_option(abi.OPT_MAX_BLOCKS, mb)

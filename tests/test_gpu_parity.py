@@ -183,7 +183,8 @@ def test_launch_geometry_does_not_change_results():
     case = util.build_case(200, 37, 4, 4)
     ref = run_gpu(case, params, fused=True)
     for options in (((abi.OPT_MAX_BLOCKS, 8),), ((abi.OPT_MAX_BLOCKS, 24), (abi.OPT_INTERP_TILE_CAP, 16)),
-                    ((abi.OPT_INTERP_TILE_CAP, 512),)):
+                    ((abi.OPT_INTERP_TILE_CAP, 512),), ((abi.OPT_AO_CHUNK, 256),), ((abi.OPT_AO_CHUNK, 512),),
+                    ((abi.OPT_AO_CHUNK, 768),)):
         for fused in (False, True):
             got = run_gpu(case, params, fused=fused, options=options)
             for grp in ("atmos", "fluxes", "net"):
@@ -296,6 +297,49 @@ def test_trip_count_hints_only_reorder_work():
         for k in runs[0]:
             np.testing.assert_array_equal(r[k], runs[0][k], err_msg=k)
     assert runs[0]["iterations"].max() > 10
+    ctx.close()
+
+
+def test_stale_chunk_table_costs_time_not_correctness():
+    """The solver's chunk table is built from the wet mask on the first call.  Rewriting the mask IN PLACE (same
+    pointer) afterwards — here: almost-all-land becomes all-ocean, so ranges sized for 16× as many land cells now
+    overflow the workgroup's wet-cell list — must still give the oracle's answer (the kernel re-classifies every
+    cell and splits its range), and so must a new mask pointer (table rebuilt)."""
+    params = ic.flux_params()
+    case = util.build_case(300, 64, 4, 4)
+    ctx = FluxContext(300, 64, 4, 4, params)
+    dev = ctx.to_device
+    src = {k: dev(v) for k, v in case["src"].items()}
+    w = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in case["weights"].items()}
+    atmos = ctx.field_set(EXCHANGE_NAMES)
+    ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
+    ocean = {k: dev(case["ocean"][k]) for k in ("T", "S", "u", "v", "mask")}
+    g = orc.make_grid(300, 64, 4, 4, 1)
+    at = orc.interpolate_atmosphere_state(g, case["src"], case["weights"], 0, 1, 0.37)
+
+    def check(mask_np):
+        fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL)
+        fluxes["iterations"] = ctx.zeros(torch.int32)
+        ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
+        torch.cuda.synchronize()
+        oc = dict(case["ocean"], mask=mask_np)
+        ref = orc.compute_atmosphere_ocean_fluxes(g, params, oc, at, nthreads=0)
+        for k in FLUX_NAMES + FLUX_OPTIONAL:
+            e = util.rel_err(util.window(fluxes[k].cpu().numpy(), 4, 4, 300, 64, 1), util.window(ref[k], 4, 4, 300, 64, 1),
+                             util.FIELD_SCALE[k])
+            assert e <= TOL_SOLVER, (k, e)
+        np.testing.assert_array_equal(util.window(fluxes["iterations"].cpu().numpy(), 4, 4, 300, 64, 1),
+                                      util.window(ref["iterations"], 4, 4, 300, 64, 1))
+
+    mostly_land = np.zeros_like(case["ocean"]["mask"])
+    mostly_land[::7, ::5] = 1
+    ocean["mask"].copy_(torch.from_numpy(mostly_land))
+    check(mostly_land)                                   # table built for a land-dominated surface
+    all_ocean = np.ones_like(mostly_land)
+    ocean["mask"].copy_(torch.from_numpy(all_ocean))     # same pointer, new contents: the table is stale
+    check(all_ocean)
+    ocean["mask"] = dev(case["ocean"]["mask"])           # new pointer: the table is rebuilt
+    check(case["ocean"]["mask"])
     ctx.close()
 
 
