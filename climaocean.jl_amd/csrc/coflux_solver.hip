@@ -23,18 +23,35 @@ constexpr int AO_LDS_BYTES = AO_PARAMS_OFFSET + (int)sizeof(DevParams);
 static_assert(AO_LDS_BYTES <= 53760, "three solver workgroups must fit the CU's 160 KB of LDS");
 
 // ---------------------------------------------------------------------------------------------
-// Chunk table.  A workgroup's four waves pull 64-cell batches of wet cells, so a chunk is only used
-// well if it holds a multiple of 256 wet cells: 512 surface cells with ≈ 370 wet ones give six batches for
-// four waves — two waves (and, with the same wave→SIMD placement in every workgroup, two SIMDs of the
-// CU) sit idle for the second half.  The wet mask is static, so the surface is cut ONCE per mask into
-// chunks of equal cost with wet = AO_WET_COST, land = 1: an open-ocean chunk holds exactly `wet_per_chunk`
-// wet cells (256, 512 or 768: whichever fills the device's 3·CU workgroup slots in whole rounds), a coastal
-// chunk slightly fewer, a land chunk at most 16× as many cells (it only writes zeros).  The table only
-// steers scheduling: the solver re-classifies every cell of its range on every call and falls back to
-// smaller pieces if a range holds more wet cells than the list (a mask changed in place), so a stale
-// table can cost time, never correctness.
+// Chunk table.  Two quantisation effects cost ≈ 25 % each when every workgroup simply takes 512 surface
+// cells: (i) a workgroup's four waves pull 64-cell batches of wet cells, so a chunk is only used well if it
+// holds a multiple of 256 wet cells (≈ 370 wet cells = six batches leave two waves — and, with the same
+// wave→SIMD placement in every workgroup, two SIMDs of the CU — idle for the second half); (ii) the device
+// holds 3 workgroups per CU, and a dispatch "round" that is only half full runs at half throughput.
+// The wet mask is static, so the surface is cut ONCE per mask into chunks of prescribed cost with
+// wet = AO_WET_COST, land = 1.  The host picks a descending sequence of rounds — each a full set of
+// 3·CU chunks of 768, 512 or 256 wet cells, the remainder as a last partial round of the smallest size —
+// so that the long workgroups start first and whatever tail is left is short.  An open-ocean chunk holds
+// exactly its nominal wet count, a coastal one slightly fewer, a land chunk at most 64× as many cells (it
+// only writes zeros).  The table only steers scheduling: the solver re-classifies every cell of its range
+// on every call and falls back to smaller pieces if a range holds more wet cells than the list (a mask
+// changed in place), so a stale table can cost time, never correctness.
 // ---------------------------------------------------------------------------------------------
-constexpr int AO_WET_COST = 16;
+constexpr int AO_WET_COST = 64;
+constexpr int AO_MAX_ROUNDS = 8;
+struct ChunkRounds {  // round r covers cost prefixes [base[r], base[r+1]) in chunks of cost[r], ids from first[r]
+    int n;
+    int base[AO_MAX_ROUNDS + 1];
+    int cost[AO_MAX_ROUNDS];
+    int first[AO_MAX_ROUNDS];
+};
+
+__device__ __forceinline__ int chunk_id(const ChunkRounds& R, int prefix) {
+    int r = 0;
+    while (r + 1 < R.n && prefix >= R.base[r + 1]) ++r;
+    return R.first[r] + (prefix - R.base[r]) / R.cost[r];
+}
+
 constexpr int CT_CELLS = 1024;  // cells per block of the table builder (4 per thread)
 
 __device__ __forceinline__ int cell_cost(const DevParams& P, const GridDesc& G, const void* mask, int idx, int ncells) {
@@ -78,7 +95,7 @@ __global__ __launch_bounds__(64) void chunk_scan_kernel(int nblocks, int* __rest
 // begins a chunk.  meta[0] = number of chunks.
 __global__ __launch_bounds__(256) void chunk_begins_kernel(const DevParams* __restrict__ g_params, GridDesc G,
                                                            const void* mask, int ncells, const int* __restrict__ sums,
-                                                           int chunk_cost, int* __restrict__ begins, int* __restrict__ meta) {
+                                                           ChunkRounds R, int* __restrict__ begins, int* __restrict__ meta) {
     __shared__ int wave_sum[4];
     const DevParams& P = *g_params;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -101,10 +118,10 @@ __global__ __launch_bounds__(256) void chunk_begins_kernel(const DevParams* __re
     for (int n = 0; n < 4; ++n) {
         const int idx = base + n;
         if (idx < ncells) {
-            const int id = prefix / chunk_cost;
+            const int id = chunk_id(R, prefix);
             if (idx == 0)
                 begins[0] = 0;
-            else if (id != (prefix - prev_cost) / chunk_cost)
+            else if (id != chunk_id(R, prefix - prev_cost))
                 begins[id] = idx;
             if (idx == ncells - 1) {
                 begins[id + 1] = ncells;
@@ -127,22 +144,39 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
     hipError_t e = hipMemcpyAsync(&total, d_sums + nblocks, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    if (wet_per_chunk <= 0) {
-        // whole dispatch rounds over the 3·CU resident workgroups; larger chunks on ties (fewer table stages)
-        const int slots = 3 * (cu_count > 0 ? cu_count : 256);
-        double best = -1.0;
-        for (int w = 768; w >= 256; w -= 256) {
-            const long n = ((long)total + (long)w * AO_WET_COST - 1) / ((long)w * AO_WET_COST);
-            const long rounds = (n + slots - 1) / slots;
-            const double eff = (double)n / (double)(rounds * slots);
-            if (eff > best + 0.02) {
-                best = eff;
-                wet_per_chunk = w;
+    const int slots = 3 * (cu_count > 0 ? cu_count : 256);
+    ChunkRounds R{};
+    int remaining = total, next_id = 0, largest = 0;
+    R.base[0] = 0;
+    while (remaining > 0 && R.n < AO_MAX_ROUNDS) {
+        // the remainder goes into one last round of the smallest chunk size that still fits the slots;
+        // otherwise a full round of the largest chunks
+        int w = 0;
+        bool last = true;
+        if (wet_per_chunk > 0) {
+            w = wet_per_chunk;  // forced size: one "round" holds everything
+        } else {
+            for (int cand = 256; cand <= 768 && !w; cand += 256)
+                if (((long)remaining + (long)cand * AO_WET_COST - 1) / ((long)cand * AO_WET_COST) <= slots) w = cand;
+            if (!w && R.n < AO_MAX_ROUNDS - 1) {
+                w = 768;
+                last = false;
             }
         }
+        if (w == 0) w = 768;
+        const int cost = w * AO_WET_COST;
+        const int count = last ? (remaining + cost - 1) / cost : slots;
+        R.cost[R.n] = cost;
+        R.first[R.n] = next_id;
+        R.base[R.n + 1] = last ? total + AO_WET_COST : R.base[R.n] + count * cost;
+        next_id += count;
+        remaining = last ? 0 : remaining - count * cost;
+        if (w > largest) largest = w;
+        ++R.n;
     }
-    hipLaunchKernelGGL(chunk_begins_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums,
-                       wet_per_chunk * AO_WET_COST, d_begins, d_meta);
+    wet_per_chunk = largest;
+    hipLaunchKernelGGL(chunk_begins_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums, R, d_begins,
+                       d_meta);
     int n = 0;
     if ((e = hipMemcpyAsync(&n, d_meta, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -151,7 +185,7 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
     return hipGetLastError();
 }
 
-int chunk_table_capacity(int ncells) { return ncells / 256 + 8; }
+int chunk_table_capacity(int ncells) { return (int)(((long)ncells * AO_WET_COST) / (256L * AO_WET_COST)) + 16; }
 int chunk_sums_capacity(int ncells) { return (ncells + CT_CELLS - 1) / CT_CELLS + 1; }
 
 // ---- production solver: LDS tables, one workgroup per chunk of the table above -----------------
