@@ -150,6 +150,8 @@ EXPORTED_SYMBOLS = (
     "cf_default_sea_ice_params", "cf_set_sea_ice_formulation", "cf_compute_atmosphere_sea_ice_fluxes",
     "cf_time_stage", "cf_time_copy", "cf_profile_enable", "cf_profile_read",
     "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
+    "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
+    "cf_window_upload", "cf_window_find", "cf_window_source",
 )
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -218,9 +220,18 @@ def load_library(path=None):
     lib.cf_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.cf_comm_destroy.argtypes = [vp]
     lib.cf_halo_exchange_rows.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int]
+    lib.cf_window_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.cf_window_destroy.argtypes = [vp]
+    lib.cf_window_host_buffer.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.cf_window_host_buffer.restype = C.POINTER(C.c_float)
+    lib.cf_window_wait_slot.argtypes = [vp, C.c_int32]
+    lib.cf_window_commit.argtypes = [vp, C.c_int32, C.c_int64]
+    lib.cf_window_upload.argtypes = [vp, C.c_int64, C.POINTER(vp)]
+    lib.cf_window_find.argtypes = [vp, C.c_int64]
+    lib.cf_window_source.argtypes = [vp, C.c_int64, C.c_int64, C.c_double, C.POINTER(AtmosSource)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("cf_last_error", "cf_device_alloc"):
+        if name not in ("cf_last_error", "cf_device_alloc", "cf_window_host_buffer"):
             fn.restype = C.c_int
     if path is None:
         _lib = lib

@@ -121,19 +121,40 @@ def set_surface(ocean, *, T=None, S=None, u=None, v=None, mask=None):
 class JRA55PrescribedAtmosphere:
     """JRA55PrescribedAtmosphere(arch; dir, dataset, start_date, end_date, time_indices_in_memory,
     prefetch) — atmosphere.jl:20-29, README.md:74.  Holds `time_indices_in_memory` 3-hourly
-    snapshots of the 9 variables (jra55_data_staging.jl:8) as Float32 640×320 fields in HBM."""
+    snapshots of the 9 variables (jra55_data_staging.jl:8) as Float32 640×320 fields in HBM.
 
-    def __init__(self, snapshots=None, *, time_indices_in_memory=2, time_interval=3 * hours, device=0,
-                 reference_height=10.0, boundary_layer_height=600.0, cyclic=True):
+    Two backends, as in the reference: everything in memory (`snapshots` = dict var -> [n, 320, 640]), or a
+    sliding window (`provider(n) -> dict var -> [320, 640]` reads snapshot n from wherever the files are;
+    `total_snapshots` per repeat-year/multi-year record).  With `prefetch` the snapshots the clock will reach next
+    are read by a background thread straight into the window's pinned staging buffers and committed to HBM by the
+    stepping thread, so file reads and PCIe copies overlap the flux kernels (launch.sh:86-93)."""
+
+    def __init__(self, snapshots=None, *, provider=None, total_snapshots=None, time_indices_in_memory=2,
+                 prefetch=True, time_interval=3 * hours, device=0, reference_height=10.0, boundary_layer_height=600.0,
+                 cyclic=True, source_size=(synthetic.JRA55_NX, synthetic.JRA55_NY)):
+        self.time_interval = time_interval
+        self.reference_height = reference_height
+        self.boundary_layer_height = boundary_layer_height
+        self.cyclic = cyclic  # RepeatYearJRA55-style cyclic time indexing vs clamped (MultiYearJRA55 record ends)
+        self.provider, self.prefetch = provider, prefetch
+        self.window = None
+        self._pending = {}   # time index -> Future of a background read into the pinned buffers
+        self._reader = None
+        if provider is not None:
+            if total_snapshots is None:
+                raise ValueError("a snapshot provider needs total_snapshots (2920 for a repeat year of 3-hourly JRA55)")
+            if time_indices_in_memory < 2:
+                raise ValueError("time_indices_in_memory must be >= 2")
+            self.n_levels = total_snapshots
+            self.n_slots = time_indices_in_memory
+            self.source_size = source_size
+            self.data = None
+            return
         dev = torch.device("cuda", device)
         if snapshots is None:
             snapshots = synthetic.jra55_snapshots(time_indices_in_memory)
         self.data = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in snapshots.items()}
         self.n_levels = next(iter(self.data.values())).shape[0]
-        self.time_interval = time_interval
-        self.reference_height = reference_height
-        self.boundary_layer_height = boundary_layer_height
-        self.cyclic = cyclic  # RepeatYearJRA55-style cyclic time indexing vs clamped
 
     def time_indices(self, t):
         """(n₁, n₂, ñ): the bracketing snapshots and the fractional position between them."""
@@ -145,6 +166,62 @@ class JRA55PrescribedAtmosphere:
         n1 = min(max(n, 0), self.n_levels - 1)
         n2 = min(max(n + 1, 0), self.n_levels - 1)
         return n1, n2, (frac if 0 <= n < self.n_levels - 1 else 0.0)
+
+    # ---- sliding-window backend ---------------------------------------------------------------
+    def _wrap(self, n):
+        return n % self.n_levels if self.cyclic else min(max(n, 0), self.n_levels - 1)
+
+    def _read_into_staging(self, n):
+        slot = n % self.n_slots
+        self.window.wait_slot(slot)          # the previous copy out of these pinned buffers has finished
+        snap = self.provider(n)
+        for v in abi.JRA55_VARIABLES:
+            np.copyto(self.window.host_view(slot, v), snap[v], casting="same_kind")
+        return slot
+
+    def source(self, context, t):
+        """The cf_atmos_source for time t.  In-memory backend: (data, n₁, n₂, ñ).  Window backend: makes n₁, n₂
+        resident (blocking only if the prefetch has not delivered them), commits finished prefetches and queues
+        the reads for the snapshots ahead."""
+        n1, n2, frac = self.time_indices(t)
+        if self.provider is None:
+            return self.data, n1, n2, frac
+        if self.window is None:
+            from .runtime import SnapshotWindow
+            self.window = SnapshotWindow(context, self.source_size[0], self.source_size[1], self.n_slots)
+            if self.prefetch:
+                from concurrent.futures import ThreadPoolExecutor
+                self._reader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="jra55-prefetch")
+        w = self.window
+        for n in (n1, n2):
+            if w.find(n) >= 0:
+                continue
+            fut = self._pending.pop(n, None)
+            slot = fut.result() if fut is not None else self._read_into_staging(n)
+            w.commit(slot, n)
+        for n, fut in list(self._pending.items()):      # prefetches that have landed in pinned memory
+            if fut.done():
+                w.commit(fut.result(), n)
+                del self._pending[n]
+        if self._reader is not None:
+            base = int(np.floor(t / self.time_interval))
+            for ahead in range(2, self.n_slots):        # slots not holding n₁ or n₂
+                n = self._wrap(base + ahead)
+                if n in (n1, n2) or w.find(n) >= 0 or n in self._pending:
+                    continue
+                if any((m % self.n_slots) == (n % self.n_slots) for m in list(self._pending) + [n1, n2]):
+                    continue
+                self._pending[n] = self._reader.submit(self._read_into_staging, n)
+        return w.source(n1, n2, frac), n1, n2, frac
+
+    def close(self):
+        if self._reader is not None:
+            self._reader.shutdown(wait=True)
+            self._reader = None
+        self._pending.clear()
+        if self.window is not None:
+            self.window.close()
+            self.window = None
 
 
 @dataclass
@@ -227,9 +304,9 @@ def OceanOnlyModel(ocean, *, atmosphere, **kw):
 def update_state(model):
     """update_state!(coupled_model) — the accelerated path."""
     itf, atm = model.interfaces, model.atmosphere
-    n1, n2, frac = atm.time_indices(model.clock.time)
+    src, n1, n2, frac = atm.source(itf.context, model.clock.time)
     ice = model.sea_ice.fields() if model.sea_ice is not None else None
-    itf.context.update_state(atm.data, itf.weights, model.ocean.surface_state(), itf.exchange_atmosphere_state,
+    itf.context.update_state(src, itf.weights, model.ocean.surface_state(), itf.exchange_atmosphere_state,
                              itf.atmosphere_ocean_interface._fields, itf.net_fluxes._ocean_fields, ice=ice,
                              level1=n1, level2=n2, time_fraction=frac)
 

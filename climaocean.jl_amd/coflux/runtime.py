@@ -108,6 +108,8 @@ class FluxContext:
         return s
 
     def source_struct(self, src, level1, level2, time_fraction):
+        if isinstance(src, abi.AtmosSource):  # built by SnapshotWindow.source(): levels and fraction are in it
+            return src
         s = abi.AtmosSource()
         shape = None
         for k, name in enumerate(abi.JRA55_VARIABLES):
@@ -241,6 +243,54 @@ class FluxContext:
     def halo_exchange_rows(self, tensors, rows=1):
         arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         self._check(self.lib.cf_halo_exchange_rows(self._h, arr, len(tensors), rows), "cf_halo_exchange_rows")
+
+
+class SnapshotWindow:
+    """JRA55PrescribedAtmosphere(arch; time_indices_in_memory = n_slots, prefetch = true): cf_window_* —
+    `n_slots` snapshots of the nine JRA55 variables in HBM, refilled asynchronously from pinned staging
+    buffers on a copy stream (atmosphere.jl:20-29).  Snapshot t lives in slot t mod n_slots."""
+
+    def __init__(self, ctx, ns_x, ns_y, n_slots):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.ns_x, self.ns_y, self.n_slots = ns_x, ns_y, n_slots
+        h = C.c_void_p()
+        ctx._check(self.lib.cf_window_create(ctx._h, ns_x, ns_y, n_slots, C.byref(h)), "cf_window_create")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self.lib.cf_window_destroy(self._h)
+            self._h = None
+
+    def host_view(self, slot, variable):
+        """NumPy view (ns_y, ns_x) float32 of the pinned staging buffer of (slot, variable)."""
+        k = abi.JRA55_VARIABLES.index(variable) if isinstance(variable, str) else variable
+        p = self.lib.cf_window_host_buffer(self._h, slot, k)
+        if not p:
+            raise CofluxError(f"no staging buffer for slot {slot}, variable {variable}")
+        return np.ctypeslib.as_array(p, shape=(self.ns_y, self.ns_x))
+
+    def wait_slot(self, slot):
+        self.ctx._check(self.lib.cf_window_wait_slot(self._h, slot), "cf_window_wait_slot")
+
+    def commit(self, slot, time_index):
+        self.ctx._check(self.lib.cf_window_commit(self._h, slot, time_index), "cf_window_commit")
+
+    def upload(self, time_index, snapshot):
+        """snapshot: dict variable -> float32 (ns_y, ns_x) host array."""
+        keep = [np.ascontiguousarray(snapshot[v], dtype=np.float32) for v in abi.JRA55_VARIABLES]
+        for a in keep:
+            assert a.shape == (self.ns_y, self.ns_x), a.shape
+        ptrs = (C.c_void_p * len(keep))(*[a.ctypes.data for a in keep])
+        self.ctx._check(self.lib.cf_window_upload(self._h, time_index, ptrs), "cf_window_upload")
+
+    def find(self, time_index):
+        return self.lib.cf_window_find(self._h, time_index)
+
+    def source(self, n1, n2, time_fraction):
+        s = abi.AtmosSource()
+        self.ctx._check(self.lib.cf_window_source(self._h, n1, n2, float(time_fraction), C.byref(s)), "cf_window_source")
+        return s
 
 
 def comm_unique_id():

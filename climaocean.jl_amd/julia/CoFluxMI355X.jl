@@ -184,6 +184,36 @@ compute_atmosphere_sea_ice_fluxes!(b::CoFluxBackend, ice::CfSeaIceState, ocean::
                        (Ptr{Cvoid}, Ref{CfSeaIceState}, Ref{CfOceanSurface}, Ref{CfExchangeFields}, Ref{CfInterfaceFluxes}),
                        b.ctx, ice, ocean, atmos, out))
 
+# ---- JRA55 snapshot window in HBM: JRA55PrescribedAtmosphere(arch; time_indices_in_memory, prefetch) ---------
+mutable struct CoFluxWindow
+    ptr::Ptr{Cvoid}
+    backend::CoFluxBackend
+    nsx::Int; nsy::Int; nslots::Int
+end
+function CoFluxWindow(b::CoFluxBackend, nsx, nsy, nslots)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(b.ctx, ccall((:cf_window_create, libcoflux), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+                       b.ctx, nsx, nsy, nslots, out))
+    w = CoFluxWindow(out[], b, nsx, nsy, nslots)
+    finalizer(x -> ccall((:cf_window_destroy, libcoflux), Cint, (Ptr{Cvoid},), x.ptr), w)
+    return w
+end
+# pinned staging buffer of (slot, variable) as a Julia array the NetCDF reader fills in place (0-based slot/variable)
+staging(w::CoFluxWindow, slot, var) =
+    unsafe_wrap(Array, ccall((:cf_window_host_buffer, libcoflux), Ptr{Float32}, (Ptr{Cvoid}, Int32, Int32), w.ptr, slot, var),
+                (w.nsx, w.nsy))
+wait_slot!(w::CoFluxWindow, slot) =
+    check(w.backend.ctx, ccall((:cf_window_wait_slot, libcoflux), Cint, (Ptr{Cvoid}, Int32), w.ptr, slot))
+commit!(w::CoFluxWindow, slot, time_index) =
+    check(w.backend.ctx, ccall((:cf_window_commit, libcoflux), Cint, (Ptr{Cvoid}, Int32, Int64), w.ptr, slot, time_index))
+resident(w::CoFluxWindow, time_index) = ccall((:cf_window_find, libcoflux), Cint, (Ptr{Cvoid}, Int64), w.ptr, time_index) >= 0
+function source(w::CoFluxWindow, n₁, n₂, ñ)          # → CfAtmosSource for update_state!
+    src = Ref{CfAtmosSource}()
+    check(w.backend.ctx, ccall((:cf_window_source, libcoflux), Cint, (Ptr{Cvoid}, Int64, Int64, Float64, Ref{CfAtmosSource}),
+                               w.ptr, n₁, n₂, ñ, src))
+    return src[]
+end
+
 # ---- latitude-slab halo rows over RCCL (Distributed(GPU(), partition = Partition(1, R))) -------
 comm_unique_id() = (id = zeros(UInt8, 128); ccall((:cf_comm_unique_id, libcoflux), Cint, (Ptr{UInt8},), id); id)
 comm_init!(b, id::Vector{UInt8}, rank, nranks) =   # `id` is MPI.bcast from rank 0

@@ -373,6 +373,32 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
                     const cf_net_ocean_fluxes* net);
 
 /* ------------------------------------------------------------------------------------------
+ * JRA55 snapshot window in HBM: JRA55PrescribedAtmosphere(arch; time_indices_in_memory = n,
+ * prefetch = true) of atmosphere.jl:20-29 / launch.sh:86-93 — `n_slots` 3-hourly snapshots of the nine
+ * variables resident on the device, refilled from host memory while the model steps.  Snapshot `t` lives in
+ * slot t mod n_slots.  Uploads run on the window's own copy stream out of pinned staging buffers and are
+ * ordered against the context's compute stream with events in both directions: a slot is not overwritten
+ * before the interpolations already queued have read it, and an interpolation does not start before the two
+ * snapshots it brackets have landed.  Reading the files (NetCDF) stays on the host side of this boundary.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cf_window cf_window;
+int cf_window_create(cf_ctx* ctx, int32_t ns_x, int32_t ns_y, int32_t n_slots, cf_window** out);
+int cf_window_destroy(cf_window* w);
+/* Pinned staging buffer [ns_y][ns_x] of (slot, variable) for readers that fill it in place.  Call
+ * cf_window_wait_slot first: the previous upload out of this buffer may still be in flight. */
+float* cf_window_host_buffer(cf_window* w, int32_t slot, int32_t variable);
+int cf_window_wait_slot(cf_window* w, int32_t slot);
+/* The slot's nine staging buffers hold snapshot `time_index`: start its asynchronous copy into HBM. */
+int cf_window_commit(cf_window* w, int32_t slot, int64_t time_index);
+/* Convenience: copy nine host arrays (CF_JRA55_* order) into slot time_index mod n_slots and commit. */
+int cf_window_upload(cf_window* w, int64_t time_index, const float* const* host_vars);
+/* Slot that holds (or is receiving) snapshot `time_index`, or -1. */
+int cf_window_find(cf_window* w, int64_t time_index);
+/* Source descriptor for interpolating between snapshots n1 and n2 (both must be in the window; the compute
+ * stream is made to wait for their uploads).  Pass it to cf_interpolate_atmosphere_state / cf_update_state. */
+int cf_window_source(cf_window* w, int64_t n1, int64_t n2, double time_fraction, cf_atmos_source* out);
+
+/* ------------------------------------------------------------------------------------------
  * Atmosphere–sea-ice interface (config sites omip_simulation.jl:62-69 ":corrected",
  * :105-113 ":ncar", atmosphere.jl:34-44).  Same Monin–Obukhov iteration, but the interface temperature is
  * a skin temperature found inside the loop from the surface energy balance against the conductive flux
