@@ -23,6 +23,7 @@ for name, mk in (("default", lambda: ic.SimilarityTheoryFluxes()), ("corrected",
             ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
         else:
             ctx.set_flux_params(P)
+        if os.environ.get("HINTS"): ctx.set_option(abi.OPT_TRIP_HINTS, int(os.environ["HINTS"]))
         res[n] = round(min(ctx.time_stage(abi.STAGE_AO_FLUXES, 20, ocean=ocean, atmos=atmos, fluxes=fluxes) for _ in range(3)) * 1e3, 1)
     print(name, json.dumps(res))
     ctx.close()
