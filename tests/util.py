@@ -88,7 +88,7 @@ def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=1e-3, maxiter=10
     `tol_unconverged`; cells that do converge but need more than `slow` iterations (a weakly contracting
     orbit, same amplification) to the north-star `tol_slow` = 1e-6; every other cell to `tol_converged`."""
     unconv = np.asarray(ref["iterations"]) >= maxiter
-    # collapsed turbulence (u★ → 1e-11 on the −5ζ branch): ζ leaves the ψ tables' range |ζ| ≤ 1.6e9, where the
+    # collapsed turbulence (u★ → 1e-11 on the −5ζ branch): ζ leaves the ψ tables' range |ζ| ≤ 4.3e9, where the
     # device clamps ψ; u★ then differs by ≈4e-11 m/s in absolute terms, all fluxes are < 1e-9 of their scale
     collapsed = np.asarray(ref["friction_velocity"]) < 1e-8
     slowc = ((np.asarray(ref["iterations"]) > slow) | collapsed) & ~unconv
