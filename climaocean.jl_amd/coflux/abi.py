@@ -117,6 +117,10 @@ class SeaIceParams(C.Structure):
                 ("albedo", C.c_double), ("emissivity", C.c_double), ("temperature_offset", C.c_double)]
 
 
+class NetSeaIceFluxes(C.Structure):
+    _fields_ = [("top_heat", C.c_void_p), ("bottom_heat", C.c_void_p)]
+
+
 class SeaIceState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("concentration", "thickness", "top_temperature", "u", "v", "albedo")]
 
@@ -148,6 +152,7 @@ EXPORTED_SYMBOLS = (
     "cf_interpolate_atmosphere_state", "cf_compute_atmosphere_ocean_fluxes",
     "cf_compute_net_ocean_fluxes", "cf_update_state", "cf_normalize_salinity_flux",
     "cf_default_sea_ice_params", "cf_set_sea_ice_formulation", "cf_compute_atmosphere_sea_ice_fluxes",
+    "cf_compute_net_sea_ice_fluxes",
     "cf_time_stage", "cf_time_copy", "cf_profile_enable", "cf_profile_read",
     "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
@@ -209,6 +214,9 @@ def load_library(path=None):
     lib.cf_set_sea_ice_formulation.argtypes = [vp, C.POINTER(FluxParams), C.POINTER(SeaIceParams)]
     lib.cf_compute_atmosphere_sea_ice_fluxes.argtypes = [
         vp, C.POINTER(SeaIceState), C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes)]
+    lib.cf_compute_net_sea_ice_fluxes.argtypes = [
+        vp, C.POINTER(SeaIceState), C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes),
+        vp, vp, C.POINTER(NetSeaIceFluxes)]
     lib.cf_time_stage.argtypes = [
         vp, C.c_int, C.c_int, C.POINTER(AtmosSource), C.POINTER(InterpWeights),
         C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes),

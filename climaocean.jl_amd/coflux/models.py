@@ -244,10 +244,28 @@ class PrescribedSeaIce:
     salt_flux: Optional[torch.Tensor] = None
     x_stress: Optional[torch.Tensor] = None
     y_stress: Optional[torch.Tensor] = None
+    # sea_ice.model.{ice_thickness, ice_thermodynamics.top_surface_temperature, velocities} (atmosphere.jl:34-39):
+    # with these the atmosphere–sea-ice interface is solved too and top_surface_temperature is updated in place
+    thickness: Optional[torch.Tensor] = None
+    top_surface_temperature: Optional[torch.Tensor] = None   # °C
+    u: Optional[torch.Tensor] = None
+    v: Optional[torch.Tensor] = None
+    albedo: Optional[torch.Tensor] = None
+    frazil_heat: Optional[torch.Tensor] = None
 
     def fields(self):
         return {k: getattr(self, k) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")
                 if getattr(self, k) is not None}
+
+    def has_surface_state(self):
+        return self.thickness is not None and self.top_surface_temperature is not None
+
+    def surface_state(self):
+        st = dict(concentration=self.concentration, thickness=self.thickness, top_temperature=self.top_surface_temperature)
+        for k in ("u", "v", "albedo"):
+            if getattr(self, k) is not None:
+                st[k] = getattr(self, k)
+        return st
 
 
 # ---------------------------------------------------------------------------------------------
@@ -258,8 +276,9 @@ class ComponentInterfaces:
     atmosphere_ocean_velocity_difference, ocean_minimum_salinity) — omip_simulation.jl:128-158."""
 
     def __init__(self, atmosphere, ocean, sea_ice=None, *, radiation=None, atmosphere_ocean_fluxes=None,
-                 atmosphere_ocean_velocity_difference=None, ocean_minimum_salinity=0.0, ocean_properties=None,
-                 store_similarity_scales=False):
+                 atmosphere_sea_ice_fluxes=None, atmosphere_ocean_velocity_difference=None,
+                 atmosphere_sea_ice_velocity_difference=None, sea_ice_properties=None, ocean_minimum_salinity=0.0,
+                 ocean_properties=None, store_similarity_scales=False):
         grid = ocean.grid
         (nx, ny, _), (hx, hy, _) = grid.size, grid.halo
         self.radiation = radiation or Radiation()
@@ -283,6 +302,23 @@ class ComponentInterfaces:
         net = dict(u=bc.u, v=bc.v, T=bc.T, S=bc.S, shortwave_surface_flux=ocean.model.shortwave_surface_flux,
                    upwelling_longwave=ctx.zeros(), downwelling_longwave=ctx.zeros(), downwelling_shortwave=ctx.zeros())
         self.net_fluxes = SimpleNamespace(ocean=SimpleNamespace(**net), _ocean_fields=net)
+        # atmosphere–sea-ice interface (omip_simulation.jl:145,154; atmosphere.jl:34-44)
+        self.atmosphere_sea_ice_interface = None
+        if sea_ice is not None and sea_ice.has_surface_state():
+            self.atmosphere_sea_ice_fluxes = atmosphere_sea_ice_fluxes or ic.SimilarityTheoryFluxes(
+                stability_functions=ic.atmosphere_sea_ice_stability_functions())
+            ice_params = ic.flux_params(self.atmosphere_sea_ice_fluxes,
+                                        velocity_difference=atmosphere_sea_ice_velocity_difference, ocean=props,
+                                        reference_height=atmosphere.reference_height,
+                                        boundary_layer_height=atmosphere.boundary_layer_height,
+                                        stefan_boltzmann_constant=self.radiation.stefan_boltzmann_constant)
+            self.sea_ice_properties = sea_ice_properties or ic.SeaIceInterfaceProperties()
+            ctx.set_sea_ice_formulation(ice_params, self.sea_ice_properties.to_params())
+            ai = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL if store_similarity_scales else ())
+            self.atmosphere_sea_ice_interface = SimpleNamespace(fluxes=SimpleNamespace(**ai), _fields=ai)
+            net_ice = ctx.field_set(("top_heat", "bottom_heat"))
+            self.net_fluxes.sea_ice = SimpleNamespace(**net_ice)
+            self.net_fluxes._sea_ice_fields = net_ice
 
 
 class OceanSeaIceModel:
@@ -309,6 +345,16 @@ def update_state(model):
     itf.context.update_state(src, itf.weights, model.ocean.surface_state(), itf.exchange_atmosphere_state,
                              itf.atmosphere_ocean_interface._fields, itf.net_fluxes._ocean_fields, ice=ice,
                              level1=n1, level2=n2, time_fraction=frac)
+    if itf.atmosphere_sea_ice_interface is not None:
+        # compute_atmosphere_sea_ice_fluxes! + compute_net_sea_ice_fluxes!: the skin temperature found by the
+        # iteration becomes the sea ice's top surface temperature (and the next step's first guess)
+        si, ai = model.sea_ice, itf.atmosphere_sea_ice_interface._fields
+        ocean_state = model.ocean.surface_state()
+        itf.context.compute_atmosphere_sea_ice_fluxes(si.surface_state(), ocean_state, itf.exchange_atmosphere_state, ai)
+        itf.context.compute_net_sea_ice_fluxes(si.surface_state(), ocean_state, itf.exchange_atmosphere_state, ai,
+                                               itf.net_fluxes._sea_ice_fields, frazil_heat=si.frazil_heat,
+                                               interface_heat=si.interface_heat)
+        si.top_surface_temperature.copy_(ai["temperature"])
 
 
 def time_step(model, dt):

@@ -178,6 +178,17 @@ class FluxContext:
                                                                   C.byref(f)),
                     "cf_compute_atmosphere_sea_ice_fluxes")
 
+    def compute_net_sea_ice_fluxes(self, ice_state, ocean, atmos, ai_fluxes, out, frazil_heat=None, interface_heat=None):
+        """compute_net_sea_ice_fluxes!: out = dict(top_heat=…, bottom_heat=…)."""
+        st = self._struct(abi.SeaIceState, ice_state, ("concentration", "albedo"))
+        o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(ai_fluxes)
+        n = self._struct(abi.NetSeaIceFluxes, out, ("top_heat", "bottom_heat"))
+        self._check(self.lib.cf_compute_net_sea_ice_fluxes(
+            self._h, C.byref(st), C.byref(o), C.byref(e), C.byref(f),
+            frazil_heat.data_ptr() if frazil_heat is not None else None,
+            interface_heat.data_ptr() if interface_heat is not None else None, C.byref(n)),
+            "cf_compute_net_sea_ice_fluxes")
+
     def compute_net_ocean_fluxes(self, ocean, atmos, fluxes, net, ice=None, weights=None):
         o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
         i = self.ice_struct(ice)

@@ -922,6 +922,25 @@ int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ic
     return CF_OK;
 }
 
+int cf_compute_net_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, const cf_ocean_surface* ocean,
+                                  const cf_exchange_fields* atmos, const cf_interface_fluxes* ai_fluxes,
+                                  const double* frazil_heat, const double* interface_heat,
+                                  const cf_net_sea_ice_fluxes* out) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
+    if (!ice || !ice->concentration) return fail(ctx, CF_ERR_INVALID, "sea-ice concentration is NULL");
+    if (!atmos || !atmos->Qs || !atmos->Ql) return fail(ctx, CF_ERR_INVALID, "downwelling radiation fields are NULL");
+    if (!ai_fluxes || !ai_fluxes->sensible_heat || !ai_fluxes->latent_heat || !ai_fluxes->temperature)
+        return fail(ctx, CF_ERR_INVALID, "atmosphere-sea-ice interface fluxes are NULL");
+    if (!out || !out->top_heat || !out->bottom_heat) return fail(ctx, CF_ERR_INVALID, "net sea-ice flux outputs are NULL");
+    if (ctx->ice_dev.mask_kind != CF_MASK_NONE && (!ocean || !ocean->mask)) return fail(ctx, CF_ERR_INVALID, "ocean mask is NULL");
+    const IceParams& K = ctx->ice_kernel;
+    HIP_TRY(ctx, launch_net_sea_ice_fluxes(ctx->stream, ctx->ice_dev, ctx->grid, ocean ? ocean->mask : nullptr, ice, K.albedo,
+                                           K.emissivity, K.eps_sigma, K.T_offset, atmos, ai_fluxes, frazil_heat,
+                                           interface_heat, out));
+    return CF_OK;
+}
+
 int cf_normalize_salinity_flux(cf_ctx* ctx, double* d_flux, const double* d_additional, const double* d_area,
                                const void* d_mask, double* d_mean_out) {
     if (!ctx || !d_flux) return fail(ctx, CF_ERR_INVALID, "cf_normalize_salinity_flux: bad arguments");

@@ -42,6 +42,10 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
                              int* nchunks_out);
 int chunk_table_capacity(int ncells);
 int chunk_sums_capacity(int ncells);
+hipError_t launch_net_sea_ice_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const void* mask,
+                                     const cf_sea_ice_state* ice, double albedo, double emissivity, double eps_sigma,
+                                     double T_offset, const cf_exchange_fields* e, const cf_interface_fluxes* f,
+                                     const double* frazil, const double* interface_heat, const cf_net_sea_ice_fluxes* out);
 constexpr int SALINITY_PARTIAL_BLOCKS = 512;
 hipError_t launch_salinity_partial_sums(hipStream_t st, const DevParams& P, const GridDesc& G, const double* flux,
                                         const double* additional, const double* area, const void* mask, double* partial,

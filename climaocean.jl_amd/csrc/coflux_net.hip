@@ -84,6 +84,48 @@ hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc&
 }
 
 // =============================================================================================
+// compute_net_sea_ice_fluxes!: top and bottom heat fluxes of the sea ice (pointwise, HBM bound)
+// =============================================================================================
+__global__ __launch_bounds__(NET_BLOCK) void net_sea_ice_flux_kernel(DevParams P, GridDesc G, const void* mask,
+                                                                     const double* __restrict__ conc,
+                                                                     const double* __restrict__ albedo_field, double albedo,
+                                                                     double emissivity, double eps_sigma, double T_offset,
+                                                                     const double* __restrict__ Qs, const double* __restrict__ Ql,
+                                                                     const double* __restrict__ Qc, const double* __restrict__ Qv,
+                                                                     const double* __restrict__ Ts,
+                                                                     const double* __restrict__ Qf, const double* __restrict__ Qi,
+                                                                     double* __restrict__ top, double* __restrict__ bottom) {
+    const int ncells = G.nx * G.ny;
+    const int idx = (int)blockIdx.x * NET_BLOCK + (int)threadIdx.x;
+    if (idx >= ncells) return;
+    const int j = idx / G.nx;
+    const size_t k = cell_index(G, idx - j * G.nx, j);
+    double sum_top = 0.0, sum_bottom = 0.0;
+    if (cell_is_wet(P, mask, k)) {
+        const double alb = albedo_field ? albedo_field[k] : albedo;
+        const double T = Ts[k] + T_offset, T2 = T * T;
+        const double Qu = eps_sigma * T2 * T2;
+        const double Qd = -(1.0 - alb) * Qs[k] - emissivity * Ql[k];
+        sum_top = conc[k] > 0.0 ? (Qd + Qu + Qc[k] + Qv[k]) : 0.0;
+        sum_bottom = (Qf ? Qf[k] : 0.0) + (Qi ? Qi[k] : 0.0);
+    }
+    top[k] = sum_top;
+    bottom[k] = sum_bottom;
+}
+
+hipError_t launch_net_sea_ice_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const void* mask,
+                                     const cf_sea_ice_state* ice, double albedo, double emissivity, double eps_sigma,
+                                     double T_offset, const cf_exchange_fields* e, const cf_interface_fluxes* f,
+                                     const double* frazil, const double* interface_heat, const cf_net_sea_ice_fluxes* out) {
+    const int ncells = G.nx * G.ny;
+    hipLaunchKernelGGL(net_sea_ice_flux_kernel, dim3((ncells + NET_BLOCK - 1) / NET_BLOCK), dim3(NET_BLOCK), 0, st, P, G, mask,
+                       ice->concentration, ice->albedo, albedo, emissivity, eps_sigma, T_offset, e->Qs, e->Ql,
+                       f->sensible_heat, f->latent_heat, f->temperature, frazil, interface_heat, out->top_heat,
+                       out->bottom_heat);
+    return hipGetLastError();
+}
+
+// =============================================================================================
 // NormalizeSalinity: area-weighted mean over wet interior cells, then subtract from the whole parent
 // =============================================================================================
 constexpr int RED_BLOCK = 256;

@@ -184,6 +184,14 @@ compute_atmosphere_sea_ice_fluxes!(b::CoFluxBackend, ice::CfSeaIceState, ocean::
                        (Ptr{Cvoid}, Ref{CfSeaIceState}, Ref{CfOceanSurface}, Ref{CfExchangeFields}, Ref{CfInterfaceFluxes}),
                        b.ctx, ice, ocean, atmos, out))
 
+struct CfNetSeaIceFluxes; top_heat::Ptr{Float64}; bottom_heat::Ptr{Float64}; end
+# compute_net_sea_ice_fluxes!(coupled_model): ΣQt, ΣQb handed to the sea-ice thermodynamics (frazil / interface may be C_NULL)
+compute_net_sea_ice_fluxes!(b::CoFluxBackend, ice::CfSeaIceState, ocean::CfOceanSurface, atmos::CfExchangeFields,
+                            ai::CfInterfaceFluxes, frazil::Ptr{Float64}, interface::Ptr{Float64}, out::CfNetSeaIceFluxes) =
+    check(b.ctx, ccall((:cf_compute_net_sea_ice_fluxes, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfSeaIceState}, Ref{CfOceanSurface}, Ref{CfExchangeFields}, Ref{CfInterfaceFluxes},
+                        Ptr{Float64}, Ptr{Float64}, Ref{CfNetSeaIceFluxes}), b.ctx, ice, ocean, atmos, ai, frazil, interface, out))
+
 # ---- JRA55 snapshot window in HBM: JRA55PrescribedAtmosphere(arch; time_indices_in_memory, prefetch) ---------
 mutable struct CoFluxWindow
     ptr::Ptr{Cvoid}

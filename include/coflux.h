@@ -439,6 +439,21 @@ int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, co
 int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, const cf_ocean_surface* ocean,
                                          const cf_exchange_fields* atmos, const cf_interface_fluxes* out);
 
+/* compute_net_sea_ice_fluxes!(coupled_model): the heat the sea-ice thermodynamics receives at its two faces,
+ *   ΣQt = (Q_d + Q_u + Q_c + Q_v)·[ℵ > 0],  Q_u = εσT_s⁴ at the skin temperature just computed,
+ *                                            Q_d = −(1 − α)Q_s − εQ_ℓ   (positive upward, W m⁻²),
+ *   ΣQb = Q_frazil + Q_interface             (the ice–ocean exchange, taken as given: SURVEY §8f),
+ * zero on land.  `ai_fluxes` is the output of cf_compute_atmosphere_sea_ice_fluxes; radiative properties are
+ * those of cf_set_sea_ice_formulation.  frazil_heat / interface_heat may be NULL (⇒ 0).                  */
+typedef struct cf_net_sea_ice_fluxes {
+    double* top_heat;     /* ΣQt */
+    double* bottom_heat;  /* ΣQb */
+} cf_net_sea_ice_fluxes;
+int cf_compute_net_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, const cf_ocean_surface* ocean,
+                                  const cf_exchange_fields* atmos, const cf_interface_fluxes* ai_fluxes,
+                                  const double* frazil_heat, const double* interface_heat,
+                                  const cf_net_sea_ice_fluxes* out);
+
 /* NormalizeSalinity callback (src/OMIPConfigurations/omip_simulation.jl:182-220, added at :385-388):
  * subtract the global, area-weighted mean over wet cells of (salinity flux [+ additional flux]) from
  * the salinity-flux field — `compute!(mean_total); parent(flux_field) .-= mean_total`, so the constant

@@ -770,6 +770,31 @@ int oracle_compute_atmosphere_sea_ice_fluxes(const cf_grid* g, const cf_flux_par
     return 0;
 }
 
+/* compute_net_sea_ice_fluxes! (NumericalEarth, [UPSTREAM-RECALL]; in-tree anchors atmosphere.jl:34-44 for the
+ * radiative properties, omip_diagnostics.jl:86-89 for the ice–ocean terms): top and bottom heat fluxes handed to
+ * the sea-ice thermodynamics.  ΣQt only where there is ice; zero on land. */
+int oracle_compute_net_sea_ice_fluxes(const cf_grid* g, const cf_flux_params* P, const cf_sea_ice_params* I,
+                                      const cf_sea_ice_state* ice, const cf_ocean_surface* o, const cf_exchange_fields* a,
+                                      const cf_interface_fluxes* f, const double* frazil, const double* interface_heat,
+                                      double* top, double* bottom) {
+    for (int j = 0; j < g->ny; ++j)
+        for (int i = 0; i < g->nx; ++i) {
+            size_t k = IDX(g, i, j);
+            double st = 0.0, sb = 0.0;
+            if (is_wet(P, g, o->mask, i, j)) {
+                double alb = ice->albedo ? ice->albedo[k] : I->albedo;
+                double T = f->temperature[k] + I->temperature_offset;
+                double Qu = I->emissivity * P->stefan_boltzmann * T * T * T * T;
+                double Qd = -(1.0 - alb) * a->Qs[k] - I->emissivity * a->Ql[k];
+                st = ice->concentration[k] > 0.0 ? (Qd + Qu + f->sensible_heat[k] + f->latent_heat[k]) : 0.0;
+                sb = (frazil ? frazil[k] : 0.0) + (interface_heat ? interface_heat[k] : 0.0);
+            }
+            top[k] = st;
+            bottom[k] = sb;
+        }
+    return 0;
+}
+
 /* NormalizeSalinity (src/OMIPConfigurations/omip_simulation.jl:182-220): `compute!(mean_total)` is
  * Oceananigans' Average over dims (1,2) — area weighted, immersed cells excluded — and
  * `parent(flux_field) .-= mean_total` subtracts it from the whole parent array. */

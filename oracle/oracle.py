@@ -205,6 +205,31 @@ def compute_atmosphere_sea_ice_fluxes(g, params, ice_params, ice, ocean, atmos):
     return out
 
 
+def compute_net_sea_ice_fluxes(g, params, ice_params, ice, ocean, atmos, ai_fluxes, frazil=None, interface_heat=None):
+    lib, keep = load(), []
+    o = _ocean_struct(ocean, keep)
+    a = {n: _f64(atmos[n]) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
+    e = _exchange_struct(a)
+    st = abi.SeaIceState()
+    for n in ("concentration", "albedo"):
+        if ice.get(n) is not None:
+            arr = _f64(ice[n])
+            keep.append(arr)
+            setattr(st, n, _ptr(arr))
+    f = abi.InterfaceFluxes()
+    for n in ("sensible_heat", "latent_heat", "temperature"):
+        arr = _f64(ai_fluxes[n])
+        keep.append(arr)
+        setattr(f, n, _ptr(arr))
+    fr = None if frazil is None else _f64(frazil)
+    ih = None if interface_heat is None else _f64(interface_heat)
+    top, bottom = np.zeros(_shape(g)), np.zeros(_shape(g))
+    rc = lib.oracle_compute_net_sea_ice_fluxes(C.byref(g), C.byref(params), C.byref(ice_params), C.byref(st), C.byref(o),
+                                               C.byref(e), C.byref(f), _ptr(fr), _ptr(ih), _ptr(top), _ptr(bottom))
+    assert rc == 0
+    return dict(top_heat=top, bottom_heat=bottom)
+
+
 def normalize_salinity_flux(g, params, flux, mask, additional=None, area=None):
     """Returns (normalised flux copy, mean)."""
     lib = load()

@@ -486,3 +486,37 @@ def test_sea_ice_interface_requires_formulation():
                                               dict(T=z["T_"], S=z["S"]), {k: z[k] for k in EXCHANGE_NAMES},
                                               ctx.field_set(FLUX_NAMES))
     ctx.close()
+
+
+def test_net_sea_ice_fluxes_match_oracle():
+    case = util.build_case(131, 67)
+    nx, ny, hx, hy = 131, 67, 3, 3
+    fluxes_f, vd = util.ICE_CONFIGS["sea_ice_corrected"]()
+    ice_params = ic.flux_params(fluxes_f, velocity_difference=vd)
+    props = ic.SeaIceInterfaceProperties()
+    g = orc.make_grid(nx, ny, hx, hy, 1)
+    at = util.polar_atmosphere(orc.interpolate_atmosphere_state(g, case["src"], case["weights"], 0, 1, 0.37))
+    state = dict(case["ice_state"])
+    ctx = FluxContext(nx, ny, hx, hy, ic.flux_params(), ring=1)
+    ctx.set_sea_ice_formulation(ice_params, props.to_params())
+    dev = ctx.to_device
+    ocean = {k: dev(case["ocean"][k]) for k in ("T", "S", "u", "v", "mask")}
+    atmos = {k: dev(at[k]) for k in EXCHANGE_NAMES}
+    st = {k: dev(v) for k, v in state.items()}
+    ai = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL)
+    ctx.compute_atmosphere_sea_ice_fluxes(st, ocean, atmos, ai)
+    rng = np.random.default_rng(3)
+    Qf, Qi = rng.normal(size=at["T"].shape), rng.normal(size=at["T"].shape)
+    out = ctx.field_set(("top_heat", "bottom_heat"))
+    ctx.compute_net_sea_ice_fluxes(st, ocean, atmos, ai, out, frazil_heat=dev(Qf), interface_heat=dev(Qi))
+    ctx.sync()
+    ai_np = {k: v.cpu().numpy() for k, v in ai.items()}
+    ref = orc.compute_net_sea_ice_fluxes(g, ice_params, props.to_params(), state, case["ocean"], at, ai_np, Qf, Qi)
+    for k in ("top_heat", "bottom_heat"):
+        e = util.rel_err(util.window(out[k].cpu().numpy(), hx, hy, nx, ny, 0), util.window(ref[k], hx, hy, nx, ny, 0), 1.0)
+        assert e <= TOL_LINEAR, (k, e)
+    out2 = ctx.field_set(("top_heat", "bottom_heat"))
+    ctx.compute_net_sea_ice_fluxes(st, ocean, atmos, ai, out2)     # no ice–ocean terms
+    ctx.sync()
+    assert torch.all(out2["bottom_heat"] == 0.0) and torch.equal(out2["top_heat"], out["top_heat"])
+    ctx.close()

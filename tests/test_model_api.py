@@ -60,3 +60,72 @@ def test_readme_recipe_config1_matches_oracle():
     # hfds [W/m²] = JT·ρ·cp (visualize/cache.jl:359-361) is O(100)
     hfds = util.window(bc.T.cpu().numpy(), h, h, nx, ny, 0) * 1026.0 * 3991.86795711963
     assert 10 < np.abs(hfds).max() < 2000
+
+
+@pytest.mark.gpu
+def test_config3_sea_ice_coupling_through_the_model_api():
+    """BASELINE config 3: OceanSeaIceModel(ocean, sea_ice; atmosphere) with the :corrected interfaces
+    (omip_simulation.jl:139-147).  Ocean partition with the ice-concentration mask, atmosphere–sea-ice interface
+    with skin temperature, net sea-ice fluxes; the skin temperature is carried from step to step."""
+    import torch
+    nx, ny, nz, h = 90, 40, 10, 3
+    grid = cm.LatitudeLongitudeGrid(size=(nx, ny, nz), halo=(h, h, h), latitude=(-70, 70), z=(-3000, 0))
+    ocean = cm.ocean_simulation(grid)
+    state = syn.ocean_state(nx, ny, h, h)
+    cm.set_surface(ocean, T=state["T"], S=state["S"], u=state["u"], v=state["v"], mask=state["mask"])
+    ice_np = syn.sea_ice_state(nx, ny, h, h)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to("cuda")
+    sea_ice = cm.PrescribedSeaIce(concentration=dev(state["ice_concentration"]), interface_heat=dev(state["ice_interface_heat"]),
+                                  salt_flux=dev(state["ice_salt_flux"]), x_stress=dev(state["ice_x_stress"]),
+                                  y_stress=dev(state["ice_y_stress"]), thickness=dev(ice_np["thickness"]),
+                                  top_surface_temperature=dev(ice_np["top_temperature"]), u=dev(ice_np["u"]),
+                                  v=dev(ice_np["v"]), albedo=dev(ice_np["albedo"]))
+    snaps = syn.jra55_snapshots(2)
+    atmosphere = cm.JRA55PrescribedAtmosphere(snaps)
+    interfaces = cm.ComponentInterfaces(atmosphere, ocean, sea_ice,
+                                        atmosphere_ocean_fluxes=ic.corrected_atmosphere_ocean_fluxes(),
+                                        atmosphere_sea_ice_fluxes=ic.corrected_atmosphere_sea_ice_fluxes(),
+                                        atmosphere_ocean_velocity_difference=ic.RelativeVelocity(),
+                                        atmosphere_sea_ice_velocity_difference=ic.RelativeVelocity(),
+                                        ocean_minimum_salinity=1.0, store_similarity_scales=True)
+    model = cm.OceanSeaIceModel(ocean, sea_ice, atmosphere=atmosphere, interfaces=interfaces)   # update_state! once
+    Ts1 = sea_ice.top_surface_temperature.cpu().numpy().copy()
+
+    # oracle replay of that first update_state!
+    g = orc.make_grid(nx, ny, h, h, 1)
+    fi, fj, phi = grid.fractional_indices()
+    w = dict(separable=True, fi=fi, fj=fj, latitude=phi)
+    props = ic.OceanProperties(surface_z=grid.surface_z)
+    at = orc.interpolate_atmosphere_state(g, snaps, w, 0, 1, 0.0)
+    p_ao = ic.flux_params(ic.corrected_atmosphere_ocean_fluxes(), velocity_difference=ic.RelativeVelocity(), ocean=props,
+                          ocean_minimum_salinity=1.0)
+    fl = orc.compute_atmosphere_ocean_fluxes(g, p_ao, state, at)
+    ice_fields = dict(concentration=state["ice_concentration"], interface_heat=state["ice_interface_heat"],
+                      salt_flux=state["ice_salt_flux"], x_stress=state["ice_x_stress"], y_stress=state["ice_y_stress"])
+    net = orc.compute_net_ocean_fluxes(g, p_ao, state, at, fl, ice=ice_fields, weights=w)
+    p_ai = ic.flux_params(ic.corrected_atmosphere_sea_ice_fluxes(), velocity_difference=ic.RelativeVelocity(), ocean=props)
+    iprops = ic.SeaIceInterfaceProperties().to_params()
+    ice_state = dict(ice_np, concentration=state["ice_concentration"])
+    ai = orc.compute_atmosphere_sea_ice_fluxes(g, p_ai, iprops, ice_state, state, at)
+    nsi = orc.compute_net_sea_ice_fluxes(g, p_ai, iprops, ice_state, state, at, ai, None, state["ice_interface_heat"])
+
+    W = lambda a, r=0: util.window(a, h, h, nx, ny, r)
+    bc = ocean.model.top_boundary_conditions
+    for name, tensor in (("u", bc.u), ("v", bc.v), ("T", bc.T), ("S", bc.S)):
+        assert util.rel_err(W(tensor.cpu().numpy()), W(net[name]), util.FIELD_SCALE[name]) < 1e-9, name
+    got_ai = {k: W(getattr(model.interfaces.atmosphere_sea_ice_interface.fluxes, k).cpu().numpy(), 1)
+              for k in util.ICE_FLUX_FIELDS}
+    got_ai["iterations"] = W(ai["iterations"], 1)      # (not stored by the model: compare the fields only)
+    util.compare_ice_fluxes(got_ai, {k: W(ai[k], 1) for k in list(util.ICE_FLUX_FIELDS) + ["iterations"]}, 1e-9)
+    conv = W(ai["iterations"]) < 100
+    assert util.rel_err(W(Ts1)[conv], W(ai["temperature"])[conv], 1.0) < 1e-9
+    top = model.interfaces.net_fluxes.sea_ice.top_heat.cpu().numpy()
+    bot = model.interfaces.net_fluxes.sea_ice.bottom_heat.cpu().numpy()
+    assert util.rel_err(W(top)[conv], W(nsi["top_heat"])[conv], 1.0) < 1e-8
+    assert util.rel_err(W(bot), W(nsi["bottom_heat"]), 1.0) < 1e-12
+
+    # the skin temperature is the next step's first guess: a second step changes it only where it had not converged
+    cm.time_step(model, 20 * cm.minutes)
+    Ts2 = sea_ice.top_surface_temperature.cpu().numpy()
+    assert np.isfinite(Ts2).all() and np.all(W(Ts2)[W(state["mask"]) != 0] <= 0.0)
+    assert model.clock.iteration == 1
