@@ -1,10 +1,11 @@
 // coflux_solver.hip — compute_atmosphere_ocean_fluxes! on gfx950: the Monin–Obukhov fixed point.
 //
-// One lane = one ocean cell.  The kernel is FP64-issue bound (≈ 250–480 VALU instructions per
+// One lane = one ocean cell.  The kernel is FP64-issue bound (≈ 130–200 VALU instructions per
 // iteration × 10–20 iterations per cell against 128 algorithmic bytes), so the design goal is to
 // waste no issue slot: ψ/log tables in LDS (coflux_fast.hpp), land compacted away before the
-// iteration, waves leaving the loop on a wave64 ballot, one workgroup per 512-cell chunk so that
-// the hardware dispatcher balances chunks of different wet fraction and trip count.
+// iteration, batches of cells with equal trip counts, waves leaving the loop on a wave64 ballot,
+// one workgroup per chunk of a table that gives every workgroup whole batches and fills the
+// device's resident-workgroup slots in whole rounds.
 #include <hip/hip_runtime.h>
 
 #include "coflux_fast.hpp"
@@ -214,8 +215,12 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
     const double* logt = tab + 4 * PSI_TABLE;
 
     const int wx = G.nx + 2 * G.ring;
-    const int range_end = chunk_begins[blockIdx.x + 1];
-    int begin = chunk_begins[blockIdx.x], end = range_end;
+    // Workgroups are dealt to the 8 XCDs round-robin; give every XCD a contiguous band of chunks so that the
+    // rows shared by neighbouring chunks (v at j+1, u at i+1) meet in one L2.
+    const int nch = (int)gridDim.x, per = nch / 8, extra = nch - per * 8, x = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+    const int chunk = nch < 16 ? (int)blockIdx.x : x * per + min(x, extra) + q;
+    const int range_end = chunk_begins[chunk + 1];
+    int begin = chunk_begins[chunk], end = range_end;
     for (;;) {
         if (tid < 2) counters[tid] = 0;
         if (tid < AO_BINS) hist[tid] = 0;
