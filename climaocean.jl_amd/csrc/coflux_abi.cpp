@@ -516,7 +516,7 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->launch.solver = value;
             return CF_OK;
         case CF_OPT_INTERP_TILE_CAP:
-            if (value < 16 || value > 512) return fail(ctx, CF_ERR_INVALID, "interp tile cap %d outside [16, 512]", value);
+            if (value != 0 && (value < 16 || value > 512)) return fail(ctx, CF_ERR_INVALID, "interp tile cap %d: 0 (LDS-free gather kernel) or 16…512", value);
             ctx->launch.interp_cap = value;
             return CF_OK;
         case CF_OPT_MAX_BLOCKS:

@@ -164,8 +164,84 @@ __global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Background variant: no LDS, ≤ 64 VGPRs, one cell per lane, all 72 corner values gathered from L2.
+// Alone it is slower than the tiled kernel (texture-address bound), but it fits into the register and LDS
+// budget the flux solver leaves free on every CU (3 × 147 VGPRs, 159 of 160 KB LDS), so on a second stream
+// it runs INSIDE the solver of the current step while that kernel is FP64-issue bound
+// (cf_prefetch_atmosphere_state).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interpolate_gather_kernel(SourceDesc S, WeightDesc Wt, GridDesc G, Exchange E) {
+    const int wx = G.nx + 2 * G.ring, wy = G.ny + 2 * G.ring;
+    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (idx >= wx * wy) return;
+    const int jj = idx / wx;
+    const int i = idx - jj * wx - G.ring, j = jj - G.ring;
+    const unsigned k = (unsigned)((j + G.hy) * G.sj + (i + G.hx));   // surfaces of < 2³² cells
+    const double fi = Wt.separable ? Wt.fi[i + G.hx] : Wt.fi[k];
+    const double fj = Wt.separable ? Wt.fj[j + G.hy] : Wt.fj[k];
+    const double ti = trunc(fi), tj = trunc(fj);
+    const double xi = fi - ti, eta = fj - tj;
+    unsigned g00, g10, g01, g11;   // offsets inside one (level, variable) plane
+    {
+        const int i0 = (int)ti, ja = (int)tj;
+        const int is0 = wrap_index(i0, S.ns_x), is1 = wrap_index(i0 + (fi > 0.0 ? 1 : (fi < 0.0 ? -1 : 0)), S.ns_x);
+        const int j0 = min(max(ja, 0), S.ns_y - 1), j1 = min(max(ja + (fj > 0.0 ? 1 : (fj < 0.0 ? -1 : 0)), 0), S.ns_y - 1);
+        g00 = (unsigned)(j0 * S.ns_x + is0);
+        g10 = (unsigned)(j0 * S.ns_x + is1);
+        g01 = (unsigned)(j1 * S.ns_x + is0);
+        g11 = (unsigned)(j1 * S.ns_x + is1);
+    }
+    const unsigned plane = (unsigned)(S.ns_x * S.ns_y);
+    const unsigned off1 = (unsigned)S.level1 * plane, off2 = (unsigned)S.level2 * plane;
+    const double w00 = (1.0 - xi) * (1.0 - eta), w01 = (1.0 - xi) * eta, w10 = xi * (1.0 - eta), w11 = xi * eta;
+    // same operation order as the tiled kernel (bitwise-identical results)
+    auto value = [&](int v) {
+        const float* a = S.data[v] + off1;
+        const float* b = S.data[v] + off2;
+        const double v1 = w00 * (double)a[g00] + w01 * (double)a[g01] + w10 * (double)a[g10] + w11 * (double)a[g11];
+        const double v2 = w00 * (double)b[g00] + w01 * (double)b[g01] + w10 * (double)b[g10] + w11 * (double)b[g11];
+        return v2 * S.tf + v1 * (1.0 - S.tf);
+    };
+    // One variable at a time in a rolled loop: ≤ 56 VGPRs is what fits beside three resident solver waves per
+    // SIMD (3 × 152 of 512 registers).
+    double ua = 0.0, va = 0.0, rain = 0.0;
+#pragma unroll 1
+    for (int v = 0; v < CF_JRA55_NVARS; ++v) {
+        const double x = value(v);
+        switch (v) {
+            case CF_JRA55_TAS: E.T[k] = x; break;
+            case CF_JRA55_PSL: E.p[k] = x; break;
+            case CF_JRA55_HUSS: E.q[k] = x; break;
+            case CF_JRA55_RSDS: E.Qs[k] = x; break;
+            case CF_JRA55_RLDS: E.Ql[k] = x; break;
+            case CF_JRA55_PRRA: rain = x; break;
+            case CF_JRA55_PRSN: E.Mp[k] = rain + x; break;
+            case CF_JRA55_UAS: ua = x; break;
+            default: va = x; break;
+        }
+    }
+    if (Wt.cos_rot != nullptr && Wt.sin_rot != nullptr) {
+        const double cs = Wt.cos_rot[k], sn = Wt.sin_rot[k];
+        const double ui = ua * cs + va * sn;
+        va = -ua * sn + va * cs;
+        ua = ui;
+    }
+    E.u[k] = ua;
+    E.v[k] = va;
+}
+
+hipError_t launch_interpolate_background(hipStream_t st, const GridDesc& G, const cf_atmos_source* s,
+                                         const cf_interp_weights* w, const cf_exchange_fields* e) {
+    const int n = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
+    hipLaunchKernelGGL(interpolate_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, make_source(s), make_weights(w), G,
+                       make_exchange(e));
+    return hipGetLastError();
+}
+
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
                               const cf_interp_weights* w, const cf_exchange_fields* e) {
+    if (L.interp_cap == 0) return launch_interpolate_background(st, G, s, w, e);  // CF_OPT_INTERP_TILE_CAP = 0
     constexpr int ROWS = 4;
     const int wx = G.nx + 2 * G.ring, wy = G.ny + 2 * G.ring;
     const int ntiles = ((wx + 63) / 64) * ((wy + ROWS - 1) / ROWS);

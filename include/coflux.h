@@ -321,7 +321,9 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 
 /* Implementation options (none of them changes what is computed beyond the stated tolerance).  */
 #define CF_OPT_SOLVER 0           /* CF_SOLVER_*                                                   */
-#define CF_OPT_INTERP_TILE_CAP 1  /* source nodes per variable in a wave's LDS JRA55 tile (128)      */
+#define CF_OPT_INTERP_TILE_CAP 1  /* source nodes per variable in a wave's LDS JRA55 tile (128; 16…512), or 0:
+                                     the LDS-free one-cell-per-lane gather kernel (≤ 56 VGPRs: small enough to run
+                                     beside the resident solver workgroups from a second stream)            */
 #define CF_OPT_MAX_BLOCKS 2       /* reserved for persistent-grid experiments (multiple of 8)        */
 #define CF_OPT_TRIP_HINTS 3       /* 1 (default): order each chunk's cells by their iteration count in the
                                      previous call so that the lanes of a wave finish together; scheduling only */
