@@ -162,6 +162,24 @@ def main():
         except Exception:
             pass
 
+        # Second view of the dominant kernel: it is FP64-VALU-issue bound, not HBM bound.  VALU
+        # wave-instructions per launch come from the committed PMC pass (profiles/r01d_pmc_ao.json, same workload);
+        # peak = one VALU instruction per SIMD per 4 cycles × 1024 SIMDs at the 2.4 GHz engine clock.
+        valu = None
+        try:
+            kname = {"default": "ao_flux_fast_kernel<false, 0>", "corrected": "ao_flux_fast_kernel<true, 0>"}.get(a.flux_configuration)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_ao.json")))["kernels"]
+            if kname in pm and (nx, ny, world) == (1440, 560, 1):
+                n_inst = pm[kname]["SQ_INSTS_VALU"]
+                peak = 1024 * 2.4e9 / 4
+                ach = n_inst / (ao_ms * 1e-3)
+                valu = dict(bound="fp64-valu-issue", kernel="ao_flux_fast_kernel", achieved=ach / 1e9, peak=peak / 1e9,
+                            unit="G wave-instructions/s", frac=ach / peak, valu_instructions_per_launch=n_inst,
+                            lane_utilisation=pm[kname]["SQ_THREAD_CYCLES_VALU"] / (64.0 * pm[kname]["SQ_ACTIVE_INST_VALU"]),
+                            source="profiles/r01d_pmc_ao.json (rocprofv3 --pmc SQ_INSTS_VALU)")
+        except Exception:
+            pass
+
         def roof(name, nbytes, ncells, ms):
             achieved = nbytes * ncells / (ms * 1e-3) / 1e9
             return dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
@@ -182,6 +200,7 @@ def main():
                    roofline=roof("ao_flux_fast_kernel (compute_atmosphere_ocean_fluxes!)", BYTES_AO, cells_rank, ao_ms),
                    roofline_interpolate=roof("interpolate_kernel (interpolate_atmosphere_state!)", BYTES_INTERP, cells_rank, interp_ms),
                    roofline_net_fluxes=roof("net_flux_kernel (compute_net_ocean_fluxes!)", BYTES_NET, nx * ny, net_ms),
+                   roofline_fp64_valu=valu,
                    stages_ms=dict(interpolate=interp_ms, ao_fluxes=ao_ms, net_fluxes=net_ms),
                    device_copy_GBs=2 * copy_bytes / (copy_ms * 1e-3) / 1e9,
                    parity="vs reference: unpinned (self-consistent restatements only; see DESIGN.md)")
