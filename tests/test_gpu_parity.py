@@ -520,3 +520,50 @@ def test_net_sea_ice_fluxes_match_oracle():
     ctx.sync()
     assert torch.all(out2["bottom_heat"] == 0.0) and torch.equal(out2["top_heat"], out["top_heat"])
     ctx.close()
+
+
+def test_adversarial_inputs_match_the_oracle_cell_by_cell():
+    """Edge states the reference kernels meet in practice: calm (Δu = 0 exactly), hurricane-force wind, bone-dry and
+    super-saturated air, fresh and hypersaline water, freezing and 35 °C water, low pressure — and a NaN-poisoned
+    atmosphere cell, which must come out as NaN in every flux field (as in the oracle), not as a plausible number."""
+    nx, ny, h = 64, 8, 2
+    case = util.build_case(nx, ny, h, h, land=False)
+    g = orc.make_grid(nx, ny, h, h, 1)
+    at = orc.interpolate_atmosphere_state(g, case["src"], case["weights"], 0, 1, 0.37)
+    oc = {k: np.array(v, copy=True) for k, v in case["ocean"].items()}
+    row = h + 3
+    cols = slice(h, h + 12)
+    oc["u"][row, :] = 0.0; oc["v"][row:row + 2, :] = 0.0
+    at["u"][row, cols] = [0.0, 80.0, 5.0, 5.0, 5.0, 5.0, 5.0, 5.0, 5.0, 1e-9, 5.0, 5.0]
+    at["v"][row, cols] = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    at["q"][row, cols] = [0.01, 0.01, 0.0, 0.05, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01]
+    oc["S"][row, cols] = [35, 35, 35, 35, 0.0, 45.0, 35, 35, 35, 35, 35, 35]
+    oc["T"][row, cols] = [15, 15, 15, 15, 15, 15, -1.9, 35.0, 15, 15, 15, 15]
+    at["p"][row, cols] = [101325] * 8 + [50000.0] + [101325] * 3
+    at["T"][row, cols] = [288, 288, 288, 288, 288, 288, 272, 300, 288, 288, 250.0, np.nan]
+    for params in (ic.flux_params(), ic.flux_params(ic.corrected_atmosphere_ocean_fluxes()),
+                   ic.flux_params(ic.ncar_atmosphere_ocean_fluxes())):
+        ref = orc.compute_atmosphere_ocean_fluxes(g, params, oc, at)
+        ctx = FluxContext(nx, ny, h, h, params)
+        dev = ctx.to_device
+        ocean = {k: dev(oc[k]) for k in ("T", "S", "u", "v", "mask")}
+        atmos = {k: dev(at[k]) for k in EXCHANGE_NAMES}
+        fl = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL)
+        fl["iterations"] = ctx.zeros(torch.int32)
+        ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fl)
+        ctx.sync()
+        got = {k: v.cpu().numpy() for k, v in fl.items()}
+        ctx.close()
+        W = lambda a: util.window(a, h, h, nx, ny, 1)
+        nan_cell = np.isnan(W(at["T"]))
+        assert nan_cell.sum() >= 1
+        for k in FLUX_NAMES:
+            gk, rk = W(got[k]), W(ref[k])
+            if k != "temperature":
+                assert np.all(np.isnan(gk[nan_cell])) and np.all(np.isnan(rk[nan_cell])), k
+            ok = ~nan_cell
+            assert np.all(np.isfinite(gk[ok])), k
+            e = util.rel_err(gk[ok], rk[ok], util.FIELD_SCALE[k])
+            assert e <= 1e-6 if np.any(W(ref["iterations"]) >= 100) else e <= TOL_SOLVER, (k, e)
+        # calm cell: exactly zero stress
+        assert W(got["x_momentum"])[3 + 1, 0 + 1] == 0.0 and W(got["y_momentum"])[3 + 1, 0 + 1] == 0.0
