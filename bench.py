@@ -118,6 +118,34 @@ def main():
         halo = SlabHaloExchanger(ctx, ny, h, rows=1, backend="torch")
     halo_fields = [ocean[k] for k in ("T", "S", "u", "v")]
 
+    # Prove the exchange on this machine before timing it: the synthetic state is a function of the GLOBAL cell
+    # index, so every rank knows what its neighbours' boundary rows must be.  Wipe the halo rows, exchange, compare.
+    halo_verified = None
+    if world > 1:
+        def check(exchanger):
+            rows = [r for r, has in ((h - 1, rank > 0), (h + ny, rank < world - 1)) if has]
+            want = [[f[r].clone() for r in rows] for f in halo_fields]
+            for f in halo_fields:
+                for r in rows:
+                    f[r].fill_(float("nan"))
+            exchanger(halo_fields)
+            ctx.sync()
+            torch.cuda.synchronize()
+            good = all(torch.equal(f[r], w) for f, ws in zip(halo_fields, want) for r, w in zip(rows, ws))
+            for f, ws in zip(halo_fields, want):      # restore either way
+                for r, w in zip(rows, ws):
+                    f[r].copy_(w)
+            flag = torch.tensor([1 if good else 0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+        halo_verified = check(halo)
+        if not halo_verified and halo.backend == "rccl":
+            print("[bench] native RCCL halo rows did not match the neighbours' rows; using torch.distributed P2P", file=sys.stderr)
+            halo = SlabHaloExchanger(ctx, ny, h, rows=1, backend="torch")
+            halo_verified = check(halo)
+        if not halo_verified:
+            raise SystemExit("bench.py: halo exchange does not reproduce the neighbours' boundary rows")
+
     def step():
         halo(halo_fields)
         ctx.update_state(src, w, ocean, atmos, fl, net, time_fraction=0.37)
@@ -195,7 +223,7 @@ def main():
                                         f"{'GPU' if a.scaling == 'weak' else 'job'}, JRA55 640x320 f32 atmosphere, "
                                         f"SimilarityTheoryFluxes(:{a.flux_configuration}) + Radiation, halo {h}, ring 1",
                                global_cells=cells_total, parallelism=f"latitude-slab x{world}",
-                               halo_backend=halo.backend),
+                               halo_backend=halo.backend, halo_verified=halo_verified),
                    # dominant kernel = compute_atmosphere_ocean_fluxes! (SURVEY.md §8d contract figure 128 B/cell)
                    roofline=roof("ao_flux_fast_kernel (compute_atmosphere_ocean_fluxes!)", BYTES_AO, cells_rank, ao_ms),
                    roofline_interpolate=roof("interpolate_kernel (interpolate_atmosphere_state!)", BYTES_INTERP, cells_rank, interp_ms),
