@@ -527,8 +527,8 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->launch.d_hint = value ? ctx->d_hint : nullptr;
             return CF_OK;
         case CF_OPT_AO_CHUNK:
-            if (value != 0 && value != 256 && value != 512 && value != 768)
-                return fail(ctx, CF_ERR_INVALID, "solver chunk %d: wet cells per workgroup must be 0 (automatic), 256, 512 or 768", value);
+            if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024)
+                return fail(ctx, CF_ERR_INVALID, "solver chunk %d: wet cells per workgroup must be 0 (automatic), 256, 512, 768 or 1024", value);
             ctx->launch.ao_chunk = value;
             ctx->chunk_valid = false;
             return CF_OK;

@@ -17,7 +17,7 @@ namespace coflux {
 constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 
 constexpr int AO_BLOCK = 256;
-constexpr int AO_CHUNK = 768;  // capacity of a workgroup's wet-cell list = the most wet cells a chunk can hold
+constexpr int AO_CHUNK = 1024;  // capacity of a workgroup's wet-cell list = the most wet cells a chunk can hold
 constexpr int AO_BINS = 32;    // trip-count bins of the per-chunk counting sort
 constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + 16 + 2 * AO_BINS * 4;
 constexpr int AO_LDS_BYTES = AO_PARAMS_OFFSET + (int)sizeof(DevParams);
@@ -145,35 +145,52 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
     hipError_t e = hipMemcpyAsync(&total, d_sums + nblocks, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    const int slots = 3 * (cu_count > 0 ? cu_count : 256);
+    // Layers.  Workgroups are dealt out in blockIdx order, one per CU before a CU gets its second, so workgroup b
+    // is the (b / CUs)-th arrival on its CU — and the SIMD arbiter serves the OLDEST wave first (s_setprio does not
+    // change that: measured).  With three equal workgroups per CU the first finishes at 60 % of the kernel and the
+    // third runs the last third alone, too few waves to keep the FP64 pipe busy (lifetimes 58 / 73 / 92 µs at
+    // equal work).  So the work is handed out in proportion to the share each arrival gets: 1024, 768 and 512
+    // wet cells for the last three layers (all multiples of 256 = whole batches for four waves), 1024 for every
+    // layer before them (on larger surfaces a new workgroup starts whenever the oldest one retires and the
+    // pipeline staggers itself; only the tail needs shaping).
+    const int layer = cu_count > 0 ? cu_count : 256;
     ChunkRounds R{};
-    int remaining = total, next_id = 0, largest = 0;
+    int next_id = 0, largest = 0;
     R.base[0] = 0;
-    while (remaining > 0 && R.n < AO_MAX_ROUNDS) {
-        // the remainder goes into one last round of the smallest chunk size that still fits the slots;
-        // otherwise a full round of the largest chunks
-        int w = 0;
-        bool last = true;
-        if (wet_per_chunk > 0) {
-            w = wet_per_chunk;  // forced size: one "round" holds everything
-        } else {
-            for (int cand = 256; cand <= 768 && !w; cand += 256)
-                if (((long)remaining + (long)cand * AO_WET_COST - 1) / ((long)cand * AO_WET_COST) <= slots) w = cand;
-            if (!w && R.n < AO_MAX_ROUNDS - 1) {
-                w = 768;
-                last = false;
-            }
-        }
-        if (w == 0) w = 768;
+    auto add_round = [&](int w, long count, bool last) {
         const int cost = w * AO_WET_COST;
-        const int count = last ? (remaining + cost - 1) / cost : slots;
         R.cost[R.n] = cost;
         R.first[R.n] = next_id;
-        R.base[R.n + 1] = last ? total + AO_WET_COST : R.base[R.n] + count * cost;
-        next_id += count;
-        remaining = last ? 0 : remaining - count * cost;
-        if (w > largest) largest = w;
+        R.base[R.n + 1] = last ? total + AO_WET_COST : R.base[R.n] + (int)(count * cost);
+        next_id += (int)count;
+        largest = w > largest ? w : largest;
         ++R.n;
+    };
+    auto cap = [&](int w) { return (long)layer * w * AO_WET_COST; };
+    auto chunks = [&](long cost_units, int w) { return (cost_units + (long)w * AO_WET_COST - 1) / ((long)w * AO_WET_COST); };
+    long need = total;
+    if (wet_per_chunk > 0) {
+        add_round(wet_per_chunk, chunks(need, wet_per_chunk), true);  // forced uniform size
+    } else if (need <= cap(256)) {
+        add_round(256, chunks(need, 256), true);
+    } else if (need <= cap(512)) {
+        add_round(512, chunks(need, 512), true);
+    } else if (need <= cap(768) + cap(512)) {
+        const long first = need - cap(512) > 0 ? chunks(need - cap(512), 768) : 0;  // as many 768s as needed, then 512s
+        if (first > 0) add_round(768, first, false);
+        add_round(512, chunks(need - first * 768L * AO_WET_COST, 512), true);
+    } else {
+        const long body = need - cap(768) - cap(512);              // everything before the last two layers
+        const long n1024 = chunks(body, 1024);
+        add_round(1024, n1024, false);
+        const long left = need - n1024 * 1024L * AO_WET_COST;      // ≤ cap(768) + cap(512)
+        const long n768 = left - cap(512) > 0 ? chunks(left - cap(512), 768) : 0;
+        if (n768 > 0) add_round(768, n768, false);
+        const long rest = left - n768 * 768L * AO_WET_COST;
+        if (rest > 0)
+            add_round(512, chunks(rest, 512), true);
+        else
+            R.base[R.n] = total + AO_WET_COST;                      // the last round added absorbs the end
     }
     wet_per_chunk = largest;
     hipLaunchKernelGGL(chunk_begins_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums, R, d_begins,
@@ -215,10 +232,7 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
     const double* logt = tab + 4 * PSI_TABLE;
 
     const int wx = G.nx + 2 * G.ring;
-    // Workgroups are dealt to the 8 XCDs round-robin; give every XCD a contiguous band of chunks so that the
-    // rows shared by neighbouring chunks (v at j+1, u at i+1) meet in one L2.
-    const int nch = (int)gridDim.x, per = nch / 8, extra = nch - per * 8, x = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
-    const int chunk = nch < 16 ? (int)blockIdx.x : x * per + min(x, extra) + q;
+    const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
     const int range_end = chunk_begins[chunk + 1];
     int begin = chunk_begins[chunk], end = range_end;
     for (;;) {
