@@ -191,12 +191,12 @@ def main():
             pass
 
         # Second view of the dominant kernel: it is FP64-VALU-issue bound, not HBM bound.  VALU
-        # wave-instructions per launch come from the committed PMC pass (profiles/r01d_pmc_ao.json, same workload);
+        # wave-instructions per launch come from the committed PMC pass (profiles/r01_pmc_ao.json, same workload);
         # peak = one VALU instruction per SIMD per 4 cycles × 1024 SIMDs at the 2.4 GHz engine clock.
         valu = None
         try:
             kname = {"default": "ao_flux_fast_kernel<false, 0>", "corrected": "ao_flux_fast_kernel<true, 0>"}.get(a.flux_configuration)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_ao.json")))["kernels"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_ao.json")))["kernels"]
             if kname in pm and (nx, ny, world) == (1440, 560, 1):
                 n_inst = pm[kname]["SQ_INSTS_VALU"]
                 peak = 1024 * 2.4e9 / 4
@@ -204,7 +204,7 @@ def main():
                 valu = dict(bound="fp64-valu-issue", kernel="ao_flux_fast_kernel", achieved=ach / 1e9, peak=peak / 1e9,
                             unit="G wave-instructions/s", frac=ach / peak, valu_instructions_per_launch=n_inst,
                             lane_utilisation=pm[kname]["SQ_THREAD_CYCLES_VALU"] / (64.0 * pm[kname]["SQ_ACTIVE_INST_VALU"]),
-                            source="profiles/r01d_pmc_ao.json (rocprofv3 --pmc SQ_INSTS_VALU)")
+                            source="profiles/r01_pmc_ao.json (rocprofv3 --pmc SQ_INSTS_VALU)")
         except Exception:
             pass
 
