@@ -20,10 +20,11 @@ for label in ("default", "fixed0", "fixed12"):
     for _ in range(5): ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
     ms = ctx.time_stage(abi.STAGE_AO_FLUXES, 20, ocean=ocean, atmos=atmos, fluxes=fluxes)
     ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
-    n = 757 * 4 * 8
+    NWG = int(os.environ.get('NWG', '760'))
+    n = NWG * 4 * 8
     out = (C.c_ulonglong * n)()
     ctx.lib.cf_debug_phase_read(out, n)
-    st = np.array(out, dtype=np.float64).reshape(757 * 4, 8)[:, :4]
+    st = np.array(out, dtype=np.float64).reshape(NWG * 4, 8)[:, :4]
     d = np.diff(st, axis=1)            # per-wave durations (counters have per-XCD bases: only differences are meaningful)
     total = st[:, 3] - st[:, 0]
     tick = total.max() / (ms * 1e3)    # ticks per µs, assuming the longest-lived wave spans the kernel
@@ -33,15 +34,15 @@ for label in ("default", "fixed0", "fixed12"):
         print(f"   {name:40s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
     a_ = total / tick
     print(f"   {'wave lifetime':40s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
-    wg_life = (st[:, 3].reshape(757, 4).max(axis=1) - st[:, 0].reshape(757, 4).min(axis=1)) / tick
-    wave_b = d[:, 2].reshape(757, 4) / tick
+    wg_life = (st[:, 3].reshape(NWG, 4).max(axis=1) - st[:, 0].reshape(NWG, 4).min(axis=1)) / tick
+    wave_b = d[:, 2].reshape(NWG, 4) / tick
     print("   WG lifetime by XCD (blockIdx % 8): " + " ".join(f"{np.median(wg_life[x::8]):.0f}/{wg_life[x::8].max():.0f}" for x in range(8)))
-    order = np.arange(757)
-    for lo, hi in ((0, 96), (96, 384), (384, 672), (672, 757)):
+    order = np.arange(NWG)
+    for lo, hi in ((0, 256), (256, 512), (512, NWG)):
         sel = (order >= lo) & (order < hi)
         print(f"   blockIdx {lo:3d}-{hi:3d}: WG lifetime median {np.median(wg_life[sel]):.1f} max {wg_life[sel].max():.1f}; wave batch-phase spread within WG (max-min) median {np.median(wave_b[sel].max(axis=1)-wave_b[sel].min(axis=1)):.1f}")
     # start skew: when did each WG start relative to the earliest WG of its XCD
-    s0 = st[:, 0].reshape(757, 4).min(axis=1)
+    s0 = st[:, 0].reshape(NWG, 4).min(axis=1)
     for x in range(2):
         rel = (s0[x::8] - s0[x::8].min()) / tick
         print(f"   XCD {x}: WG start offsets median {np.median(rel):.1f} p90 {np.percentile(rel,90):.1f} max {rel.max():.1f} us")
