@@ -8,6 +8,8 @@ s = s.replace("namespace coflux {\n", "namespace coflux {\n__device__ unsigned l
 s = s.replace("    const int tid = threadIdx.x, lane = tid & 63;\n    stage_tables(tab, g_tab, tid, AO_BLOCK);", "    const int tid = threadIdx.x, lane = tid & 63;\n    STAMP(0);\n    if (lane == 0) { g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + 4] = __builtin_amdgcn_s_getreg(63492); g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + 5] = __builtin_amdgcn_s_getreg(63508); }\n    stage_tables(tab, g_tab, tid, AO_BLOCK);", 1)
 s = s.replace("        // ---- phase 1: classify", "        STAMP(1);\n        // ---- phase 1: classify", 1)
 s = s.replace("        // ---- phase 3: waves pull", "        STAMP(2);\n        // ---- phase 3: waves pull", 1)
+s = s.replace("        __syncthreads();\n        if (tid < 64) {  // exclusive scan", "        STAMP(6);\n        __syncthreads();\n        if (tid < 64) {  // exclusive scan", 1)
+s = s.replace("        const int nwet = counters[0];", "        STAMP(7);\n        const int nwet = counters[0];", 1)
 s = s.replace("        if (end >= range_end) break;", "        STAMP(3);\n        if (end >= range_end) break;", 1)
 s = s.replace("hipError_t launch_debug_eval(", "extern \"C\" int cf_debug_phase_read(unsigned long long* out, int n) {\n    hipDeviceSynchronize();\n    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * n);\n    return 0;\n}\n\nhipError_t launch_debug_eval(", 1)
 open('/tmp/_solver_phase.hip', 'w').write(s)

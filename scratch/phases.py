@@ -24,7 +24,8 @@ for label in ("default", "fixed0", "fixed12"):
     n = NWG * 4 * 8
     out = (C.c_ulonglong * n)()
     ctx.lib.cf_debug_phase_read(out, n)
-    st = np.array(out, dtype=np.float64).reshape(NWG * 4, 8)[:, :4]
+    raw = np.array(out, dtype=np.float64).reshape(NWG * 4, 8)
+    st = raw[:, :4]
     d = np.diff(st, axis=1)            # per-wave durations (counters have per-XCD bases: only differences are meaningful)
     total = st[:, 3] - st[:, 0]
     tick = total.max() / (ms * 1e3)    # ticks per µs, assuming the longest-lived wave spans the kernel
@@ -32,6 +33,9 @@ for label in ("default", "fixed0", "fixed12"):
     for q, name in enumerate(("stage tables + sync", "classify + sort", "batches (load/prologue/iterate/store)")):
         a_ = d[:, q] / tick
         print(f"   {name:40s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
+    for nm, v in (("  classify: own pass-1 loop", raw[:, 6] - raw[:, 1]), ("  classify: wait at sync + bin scan", raw[:, 7] - raw[:, 6]), ("  classify: scatter pass + sync", raw[:, 2] - raw[:, 7])):
+        a_ = v / tick
+        print(f"   {nm:40s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
     a_ = total / tick
     print(f"   {'wave lifetime':40s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
     wg_life = (st[:, 3].reshape(NWG, 4).max(axis=1) - st[:, 0].reshape(NWG, 4).min(axis=1)) / tick
