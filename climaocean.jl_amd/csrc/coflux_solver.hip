@@ -225,9 +225,23 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
     int* bin_start = hist + AO_BINS;
     DevParams* lp = reinterpret_cast<DevParams*>(smem + AO_PARAMS_OFFSET);
     const int tid = threadIdx.x, lane = tid & 63;
-    stage_tables(tab, g_tab, tid, AO_BLOCK);
+    // Parameters first (ordinary loads), then the 47 KB of tables as LDS-DMA (global_load_lds, 1 KB per wave
+    // instruction, no VGPR round trip).  The tables are first read in the batch phase, two barriers later, so
+    // the first barrier below deliberately does NOT drain the DMA: the classification's own loads run while the
+    // tables stream in.
     for (int n = tid; n < (int)(sizeof(DevParams) / sizeof(double)); n += AO_BLOCK)
         reinterpret_cast<double*>(lp)[n] = reinterpret_cast<const double*>(g_params)[n];
+    if (tid < 2) counters[tid] = 0;
+    if (tid < AO_BINS) hist[tid] = 0;
+    static_assert(TABLE_BYTES % 1024 == 0, "the table stage copies whole 1 KB pieces");
+    {
+        const char* gb = reinterpret_cast<const char*>(g_tab);
+        for (int c = tid >> 6; c < TABLE_BYTES / 1024; c += AO_BLOCK / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(smem + c * 1024), 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only: vmcnt / expcnt fields left at their maxima
+    __builtin_amdgcn_s_barrier();
     const DevParams& P = *lp;  // prologue-only parameters live in LDS, not in SGPRs
     const double* logt = tab + 4 * PSI_TABLE;
 
@@ -235,10 +249,14 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
     const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
     const int range_end = chunk_begins[chunk + 1];
     int begin = chunk_begins[chunk], end = range_end;
+    bool first_piece = true;
     for (;;) {
-        if (tid < 2) counters[tid] = 0;
-        if (tid < AO_BINS) hist[tid] = 0;
-        __syncthreads();
+        if (!first_piece) {
+            if (tid < 2) counters[tid] = 0;
+            if (tid < AO_BINS) hist[tid] = 0;
+            __syncthreads();
+        }
+        first_piece = false;
         // ---- phase 1: classify, zero land, histogram of the trip-count hints -----------------------
         // (the hint is the cell's iteration count in the previous call — fields evolve slowly from one
         // coupled step to the next; it only orders the list and cannot change any result)
@@ -283,6 +301,7 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
                 list[atomicAdd(&bin_start[bin], 1)] = idx;
             }
         }
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the table DMA has landed
         __syncthreads();
         // ---- phase 3: waves pull 64 wet cells at a time --------------------------------------------
         // (requesting the next batch's inputs before iterating the current one was tried: +20 VGPRs cost the
