@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../climaocean.jl_amd/csrc"
 python3 - <<'PY'
 s = open('coflux_solver.hip').read()
 s = s.replace("namespace coflux {\n", "namespace coflux {\n__device__ unsigned long long g_stamp[4096 * 8];\n#define STAMP(q) do { if (lane == 0) g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + (q)] = __builtin_readcyclecounter(); } while (0)\n", 1)
-s = s.replace("    const int tid = threadIdx.x, lane = tid & 63;\n    stage_tables(tab, g_tab, tid, AO_BLOCK);", "    const int tid = threadIdx.x, lane = tid & 63;\n    STAMP(0);\n    if (lane == 0) { g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + 4] = __builtin_amdgcn_s_getreg(63492); g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + 5] = __builtin_amdgcn_s_getreg(63508); }\n    stage_tables(tab, g_tab, tid, AO_BLOCK);", 1)
+s = s.replace("    const int tid = threadIdx.x, lane = tid & 63;\n", "    const int tid = threadIdx.x, lane = tid & 63;\n    STAMP(0);\n    if (lane == 0) { g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + 4] = __builtin_amdgcn_s_getreg(63492); g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + 5] = __builtin_amdgcn_s_getreg(63508); }\n", 1)
 s = s.replace("        // ---- phase 1: classify", "        STAMP(1);\n        // ---- phase 1: classify", 1)
 s = s.replace("        // ---- phase 3: waves pull", "        STAMP(2);\n        // ---- phase 3: waves pull", 1)
 s = s.replace("        __syncthreads();\n        if (tid < 64) {  // exclusive scan", "        STAMP(6);\n        __syncthreads();\n        if (tid < 64) {  // exclusive scan", 1)
