@@ -78,7 +78,7 @@ struct cf_ctx {
     int rank = 0, nranks = 1;
     // per-kernel event recorder (cf_profile_enable): 4 events per recorded update_state
     std::vector<hipEvent_t> prof_events;
-    int prof_capacity = 0, prof_count = 0;
+    int prof_capacity = 0, prof_count = 0, prof_stride = 1, prof_calls = 0;
 };
 
 static thread_local std::string g_error;
@@ -526,6 +526,10 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
         case CF_OPT_TRIP_HINTS:
             ctx->launch.d_hint = value ? ctx->d_hint : nullptr;
             return CF_OK;
+        case CF_OPT_PROFILE_STRIDE:
+            if (value < 1) return fail(ctx, CF_ERR_INVALID, "profile stride %d must be >= 1", value);
+            ctx->prof_stride = value;
+            return CF_OK;
         case CF_OPT_AO_CHUNK:
             if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024)
                 return fail(ctx, CF_ERR_INVALID, "solver chunk %d: wet cells per workgroup must be 0 (automatic), 256, 512, 768 or 1024", value);
@@ -696,7 +700,7 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     // saves the 40 B/cell re-read of the atmosphere state — ≈ 6 µs — but ties the FP64-issue-bound
     // solver to the interpolation's tile geometry and LDS footprint; measured slower, see DESIGN.md.)
     CHECK(ensure_chunk_table(ctx, ocean->mask));
-    const bool rec = ctx->prof_count < ctx->prof_capacity;
+    const bool rec = ctx->prof_count < ctx->prof_capacity && (ctx->prof_calls++ % ctx->prof_stride) == 0;
     hipEvent_t* ev = rec ? &ctx->prof_events[4 * (size_t)ctx->prof_count] : nullptr;
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
     HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
@@ -716,7 +720,7 @@ int cf_profile_enable(cf_ctx* ctx, int max_records) {
     if (!ctx || max_records < 0) return fail(ctx, CF_ERR_INVALID, "cf_profile_enable: bad arguments");
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     ctx->prof_events.clear();
-    ctx->prof_capacity = ctx->prof_count = 0;
+    ctx->prof_capacity = ctx->prof_count = ctx->prof_calls = 0;
     ctx->prof_events.resize(4 * (size_t)max_records);
     for (auto& e : ctx->prof_events) HIP_TRY(ctx, hipEventCreate(&e));
     ctx->prof_capacity = max_records;

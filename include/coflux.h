@@ -328,6 +328,8 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 #define CF_OPT_TRIP_HINTS 3       /* 1 (default): order each chunk's cells by their iteration count in the
                                      previous call so that the lanes of a wave finish together; scheduling only */
 #define CF_OPT_AO_CHUNK 4         /* wet cells per workgroup of the flux solver: 256, 512, 768 or 0 = automatic */
+#define CF_OPT_PROFILE_STRIDE 5   /* cf_profile_enable: bracket only every n-th cf_update_state with events (1); the event
+                                     records between the kernels cost ≈ 4 µs of stream time each               */
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path, LDS-tabulated ψ/log, ≤1e-12 of libm */
 #define CF_SOLVER_LIBM 1    /* same iteration on ocml's libm (slow; cross-check)                     */
 int cf_set_option(cf_ctx* ctx, int option, int value);
@@ -486,7 +488,7 @@ int cf_time_copy(cf_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int 
 /* Per-kernel timing INSIDE a caller's timed region: while enabled, cf_update_state brackets each of
  * its kernels with HIP events on the launch stream (no host sync).  cf_profile_read synchronises and
  * returns the average duration of `kernel` over the recorded steps.  cf_profile_enable(ctx, n)
- * (re)arms the recorder for n steps; 0 disables.                                                   */
+ * (re)arms the recorder for n records; 0 disables; CF_OPT_PROFILE_STRIDE samples every k-th step.                                                 */
 #define CF_KERNEL_INTERPOLATE 0
 #define CF_KERNEL_AO_FLUXES 1
 #define CF_KERNEL_NET_FLUXES 2
