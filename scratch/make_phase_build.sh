@@ -9,7 +9,7 @@ s = s.replace("    const int tid = threadIdx.x, lane = tid & 63;\n", "    const 
 s = s.replace("        // ---- phase 1: classify", "        STAMP(1);\n        // ---- phase 1: classify", 1)
 s = s.replace("        // ---- phase 3: waves pull", "        STAMP(2);\n        // ---- phase 3: waves pull", 1)
 s = s.replace("        __syncthreads();\n        if (tid < 64) {  // exclusive scan", "        STAMP(6);\n        __syncthreads();\n        if (tid < 64) {  // exclusive scan", 1)
-s = s.replace("        const int nwet = counters[0];", "        STAMP(7);\n        const int nwet = counters[0];", 1)
+s = s.replace("        const int nwet = counters[0];", "        const int nwet = counters[0];\n        if (lane == 0) g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + 7] = ((unsigned long long)(end - begin) << 32) | (unsigned)nwet;  /* RANGE_LEN */", 1)
 s = s.replace("        if (end >= range_end) break;", "        STAMP(3);\n        if (end >= range_end) break;", 1)
 s = s.replace("hipError_t launch_debug_eval(", "extern \"C\" int cf_debug_phase_read(unsigned long long* out, int n) {\n    hipDeviceSynchronize();\n    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * n);\n    return 0;\n}\n\nhipError_t launch_debug_eval(", 1)
 open('/tmp/_solver_phase.hip', 'w').write(s)
