@@ -147,7 +147,7 @@ class InterpWeights(C.Structure):
 # Every symbol include/coflux.h declares (tests check they are all exported).
 EXPORTED_SYMBOLS = (
     "cf_version", "cf_default_flux_params", "cf_create", "cf_destroy", "cf_last_error",
-    "cf_set_flux_params", "cf_set_stream", "cf_set_option", "cf_debug_eval", "cf_sync",
+    "cf_set_flux_params", "cf_set_stream", "cf_set_option", "cf_debug_eval", "cf_debug_chunk_plan", "cf_sync",
     "cf_device_alloc", "cf_device_free", "cf_h2d", "cf_d2h",
     "cf_interpolate_atmosphere_state", "cf_compute_atmosphere_ocean_fluxes",
     "cf_compute_net_ocean_fluxes", "cf_update_state", "cf_normalize_salinity_flux",
@@ -192,6 +192,7 @@ def load_library(path=None):
     lib.cf_set_stream.argtypes = [vp, vp]
     lib.cf_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.cf_debug_eval.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    lib.cf_debug_chunk_plan.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     lib.cf_sync.argtypes = [vp]
     lib.cf_device_alloc.argtypes = [vp, C.c_size_t]
     lib.cf_device_alloc.restype = vp

@@ -134,6 +134,57 @@ __global__ __launch_bounds__(256) void chunk_begins_kernel(const DevParams* __re
     }
 }
 
+// Layers.  Workgroups are dealt out in blockIdx order, one per CU before a CU gets its second, so workgroup b
+// is the (b / CUs)-th arrival on its CU — and the SIMD arbiter serves the OLDEST wave first (s_setprio does not
+// change that: measured).  With three equal workgroups per CU the first finishes at 60 % of the kernel and the
+// third runs the last third alone, too few waves to keep the FP64 pipe busy (lifetimes 58 / 73 / 92 µs at
+// equal work).  So the work is handed out in proportion to the share each arrival gets: 1024, 768 and 512
+// wet cells for the last three layers (all multiples of 256 = whole batches for four waves), 1024 for every
+// layer before them (on larger surfaces a new workgroup starts whenever the oldest one retires and the
+// pipeline staggers itself; only the tail needs shaping).  Pure host arithmetic (tests/test_abi.py checks it
+// without a GPU through cf_debug_chunk_plan); returns the largest chunk size used.
+int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkRounds* out) {
+    const int layer = cu_count > 0 ? cu_count : 256;
+    ChunkRounds R{};
+    int next_id = 0, largest = 0;
+    R.base[0] = 0;
+    auto add_round = [&](int w, long count, bool last) {
+        if (count <= 0) return;
+        const int cost = w * AO_WET_COST;
+        R.cost[R.n] = cost;
+        R.first[R.n] = next_id;
+        R.base[R.n + 1] = last ? (int)total + AO_WET_COST : R.base[R.n] + (int)(count * cost);
+        next_id += (int)count;
+        largest = w > largest ? w : largest;
+        ++R.n;
+    };
+    auto cap = [&](int w) { return (long)layer * w * AO_WET_COST; };
+    auto chunks = [&](long cost_units, int w) {
+        return cost_units <= 0 ? 0L : (cost_units + (long)w * AO_WET_COST - 1) / ((long)w * AO_WET_COST);
+    };
+    const long need = total > 0 ? total : 1;
+    if (forced_wet_per_chunk > 0) {
+        add_round(forced_wet_per_chunk, chunks(need, forced_wet_per_chunk), true);  // forced uniform size
+    } else if (need <= cap(256)) {
+        add_round(256, chunks(need, 256), true);
+    } else if (need <= cap(512)) {
+        add_round(512, chunks(need, 512), true);
+    } else {
+        // 1024s for everything before the last two layers (none on a surface that fits three layers), then as
+        // many 768s as still needed, then 512s
+        const long body = need - cap(768) - cap(512);
+        const long n1024 = chunks(body, 1024);
+        add_round(1024, n1024, false);
+        const long left = need - n1024 * 1024L * AO_WET_COST;
+        const long n768 = chunks(left - cap(512), 768);
+        add_round(768, n768, false);
+        add_round(512, chunks(left - n768 * 768L * AO_WET_COST, 512), false);
+        R.base[R.n] = (int)total + AO_WET_COST;  // the last round added absorbs the end
+    }
+    *out = R;
+    return largest;
+}
+
 hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
                              int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
                              int* nchunks_out) {
@@ -145,53 +196,8 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
     hipError_t e = hipMemcpyAsync(&total, d_sums + nblocks, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    // Layers.  Workgroups are dealt out in blockIdx order, one per CU before a CU gets its second, so workgroup b
-    // is the (b / CUs)-th arrival on its CU — and the SIMD arbiter serves the OLDEST wave first (s_setprio does not
-    // change that: measured).  With three equal workgroups per CU the first finishes at 60 % of the kernel and the
-    // third runs the last third alone, too few waves to keep the FP64 pipe busy (lifetimes 58 / 73 / 92 µs at
-    // equal work).  So the work is handed out in proportion to the share each arrival gets: 1024, 768 and 512
-    // wet cells for the last three layers (all multiples of 256 = whole batches for four waves), 1024 for every
-    // layer before them (on larger surfaces a new workgroup starts whenever the oldest one retires and the
-    // pipeline staggers itself; only the tail needs shaping).
-    const int layer = cu_count > 0 ? cu_count : 256;
     ChunkRounds R{};
-    int next_id = 0, largest = 0;
-    R.base[0] = 0;
-    auto add_round = [&](int w, long count, bool last) {
-        const int cost = w * AO_WET_COST;
-        R.cost[R.n] = cost;
-        R.first[R.n] = next_id;
-        R.base[R.n + 1] = last ? total + AO_WET_COST : R.base[R.n] + (int)(count * cost);
-        next_id += (int)count;
-        largest = w > largest ? w : largest;
-        ++R.n;
-    };
-    auto cap = [&](int w) { return (long)layer * w * AO_WET_COST; };
-    auto chunks = [&](long cost_units, int w) { return (cost_units + (long)w * AO_WET_COST - 1) / ((long)w * AO_WET_COST); };
-    long need = total;
-    if (wet_per_chunk > 0) {
-        add_round(wet_per_chunk, chunks(need, wet_per_chunk), true);  // forced uniform size
-    } else if (need <= cap(256)) {
-        add_round(256, chunks(need, 256), true);
-    } else if (need <= cap(512)) {
-        add_round(512, chunks(need, 512), true);
-    } else if (need <= cap(768) + cap(512)) {
-        const long first = need - cap(512) > 0 ? chunks(need - cap(512), 768) : 0;  // as many 768s as needed, then 512s
-        if (first > 0) add_round(768, first, false);
-        add_round(512, chunks(need - first * 768L * AO_WET_COST, 512), true);
-    } else {
-        const long body = need - cap(768) - cap(512);              // everything before the last two layers
-        const long n1024 = chunks(body, 1024);
-        add_round(1024, n1024, false);
-        const long left = need - n1024 * 1024L * AO_WET_COST;      // ≤ cap(768) + cap(512)
-        const long n768 = left - cap(512) > 0 ? chunks(left - cap(512), 768) : 0;
-        if (n768 > 0) add_round(768, n768, false);
-        const long rest = left - n768 * 768L * AO_WET_COST;
-        if (rest > 0)
-            add_round(512, chunks(rest, 512), true);
-        else
-            R.base[R.n] = total + AO_WET_COST;                      // the last round added absorbs the end
-    }
+    const int largest = plan_chunk_rounds(total, cu_count, wet_per_chunk, &R);
     wet_per_chunk = largest;
     hipLaunchKernelGGL(chunk_begins_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums, R, d_begins,
                        d_meta);
@@ -409,6 +415,21 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     else
         launch_ao_spec<false>(st, grid, L, C, G, O, E, F);
     return hipGetLastError();
+}
+
+// self-test hook: the chunk plan for a given total cost (tests/test_abi.py, no GPU needed).
+// out[0] = rounds, then per round: wet cells per chunk, number of chunks
+extern "C" int cf_debug_chunk_plan(long long total_cost, int cu_count, int forced_wet_per_chunk, int* out, int capacity) {
+    ChunkRounds R{};
+    plan_chunk_rounds((long)total_cost, cu_count, forced_wet_per_chunk, &R);
+    if (!out || capacity < 1 + 2 * R.n) return -1;
+    out[0] = R.n;
+    for (int r = 0; r < R.n; ++r) {
+        out[1 + 2 * r] = R.cost[r] / AO_WET_COST;
+        const long span = (long)R.base[r + 1] - R.base[r];
+        out[2 + 2 * r] = (int)((span + R.cost[r] - 1) / R.cost[r]);
+    }
+    return AO_WET_COST;
 }
 
 hipError_t launch_debug_eval(hipStream_t st, const LaunchCfg& L, int fn, int n, const double* x, double* y) {

@@ -336,6 +336,11 @@ int cf_set_option(cf_ctx* ctx, int option, int value);
 /* Self-test hook: y[k] = f(x[k]) with the device primitives the solver uses
  * (f: 0 log, 1 exp, 2 cbrt, 3 sqrt, 4 1/x, 5 ψ_m(ζ), 6 ψ_h(ζ)); d_x, d_y device pointers.        */
 int cf_debug_eval(cf_ctx* ctx, int function, int n, const double* d_x, double* d_y);
+/* Self-test hook (host arithmetic only, works without a GPU): the solver's chunk plan for a surface of total
+ * cost `total_cost` (wet cell = the returned cost unit, land cell = 1) on `cu_count` compute units.
+ * out[0] = number of rounds, then per round (wet cells per chunk, number of chunks).  Returns the wet-cell cost
+ * unit, or −1 if `capacity` ints are too few. */
+int cf_debug_chunk_plan(long long total_cost, int cu_count, int forced_wet_per_chunk, int* out, int capacity);
 int cf_sync(cf_ctx* ctx);
 
 /* Device memory for callers that cannot own HIP memory themselves (Julia without AMDGPU.jl). */
