@@ -173,12 +173,12 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
         // 1024s for everything before the last two layers (none on a surface that fits three layers), then as
         // many 768s as still needed, then 512s
         const long body = need - cap(768) - cap(512);
-        const long n1024 = chunks(body, 1024);
+        const long n1024 = body > 0 ? (body + cap(1024) - 1) / cap(1024) * layer : 0;  // whole layers of 1024s
         add_round(1024, n1024, false);
         const long left = need - n1024 * 1024L * AO_WET_COST;
-        const long n768 = chunks(left - cap(512), 768);
+        const long n768 = left > cap(768) ? layer : chunks(left, 768);                 // a whole layer of 768s if needed
         add_round(768, n768, false);
-        add_round(512, chunks(left - n768 * 768L * AO_WET_COST, 512), false);
+        add_round(512, chunks(left - n768 * 768L * AO_WET_COST, 512), false);          // the youngest layer takes the rest
         R.base[R.n] = (int)total + AO_WET_COST;  // the last round added absorbs the end
     }
     *out = R;
