@@ -1,0 +1,99 @@
+// coflux_ctx.hpp — the context object behind the C ABI and the error plumbing shared by its translation units
+// (coflux_abi.cpp, coflux_window.cpp).  Internal: nothing here crosses the ABI.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/coflux.h"
+#include "coflux_fast.hpp"
+#include "coflux_kernels.h"
+#include "coflux_tables.h"
+
+using namespace coflux;
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+};
+
+struct cf_ctx {
+    int device = 0;
+    GridDesc grid{};
+    cf_flux_params params{};
+    DevParams dev{};
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    LoopParams fast{};
+    DevParams* d_params = nullptr;
+    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, 0, 256, nullptr, nullptr, nullptr, nullptr, 0};
+    uint8_t* d_hint = nullptr;
+    // cost-balanced chunk table of the solver, rebuilt when the wet mask (pointer / kind / surface z) changes
+    int* d_chunk_sums = nullptr;
+    int* d_chunk_begins = nullptr;
+    int* d_chunk_meta = nullptr;
+    const void* chunk_mask = nullptr;
+    int chunk_mask_kind = -1;
+    double chunk_z_surface = 0.0;
+    int chunk_wet = 0;      // wet cells per chunk actually used
+    bool chunk_valid = false;
+    double* d_reduce = nullptr;  // [2·SALINITY_PARTIAL_BLOCKS partial sums][2 totals]
+    // atmosphere–sea-ice formulation (cf_set_sea_ice_formulation)
+    bool ice_ready = false;
+    cf_flux_params ice_params{};
+    cf_sea_ice_params ice_props{};
+    DevParams ice_dev{};
+    LoopParams ice_loop{};
+    IceParams ice_kernel{};
+    double* d_ice_tables = nullptr;
+    DevParams* d_ice_params = nullptr;
+    // halo rows travel on their own stream so that they overlap the interpolation kernel, which
+    // does not read the ocean state; consumers of the ocean fields wait on ev_comm_done
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_main_idle = nullptr, ev_comm_done = nullptr;
+    bool comm_pending = false;
+    double* d_tables = nullptr;
+    int tables_kind = -1;
+    std::string error;
+    // RCCL
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    // per-kernel event recorder (cf_profile_enable): 4 events per recorded update_state
+    std::vector<hipEvent_t> prof_events;
+    int prof_capacity = 0, prof_count = 0, prof_stride = 1, prof_calls = 0;
+};
+
+// sets the thread-local and the context's last-error text and returns `code`
+int cf_fail(cf_ctx* ctx, int code, const char* fmt, ...);
+#define fail cf_fail
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(ctx, CF_ERR_HIP, "%s:%d: %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define CHECK(call)            \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_ != CF_OK) return rc_; \
+    } while (0)
