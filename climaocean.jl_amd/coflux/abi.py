@@ -152,7 +152,7 @@ EXPORTED_SYMBOLS = (
     "cf_interpolate_atmosphere_state", "cf_compute_atmosphere_ocean_fluxes",
     "cf_compute_net_ocean_fluxes", "cf_update_state", "cf_normalize_salinity_flux",
     "cf_default_sea_ice_params", "cf_set_sea_ice_formulation", "cf_compute_atmosphere_sea_ice_fluxes",
-    "cf_compute_net_sea_ice_fluxes",
+    "cf_compute_net_sea_ice_fluxes", "cf_update_state_sea_ice",
     "cf_time_stage", "cf_time_copy", "cf_profile_enable", "cf_profile_read",
     "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
@@ -218,6 +218,10 @@ def load_library(path=None):
     lib.cf_compute_net_sea_ice_fluxes.argtypes = [
         vp, C.POINTER(SeaIceState), C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes),
         vp, vp, C.POINTER(NetSeaIceFluxes)]
+    lib.cf_update_state_sea_ice.argtypes = [
+        vp, C.POINTER(AtmosSource), C.POINTER(InterpWeights), C.POINTER(OceanSurface), C.POINTER(ExchangeFields),
+        C.POINTER(InterfaceFluxes), C.POINTER(SeaIceFields), C.POINTER(NetOceanFluxes), C.POINTER(SeaIceState),
+        C.POINTER(InterfaceFluxes), vp, vp, C.POINTER(NetSeaIceFluxes)]
     lib.cf_time_stage.argtypes = [
         vp, C.c_int, C.c_int, C.POINTER(AtmosSource), C.POINTER(InterpWeights),
         C.POINTER(OceanSurface), C.POINTER(ExchangeFields), C.POINTER(InterfaceFluxes),

@@ -342,19 +342,21 @@ def update_state(model):
     itf, atm = model.interfaces, model.atmosphere
     src, n1, n2, frac = atm.source(itf.context, model.clock.time)
     ice = model.sea_ice.fields() if model.sea_ice is not None else None
+    if itf.atmosphere_sea_ice_interface is not None:
+        # the ocean path, then compute_atmosphere_sea_ice_fluxes! + compute_net_sea_ice_fluxes! in one ABI call; the
+        # skin temperature found by the iteration becomes the sea ice's top surface temperature (and the next step's
+        # first guess)
+        si, ai = model.sea_ice, itf.atmosphere_sea_ice_interface._fields
+        itf.context.update_state_sea_ice(src, itf.weights, model.ocean.surface_state(), itf.exchange_atmosphere_state,
+                                         itf.atmosphere_ocean_interface._fields, itf.net_fluxes._ocean_fields, ice,
+                                         si.surface_state(), ai, itf.net_fluxes._sea_ice_fields,
+                                         frazil_heat=si.frazil_heat, interface_heat=si.interface_heat,
+                                         level1=n1, level2=n2, time_fraction=frac)
+        si.top_surface_temperature.copy_(ai["temperature"])
+        return
     itf.context.update_state(src, itf.weights, model.ocean.surface_state(), itf.exchange_atmosphere_state,
                              itf.atmosphere_ocean_interface._fields, itf.net_fluxes._ocean_fields, ice=ice,
                              level1=n1, level2=n2, time_fraction=frac)
-    if itf.atmosphere_sea_ice_interface is not None:
-        # compute_atmosphere_sea_ice_fluxes! + compute_net_sea_ice_fluxes!: the skin temperature found by the
-        # iteration becomes the sea ice's top surface temperature (and the next step's first guess)
-        si, ai = model.sea_ice, itf.atmosphere_sea_ice_interface._fields
-        ocean_state = model.ocean.surface_state()
-        itf.context.compute_atmosphere_sea_ice_fluxes(si.surface_state(), ocean_state, itf.exchange_atmosphere_state, ai)
-        itf.context.compute_net_sea_ice_fluxes(si.surface_state(), ocean_state, itf.exchange_atmosphere_state, ai,
-                                               itf.net_fluxes._sea_ice_fields, frazil_heat=si.frazil_heat,
-                                               interface_heat=si.interface_heat)
-        si.top_surface_temperature.copy_(ai["temperature"])
 
 
 def time_step(model, dt):

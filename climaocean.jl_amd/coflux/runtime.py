@@ -210,6 +210,23 @@ class FluxContext:
                                              C.byref(f), C.byref(i) if i is not None else None, C.byref(n)),
                     "cf_update_state")
 
+    def update_state_sea_ice(self, src, weights, ocean, atmos, fluxes, net, ice, ice_state, ai_fluxes, net_ice,
+                             frazil_heat=None, interface_heat=None, level1=0, level2=1, time_fraction=0.0):
+        """update_state! of a model with sea ice: the ocean path, then the atmosphere–sea-ice interface and the
+        net sea-ice fluxes (cf_update_state_sea_ice)."""
+        s = self.source_struct(src, level1, level2, time_fraction)
+        w = self.weights_struct(weights)
+        o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
+        i = self.ice_struct(ice)
+        n = self.net_struct(net)
+        st = self._struct(abi.SeaIceState, ice_state, ("concentration", "thickness", "top_temperature", "u", "v", "albedo"))
+        af = self.fluxes_struct(ai_fluxes)
+        ni = self._struct(abi.NetSeaIceFluxes, net_ice, ("top_heat", "bottom_heat"))
+        self._check(self.lib.cf_update_state_sea_ice(
+            self._h, C.byref(s), C.byref(w), C.byref(o), C.byref(e), C.byref(f), C.byref(i) if i is not None else None,
+            C.byref(n), C.byref(st), C.byref(af), frazil_heat.data_ptr() if frazil_heat is not None else None,
+            interface_heat.data_ptr() if interface_heat is not None else None, C.byref(ni)), "cf_update_state_sea_ice")
+
     def time_stage(self, stage, launches, *, src=None, weights=None, ocean=None, atmos=None, fluxes=None,
                    net=None, ice=None, level1=0, level2=1, time_fraction=0.0):
         """Average ms per launch of one stage, measured with HIP events on the launch stream."""

@@ -840,6 +840,19 @@ int cf_compute_net_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, cons
     return CF_OK;
 }
 
+int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
+                            const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
+                            const cf_interface_fluxes* ao_fluxes, const cf_sea_ice_fields* ice_partition,
+                            const cf_net_ocean_fluxes* net, const cf_sea_ice_state* ice_state,
+                            const cf_interface_fluxes* ai_fluxes, const double* frazil_heat,
+                            const double* interface_heat, const cf_net_sea_ice_fluxes* net_ice) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
+    CHECK(cf_update_state(ctx, src, w, ocean, atmos, ao_fluxes, ice_partition, net));
+    CHECK(cf_compute_atmosphere_sea_ice_fluxes(ctx, ice_state, ocean, atmos, ai_fluxes));
+    return cf_compute_net_sea_ice_fluxes(ctx, ice_state, ocean, atmos, ai_fluxes, frazil_heat, interface_heat, net_ice);
+}
+
 int cf_normalize_salinity_flux(cf_ctx* ctx, double* d_flux, const double* d_additional, const double* d_area,
                                const void* d_mask, double* d_mean_out) {
     if (!ctx || !d_flux) return fail(ctx, CF_ERR_INVALID, "cf_normalize_salinity_flux: bad arguments");

@@ -192,6 +192,16 @@ compute_net_sea_ice_fluxes!(b::CoFluxBackend, ice::CfSeaIceState, ocean::CfOcean
                        (Ptr{Cvoid}, Ref{CfSeaIceState}, Ref{CfOceanSurface}, Ref{CfExchangeFields}, Ref{CfInterfaceFluxes},
                         Ptr{Float64}, Ptr{Float64}, Ref{CfNetSeaIceFluxes}), b.ctx, ice, ocean, atmos, ai, frazil, interface, out))
 
+# update_state!(coupled_model) with sea ice: ocean path + atmosphere–sea-ice interface + net sea-ice fluxes, five launches
+update_state_sea_ice!(b::CoFluxBackend, src::CfAtmosSource, w::CfInterpWeights, ocean::CfOceanSurface, atmos::CfExchangeFields,
+                      ao::CfInterfaceFluxes, partition::CfSeaIceFields, net::CfNetOceanFluxes, ice::CfSeaIceState,
+                      ai::CfInterfaceFluxes, frazil::Ptr{Float64}, interface::Ptr{Float64}, net_ice::CfNetSeaIceFluxes) =
+    check(b.ctx, ccall((:cf_update_state_sea_ice, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfAtmosSource}, Ref{CfInterpWeights}, Ref{CfOceanSurface}, Ref{CfExchangeFields},
+                        Ref{CfInterfaceFluxes}, Ref{CfSeaIceFields}, Ref{CfNetOceanFluxes}, Ref{CfSeaIceState},
+                        Ref{CfInterfaceFluxes}, Ptr{Float64}, Ptr{Float64}, Ref{CfNetSeaIceFluxes}),
+                       b.ctx, src, w, ocean, atmos, ao, partition, net, ice, ai, frazil, interface, net_ice))
+
 # ---- JRA55 snapshot window in HBM: JRA55PrescribedAtmosphere(arch; time_indices_in_memory, prefetch) ---------
 mutable struct CoFluxWindow
     ptr::Ptr{Cvoid}

@@ -463,6 +463,17 @@ int cf_compute_net_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, cons
                                   const double* frazil_heat, const double* interface_heat,
                                   const cf_net_sea_ice_fluxes* out);
 
+/* update_state!(coupled_model) of a model WITH sea ice (BASELINE config 3; omip_simulation.jl:139-163): cf_update_state
+ * followed by cf_compute_atmosphere_sea_ice_fluxes and cf_compute_net_sea_ice_fluxes on the same stream — five
+ * launches, no host synchronisation.  `ice_partition` (ℵ, ice–ocean fluxes) feeds the ocean partition, `ice_state`
+ * the interface solve; `ai_fluxes->temperature` receives the new skin temperature. */
+int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
+                            const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
+                            const cf_interface_fluxes* ao_fluxes, const cf_sea_ice_fields* ice_partition,
+                            const cf_net_ocean_fluxes* net, const cf_sea_ice_state* ice_state,
+                            const cf_interface_fluxes* ai_fluxes, const double* frazil_heat,
+                            const double* interface_heat, const cf_net_sea_ice_fluxes* net_ice);
+
 /* NormalizeSalinity callback (src/OMIPConfigurations/omip_simulation.jl:182-220, added at :385-388):
  * subtract the global, area-weighted mean over wet cells of (salinity flux [+ additional flux]) from
  * the salinity-flux field — `compute!(mean_total); parent(flux_field) .-= mean_total`, so the constant
