@@ -171,10 +171,13 @@ class JRA55PrescribedAtmosphere:
     def _wrap(self, n):
         return n % self.n_levels if self.cyclic else min(max(n, 0), self.n_levels - 1)
 
-    def _read_into_staging(self, n):
-        slot = n % self.n_slots
+    def _read_into_staging(self, k):
+        """Snapshot COUNTER k (monotone in time, not wrapped) → the provider's record index wrap(k), staged in slot
+        k mod n_slots.  Slots follow the counter, not the record index: at the end of a repeat year the indices
+        jump from total−1 to 0, and two consecutive snapshots must never share a slot."""
+        slot = k % self.n_slots
         self.window.wait_slot(slot)          # the previous copy out of these pinned buffers has finished
-        snap = self.provider(n)
+        snap = self.provider(self._wrap(k))
         for v in abi.JRA55_VARIABLES:
             np.copyto(self.window.host_view(slot, v), snap[v], casting="same_kind")
         return slot
@@ -187,32 +190,39 @@ class JRA55PrescribedAtmosphere:
         if self.provider is None:
             return self.data, n1, n2, frac
         if self.window is None:
-            from .runtime import SnapshotWindow
-            self.window = SnapshotWindow(context, self.source_size[0], self.source_size[1], self.n_slots)
-            if self.prefetch:
+            from . import runtime
+            self.window = runtime.SnapshotWindow(context, self.source_size[0], self.source_size[1], self.n_slots)
+            if self.prefetch and self.n_slots > 2:
                 from concurrent.futures import ThreadPoolExecutor
                 self._reader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="jra55-prefetch")
         w = self.window
-        for n in (n1, n2):
-            if w.find(n) >= 0:
+        base = int(np.floor(t / self.time_interval))
+        if self.cyclic:
+            k1, k2 = base, base + 1
+        else:   # clamped record: the counters stop at its ends
+            k1 = min(max(base, 0), self.n_levels - 1)
+            k2 = min(max(base + 1, 0), self.n_levels - 1)
+        for k in (k1, k2):
+            if w.find(k) >= 0:
                 continue
-            fut = self._pending.pop(n, None)
-            slot = fut.result() if fut is not None else self._read_into_staging(n)
-            w.commit(slot, n)
-        for n, fut in list(self._pending.items()):      # prefetches that have landed in pinned memory
+            fut = self._pending.pop(k, None)
+            slot = fut.result() if fut is not None else self._read_into_staging(k)
+            w.commit(slot, k)
+        for k, fut in list(self._pending.items()):      # prefetches that have landed in pinned memory
             if fut.done():
-                w.commit(fut.result(), n)
-                del self._pending[n]
+                w.commit(fut.result(), k)
+                del self._pending[k]
         if self._reader is not None:
-            base = int(np.floor(t / self.time_interval))
-            for ahead in range(2, self.n_slots):        # slots not holding n₁ or n₂
-                n = self._wrap(base + ahead)
-                if n in (n1, n2) or w.find(n) >= 0 or n in self._pending:
+            for ahead in range(2, self.n_slots):        # the slots that hold neither k₁ nor k₂
+                k = base + ahead
+                if not self.cyclic and not (0 <= k < self.n_levels):
                     continue
-                if any((m % self.n_slots) == (n % self.n_slots) for m in list(self._pending) + [n1, n2]):
+                if k in (k1, k2) or w.find(k) >= 0 or k in self._pending:
                     continue
-                self._pending[n] = self._reader.submit(self._read_into_staging, n)
-        return w.source(n1, n2, frac), n1, n2, frac
+                if any((m % self.n_slots) == (k % self.n_slots) for m in list(self._pending) + [k1, k2]):
+                    continue
+                self._pending[k] = self._reader.submit(self._read_into_staging, k)
+        return w.source(k1, k2, frac), n1, n2, frac
 
     def close(self):
         if self._reader is not None:

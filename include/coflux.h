@@ -384,8 +384,9 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
 /* ------------------------------------------------------------------------------------------
  * JRA55 snapshot window in HBM: JRA55PrescribedAtmosphere(arch; time_indices_in_memory = n,
  * prefetch = true) of atmosphere.jl:20-29 / launch.sh:86-93 — `n_slots` 3-hourly snapshots of the nine
- * variables resident on the device, refilled from host memory while the model steps.  Snapshot `t` lives in
- * slot t mod n_slots.  Uploads run on the window's own copy stream out of pinned staging buffers and are
+ * variables resident on the device, refilled from host memory while the model steps.  `time_index` is the
+ * monotone snapshot COUNTER ⌊t/Δt⌋ (not the index inside a repeat-year record, which jumps back at the wrap and
+ * would put two consecutive snapshots into one slot); snapshot counter t lives in slot t mod n_slots.  Uploads run on the window's own copy stream out of pinned staging buffers and are
  * ordered against the context's compute stream with events in both directions: a slot is not overwritten
  * before the interpolations already queued have read it, and an interpolation does not start before the two
  * snapshots it brackets have landed.  Reading the files (NetCDF) stays on the host side of this boundary.

@@ -7,6 +7,7 @@ import torch
 
 import oracle as orc
 import util
+from coflux import abi
 from coflux import interface_computations as ic
 from coflux import models as cm
 from coflux import synthetic as syn
@@ -129,3 +130,65 @@ def test_config3_sea_ice_coupling_through_the_model_api():
     Ts2 = sea_ice.top_surface_temperature.cpu().numpy()
     assert np.isfinite(Ts2).all() and np.all(W(Ts2)[W(state["mask"]) != 0] <= 0.0)
     assert model.clock.iteration == 1
+
+
+class _FakeWindow:
+    """Host-side stand-in for runtime.SnapshotWindow: records what the sliding-window logic asks for."""
+
+    def __init__(self, ctx, nsx, nsy, n_slots):
+        self.n_slots, self.nsx, self.nsy = n_slots, nsx, nsy
+        self.slots = [None] * n_slots          # committed snapshot per slot
+        self.staging = [dict() for _ in range(n_slots)]
+        self.log = []
+
+    def host_view(self, slot, var):
+        return self.staging[slot].setdefault(var, np.zeros((self.nsy, self.nsx), np.float32))
+
+    def wait_slot(self, slot):
+        self.log.append(("wait", slot))
+
+    def commit(self, slot, n):
+        assert slot == n % self.n_slots
+        self.slots[slot] = (n, float(self.staging[slot]["tas"][0, 0]))
+        self.log.append(("commit", slot, n))
+
+
+    def find(self, n):
+        s = self.slots[n % self.n_slots]
+        return n % self.n_slots if s is not None and s[0] == n else -1
+
+    def source(self, k1, k2, frac):
+        assert self.find(k1) >= 0 and self.find(k2) >= 0, (k1, k2, self.slots)
+        # the staged data really is the record asked for (the provider writes its record index into tas)
+        return ("src", self.slots[k1 % self.n_slots][1], self.slots[k2 % self.n_slots][1], frac)
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+@pytest.mark.parametrize("n_slots", [2, 3, 5])
+def test_sliding_window_bookkeeping_without_a_gpu(monkeypatch, prefetch, n_slots):
+    """JRA55PrescribedAtmosphere(provider=…): the two bracketing snapshots are always resident when asked for, a slot
+    is never refilled while it holds one of them, the repeat-year record wraps, and prefetching reads ahead."""
+    from coflux import runtime
+    monkeypatch.setattr(runtime, "SnapshotWindow", _FakeWindow)
+    total, reads = 7, []
+
+    def provider(n):
+        reads.append(n)
+        return {v: np.full((4, 8), float(n), np.float32) for v in abi.JRA55_VARIABLES}
+
+    atm = cm.JRA55PrescribedAtmosphere(provider=provider, total_snapshots=total, time_indices_in_memory=n_slots,
+                                       prefetch=prefetch, source_size=(8, 4))
+    dt, t = 20 * cm.minutes, 0.0
+    for step in range(120):                       # 40 h: wraps the 7-snapshot record almost twice
+        src, n1, n2, frac = atm.source(None, t)
+        n = int(np.floor(t / (3 * 3600)))
+        assert (n1, n2) == (n % total, (n + 1) % total) and abs(frac - (t / (3 * 3600) - n)) < 1e-12
+        assert src == ("src", float(n1), float(n2), frac)
+        t += dt
+    assert set(reads) == set(range(total))
+    assert len(reads) <= 16 + (n_slots if prefetch else 0)        # ≈ one read per 3-hourly snapshot crossed, no thrashing
+    assert (atm._reader is not None) == (prefetch and n_slots > 2)
+    atm.close()

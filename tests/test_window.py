@@ -61,7 +61,7 @@ def test_sliding_window_atmosphere_equals_in_memory_atmosphere(prefetch):
     """README recipe with a provider-backed window of 3 snapshots vs all 6 snapshots resident: every step's
     boundary conditions are bitwise identical (same kernels, same data, different residency)."""
     nx, ny, nz, h = 90, 40, 10, 3
-    snaps = syn.jra55_snapshots(6)
+    snaps = syn.jra55_snapshots(7)          # 7 is no multiple of the 3 slots: the wrap 6 → 0 must not collide
     state = syn.ocean_state(nx, ny, h, h)
     reads = []
 
@@ -77,17 +77,17 @@ def test_sliding_window_atmosphere_equals_in_memory_atmosphere(prefetch):
         return ocean, cm.OceanSeaIceModel(ocean, atmosphere=atmosphere)
 
     ocean_a, model_a = build(cm.JRA55PrescribedAtmosphere(snaps))
-    windowed = cm.JRA55PrescribedAtmosphere(provider=provider, total_snapshots=6, time_indices_in_memory=3,
+    windowed = cm.JRA55PrescribedAtmosphere(provider=provider, total_snapshots=7, time_indices_in_memory=3,
                                             prefetch=prefetch)
     ocean_b, model_b = build(windowed)
-    for _ in range(60):                                    # 60 × 20 min = 20 h: snapshots 0…7 → wraps the repeat "year"
+    for _ in range(72):                                    # 72 × 20 min = 24 h: 8 snapshot intervals → wraps the repeat "year"
         cm.time_step(model_a, 20 * cm.minutes)
         cm.time_step(model_b, 20 * cm.minutes)
         for name in ("u", "v", "T", "S"):
             a = getattr(ocean_a.model.top_boundary_conditions, name)
             b = getattr(ocean_b.model.top_boundary_conditions, name)
             assert torch.equal(a, b), (model_a.clock.iteration, name)
-    assert set(reads) == set(range(6)) and len(reads) >= 8   # wrapped: 0 and 1 were read again
+    assert set(reads) == set(range(7)) and len(reads) >= 9   # wrapped: 0 and 1 were read again
     if prefetch:
         assert windowed._reader is not None
     windowed.close()
