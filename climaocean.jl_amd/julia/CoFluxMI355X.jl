@@ -222,6 +222,7 @@ staging(w::CoFluxWindow, slot, var) =
                 (w.nsx, w.nsy))
 wait_slot!(w::CoFluxWindow, slot) =
     check(w.backend.ctx, ccall((:cf_window_wait_slot, libcoflux), Cint, (Ptr{Cvoid}, Int32), w.ptr, slot))
+# time_index = the monotone snapshot counter ⌊t/Δt⌋ (slot = counter mod nslots), not the index inside a repeat-year record
 commit!(w::CoFluxWindow, slot, time_index) =
     check(w.backend.ctx, ccall((:cf_window_commit, libcoflux), Cint, (Ptr{Cvoid}, Int32, Int64), w.ptr, slot, time_index))
 resident(w::CoFluxWindow, time_index) = ccall((:cf_window_find, libcoflux), Cint, (Ptr{Cvoid}, Int64), w.ptr, time_index) >= 0
