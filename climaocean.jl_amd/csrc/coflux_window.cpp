@@ -76,6 +76,7 @@ int cf_window_wait_slot(cf_window* w, int32_t slot) {
     if (!w) return fail(nullptr, CF_ERR_INVALID, "window is NULL");
     if (slot < 0 || slot >= w->n_slots) return fail(w->ctx, CF_ERR_INVALID, "slot %d outside [0, %d)", slot, w->n_slots);
     if (w->in_flight[slot]) {
+        HIP_TRY(w->ctx, hipSetDevice(w->ctx->device));  // a reader thread calls this: its current device may differ
         HIP_TRY(w->ctx, hipEventSynchronize(w->ev_uploaded[slot]));
         w->in_flight[slot] = 0;
     }
