@@ -443,6 +443,7 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
 
 int cf_debug_eval(cf_ctx* ctx, int function, int n, const double* d_x, double* d_y) {
     if (!ctx || !d_x || !d_y || n < 0) return fail(ctx, CF_ERR_INVALID, "cf_debug_eval: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     HIP_TRY(ctx, launch_debug_eval(ctx->stream, ctx->launch, function, n, d_x, d_y));
     return CF_OK;
 }
@@ -458,6 +459,7 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream) {
 
 int cf_sync(cf_ctx* ctx) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (int rc = wait_for_halos(ctx)) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CF_OK;
@@ -547,6 +549,7 @@ static int wait_for_halos(cf_ctx* ctx) {
 int cf_interpolate_atmosphere_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
                                     const cf_exchange_fields* out) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     CHECK(check_source(ctx, src));
     CHECK(check_weights(ctx, w));
     CHECK(check_exchange(ctx, out, true));
@@ -557,6 +560,7 @@ int cf_interpolate_atmosphere_state(cf_ctx* ctx, const cf_atmos_source* src, con
 int cf_compute_atmosphere_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
                                        const cf_interface_fluxes* out) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     CHECK(check_ocean(ctx, ocean));
     CHECK(check_exchange(ctx, atmos, false));
     CHECK(check_fluxes(ctx, out));
@@ -572,6 +576,7 @@ int cf_compute_net_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean, cons
                                 const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice,
                                 const cf_interp_weights* w, const cf_net_ocean_fluxes* out) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     CHECK(check_ocean(ctx, ocean));
     CHECK(check_exchange(ctx, atmos, true));
     CHECK(check_fluxes(ctx, fluxes));
@@ -585,6 +590,7 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
                     const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
                     const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     CHECK(check_source(ctx, src));
     CHECK(check_weights(ctx, w));
     CHECK(check_ocean(ctx, ocean));
@@ -808,6 +814,7 @@ int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, co
 int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, const cf_ocean_surface* ocean,
                                          const cf_exchange_fields* atmos, const cf_interface_fluxes* out) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
     if (!ice || !ice->thickness || !ice->top_temperature)
         return fail(ctx, CF_ERR_INVALID, "sea-ice thickness and top temperature are NULL");
@@ -826,6 +833,7 @@ int cf_compute_net_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, cons
                                   const double* frazil_heat, const double* interface_heat,
                                   const cf_net_sea_ice_fluxes* out) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
     if (!ice || !ice->concentration) return fail(ctx, CF_ERR_INVALID, "sea-ice concentration is NULL");
     if (!atmos || !atmos->Qs || !atmos->Ql) return fail(ctx, CF_ERR_INVALID, "downwelling radiation fields are NULL");
@@ -856,6 +864,7 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
 int cf_normalize_salinity_flux(cf_ctx* ctx, double* d_flux, const double* d_additional, const double* d_area,
                                const void* d_mask, double* d_mean_out) {
     if (!ctx || !d_flux) return fail(ctx, CF_ERR_INVALID, "cf_normalize_salinity_flux: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (ctx->dev.mask_kind != CF_MASK_NONE && !d_mask)
         return fail(ctx, CF_ERR_INVALID, "mask_kind = %d but the mask is NULL", ctx->dev.mask_kind);
     if (!ctx->d_reduce) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_reduce, sizeof(double) * (2 * SALINITY_PARTIAL_BLOCKS + 2)));
@@ -872,6 +881,7 @@ int cf_normalize_salinity_flux(cf_ctx* ctx, double* d_flux, const double* d_addi
 
 int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int rows) {
     if (!ctx || !d_fields || nfields <= 0) return fail(ctx, CF_ERR_INVALID, "cf_halo_exchange_rows: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (!ctx->comm) return fail(ctx, CF_ERR_COMM, "cf_comm_init has not been called");
     const GridDesc& G = ctx->grid;
     if (rows <= 0 || rows > G.hy || rows > G.ny) return fail(ctx, CF_ERR_INVALID, "rows = %d outside [1, min(hy, ny)]", rows);
