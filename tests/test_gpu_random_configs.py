@@ -67,3 +67,27 @@ def test_random_formulation_matches_oracle(seed):
     np.testing.assert_array_equal(
         util.window(got["fluxes"]["iterations"], 3, 3, nx, ny, 1)[util.window(ref["fluxes"]["iterations"], 3, 3, nx, ny, 1) < params.maxiter],
         util.window(ref["fluxes"]["iterations"], 3, 3, nx, ny, 1)[util.window(ref["fluxes"]["iterations"], 3, 3, nx, ny, 1) < params.maxiter])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_radiation_and_partition_parameters_match_oracle(seed):
+    """Net-flux assembly under random surface properties: constant or latitude-dependent albedo, emissivity, ocean
+    density / heat capacity / freshwater density, salinity floor, shortwave to the surface flux or into JT, with
+    and without the sea-ice partition, uint8 or bottom-height wet mask, random time level pair and fraction."""
+    rng = random.Random(5000 + seed)
+    albedo = rng.choice([0.06, 0.1, ic.LatitudeDependentAlbedo(), ic.LatitudeDependentAlbedo(diffuse=0.08, direct=0.02)])
+    props = ic.OceanProperties(reference_density=rng.choice([1026.0, 1035.0]), heat_capacity=rng.choice([3991.86795711963, 3850.0]),
+                               freshwater_density=rng.choice([1000.0, 999.8]))
+    params = ic.flux_params(rng.choice([ic.SimilarityTheoryFluxes(), ic.corrected_atmosphere_ocean_fluxes(),
+                                        ic.ncar_atmosphere_ocean_fluxes()]),
+                            ocean=props, ocean_surface=ic.SurfaceRadiationProperties(albedo, rng.choice([1.0, 0.97, 0.9])),
+                            ocean_minimum_salinity=rng.choice([0.0, 1.0, 34.5]), penetrating_shortwave=rng.random() < 0.5,
+                            stefan_boltzmann_constant=rng.choice([5.67e-8, 5.670374419e-8]))
+    nx, ny = rng.choice([(72, 40), (101, 19)])
+    case = util.build_case(nx, ny, 4, 4, weights=rng.choice(["latlon", "tripolar"]), n_levels=4)
+    l1, l2 = rng.sample(range(4), 2)
+    tf = rng.choice([0.0, 1.0, rng.random()])
+    use_ice, fused = rng.random() < 0.6, rng.random() < 0.5
+    got = run_gpu(case, params, fused=fused, ice=use_ice, time_fraction=tf, level1=l1, level2=l2)
+    ref = run_oracle(case, params, ice=use_ice, time_fraction=tf, level1=l1, level2=l2)
+    compare(case, got, ref, 1, maxiter=max(params.maxiter, 1))
