@@ -73,7 +73,7 @@ def test_random_formulation_matches_oracle(seed):
 def test_random_radiation_and_partition_parameters_match_oracle(seed):
     """Net-flux assembly under random surface properties: constant or latitude-dependent albedo, emissivity, ocean
     density / heat capacity / freshwater density, salinity floor, shortwave to the surface flux or into JT, with
-    and without the sea-ice partition, uint8 or bottom-height wet mask, random time level pair and fraction."""
+    and without the sea-ice partition, random time level pair and fraction."""
     rng = random.Random(5000 + seed)
     albedo = rng.choice([0.06, 0.1, ic.LatitudeDependentAlbedo(), ic.LatitudeDependentAlbedo(diffuse=0.08, direct=0.02)])
     props = ic.OceanProperties(reference_density=rng.choice([1026.0, 1035.0]), heat_capacity=rng.choice([3991.86795711963, 3850.0]),
