@@ -48,25 +48,31 @@ def parse():
     ap.add_argument("--halo-backend", choices=("rccl", "torch"), default="rccl")
     ap.add_argument("--flux-configuration", choices=("default", "corrected", "ncar"), default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-repeats", type=int, default=3)
+    ap.add_argument("--cpu-repeats", type=int, default=0)  # 0: as many passes as fit ≈ 6 s (3…30)
     return ap.parse_args()
 
 
 def cpu_baseline(case_np, params, nx, ny, h, repeats):
     """The CPU oracle (C restatement, OpenMP over rows) timed on this box's host cores on the same
-    workload: `repeats` full passes of interpolate + solver + net fluxes over the rank-0 slab."""
+    workload: full passes of interpolate + solver + net fluxes over the rank-0 slab.  `repeats` = 0 sizes the
+    sample itself: as many passes as fit ≈ 6 s of wall time (at least 3, at most 30), best pass reported."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     g = orc.make_grid(nx, ny, h, h, 1)
     cores = orc.max_threads()
-    t_best = None
-    for _ in range(repeats):
+
+    def one_pass():
         t0 = time.perf_counter()
         atmos = orc.interpolate_atmosphere_state(g, case_np["src"], case_np["weights"], 0, 1, 0.37)
         fl = orc.compute_atmosphere_ocean_fluxes(g, params, case_np["ocean"], atmos, nthreads=0, scales=False)
         orc.compute_net_ocean_fluxes(g, params, case_np["ocean"], atmos, fl, weights=case_np["weights"])
-        dt = time.perf_counter() - t0
-        t_best = dt if t_best is None else min(t_best, dt)
+        return time.perf_counter() - t0
+
+    t_best = one_pass()
+    if repeats <= 0:
+        repeats = min(30, max(3, int(6.0 / max(t_best, 1e-3))))
+    for _ in range(repeats - 1):
+        t_best = min(t_best, one_pass())
     return dict(value=nx * ny / t_best, unit="cells/s", cores=cores, kind="port",
                 sample=f"{repeats} full update_state passes over the {nx}x{ny} surface (best of {repeats}); "
                        "oracle/coflux_oracle.c, OpenMP over rows")
