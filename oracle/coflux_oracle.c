@@ -822,6 +822,10 @@ double oracle_saturation_vapor_pressure_liquid(const cf_flux_params* P, double T
     thermo_derived d = derive(&P->thermo);
     return svp_liquid(&P->thermo, &d, T);
 }
+double oracle_saturation_vapor_pressure_ice(const cf_flux_params* P, double T) {
+    thermo_derived d = derive(&P->thermo);
+    return svp_ice(&P->thermo, &d, T);
+}
 double oracle_water_mole_fraction(const cf_flux_params* P, double S) {
     return water_mole_fraction(&P->seawater, S);
 }

@@ -40,6 +40,8 @@ def load():
             getattr(lib, n).argtypes = [C.c_int, C.c_double]
         lib.oracle_saturation_vapor_pressure_liquid.restype = C.c_double
         lib.oracle_saturation_vapor_pressure_liquid.argtypes = [C.POINTER(abi.FluxParams), C.c_double]
+        lib.oracle_saturation_vapor_pressure_ice.restype = C.c_double
+        lib.oracle_saturation_vapor_pressure_ice.argtypes = [C.POINTER(abi.FluxParams), C.c_double]
         lib.oracle_water_mole_fraction.restype = C.c_double
         lib.oracle_water_mole_fraction.argtypes = [C.POINTER(abi.FluxParams), C.c_double]
         lib.oracle_air_density.restype = C.c_double
