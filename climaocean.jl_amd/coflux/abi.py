@@ -8,6 +8,9 @@ import os
 
 ABI_VERSION = 1
 COMM_ID_BYTES = 128
+PEER_HANDLE_BYTES = 64
+HALO_NONE, HALO_RCCL, HALO_PEER = 0, 1, 2
+FOLD_CENTER, FOLD_X_FACE, FOLD_Y_FACE = 0, 1, 2
 
 # enums (values from include/coflux.h)
 SIMILARITY_LOGARITHMIC, SIMILARITY_COARE_LOGARITHMIC = 0, 1
@@ -138,6 +141,16 @@ class AtmosSource(C.Structure):
                 ("time_fraction", C.c_double)]
 
 
+class RunSchedule(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("n_ocean_states", C.c_int32),
+                ("ocean_states", C.POINTER(OceanSurface)),
+                ("n_atmos_sets", C.c_int32), ("pipeline", C.c_int32),
+                ("atmos", C.POINTER(ExchangeFields)),
+                ("first_level", C.c_int32), ("halo_backend", C.c_int32),
+                ("halo_rows", C.c_int32), ("fold_north", C.c_int32),
+                ("time_fraction", C.c_double), ("time_fraction_increment", C.c_double)]
+
+
 class InterpWeights(C.Structure):
     _fields_ = [("separable", C.c_int32), ("reserved", C.c_int32),
                 ("fi", C.c_void_p), ("fj", C.c_void_p),
@@ -155,6 +168,8 @@ EXPORTED_SYMBOLS = (
     "cf_compute_net_sea_ice_fluxes", "cf_update_state_sea_ice",
     "cf_time_stage", "cf_time_copy", "cf_profile_enable", "cf_profile_read",
     "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
+    "cf_peer_halo_export", "cf_peer_halo_connect", "cf_halo_exchange_rows_peer", "cf_fold_north_halo",
+    "cf_time_steps", "cf_prefetch_atmosphere_state",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
     "cf_window_upload", "cf_window_find", "cf_window_source",
 )
@@ -233,6 +248,14 @@ def load_library(path=None):
     lib.cf_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.cf_comm_destroy.argtypes = [vp]
     lib.cf_halo_exchange_rows.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int]
+    lib.cf_peer_halo_export.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.cf_peer_halo_connect.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    lib.cf_halo_exchange_rows_peer.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int]
+    lib.cf_fold_north_halo.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.c_int]
+    lib.cf_time_steps.argtypes = [
+        vp, C.c_int64, C.c_int, C.POINTER(RunSchedule), C.POINTER(AtmosSource), C.POINTER(InterpWeights),
+        C.POINTER(InterfaceFluxes), C.POINTER(SeaIceFields), C.POINTER(NetOceanFluxes)]
+    lib.cf_prefetch_atmosphere_state.argtypes = [vp, C.POINTER(AtmosSource), C.POINTER(InterpWeights), C.POINTER(ExchangeFields)]
     lib.cf_window_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.cf_window_destroy.argtypes = [vp]
     lib.cf_window_host_buffer.argtypes = [vp, C.c_int32, C.c_int32]

@@ -50,15 +50,34 @@ def exchange_halo_rows_torch(tensors, ny, hy, rows=1, group=None):
         t[sl].copy_(buf)
 
 
+def fold_north_halo_torch(t, nx, ny, hx, hy, rows, location="center", sign=1.0):
+    """Tripolar fold of one (ny+2hy, nx+2hx) array held by the LAST slab (include/coflux.h: cf_fold_north_halo;
+    Oceananigans' zipper boundary condition): north halo rows from the slab's own mirrored interior rows.
+    The torch form of the fold for CPU slabs (gloo tests); libcoflux's kernel is the GPU form."""
+    i = torch.arange(-hx, nx + hx) % nx
+    for r in range(1, rows + 1):
+        if location == "x_face":
+            src_i, src_j, sg = (nx - i) % nx, ny - 1 - r, torch.where(i == 0, abs(sign), sign).to(t.dtype)
+        elif location == "y_face":
+            src_i, src_j, sg = nx - 1 - i, ny - r, sign
+        else:
+            src_i, src_j, sg = nx - 1 - i, ny - 1 - r, sign
+        t[hy + ny - 1 + r, :] = sg * t[hy + src_j, hx + src_i]
+
+
 class SlabHaloExchanger:
     """Per-step halo exchange of the ocean surface fields of one slab.
 
-    backend "rccl": libcoflux's grouped ncclSend/ncclRecv on the kernels' stream (the unique id is
-    created on rank 0 and broadcast with torch.distributed); "torch": torch.distributed P2P.
+    backend "rccl": libcoflux's grouped ncclSend/ncclRecv on its communication stream (the unique id is
+    created on rank 0 and broadcast with torch.distributed); "peer": libcoflux's peer-direct mailboxes (HIP IPC
+    handles gathered with torch.distributed); "torch": torch.distributed P2P.
+    `rows` defaults to ring + 1: with ring = 1 the kernels also compute row j = ny, whose cell-centre v reads the
+    y-face at j = ny + 1.
     """
 
-    def __init__(self, ctx, ny, hy, rows=1, backend="rccl"):
-        self.ctx, self.ny, self.hy, self.rows = ctx, ny, hy, rows
+    def __init__(self, ctx, ny, hy, rows=None, backend="rccl"):
+        self.ctx, self.ny, self.hy = ctx, ny, hy
+        self.rows = rows if rows is not None else ctx.grid.ring + 1
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.backend = backend if self.world > 1 else "none"
@@ -67,9 +86,17 @@ class SlabHaloExchanger:
             ident = [comm_unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(ident, src=0)
             ctx.comm_init(ident[0], self.rank, self.world)
+        elif self.backend == "peer":
+            mine = ctx.peer_halo_export(max_fields=4, max_rows=self.rows)
+            handles = [None] * self.world
+            dist.all_gather_object(handles, mine)
+            ctx.peer_halo_connect(handles[self.rank - 1] if self.rank > 0 else None,
+                                  handles[self.rank + 1] if self.rank < self.world - 1 else None, self.rank, self.world)
 
     def __call__(self, tensors):
         if self.backend == "rccl":
             self.ctx.halo_exchange_rows(tensors, self.rows)
+        elif self.backend == "peer":
+            self.ctx.halo_exchange_rows_peer(tensors, self.rows)
         elif self.backend == "torch":
             exchange_halo_rows_torch(tensors, self.ny, self.hy, self.rows)

@@ -263,6 +263,60 @@ class FluxContext:
         self._check(self.lib.cf_profile_read(self._h, kernel, C.byref(ms), C.byref(n)), "cf_profile_read")
         return ms.value, n.value
 
+    def prefetch_atmosphere_state(self, src, weights, atmos_next, level1=0, level2=1, time_fraction=0.0):
+        """Start the NEXT step's interpolate_atmosphere_state! on the auxiliary stream (cf_prefetch_atmosphere_state)."""
+        s = self.source_struct(src, level1, level2, time_fraction)
+        w = self.weights_struct(weights)
+        e = self.exchange_struct(atmos_next)
+        self._check(self.lib.cf_prefetch_atmosphere_state(self._h, C.byref(s), C.byref(w), C.byref(e)),
+                    "cf_prefetch_atmosphere_state")
+
+    def make_schedule(self, ocean_states, atmos_sets, *, first_level=0, time_fraction=0.0, time_fraction_increment=0.0,
+                      pipeline=False, halo_backend=abi.HALO_NONE, halo_rows=0, fold_north=False):
+        """cf_run_schedule for cf_time_steps; keeps the ctypes arrays alive on the returned object."""
+        sch = abi.RunSchedule()
+        oc = (abi.OceanSurface * len(ocean_states))(*[self.ocean_struct(o) for o in ocean_states])
+        at = (abi.ExchangeFields * len(atmos_sets))(*[self.exchange_struct(a) for a in atmos_sets])
+        sch.struct_size = C.sizeof(abi.RunSchedule)
+        sch.n_ocean_states, sch.ocean_states = len(ocean_states), oc
+        sch.n_atmos_sets, sch.atmos, sch.pipeline = len(atmos_sets), at, 1 if pipeline else 0
+        sch.first_level, sch.halo_backend, sch.halo_rows = first_level, halo_backend, halo_rows
+        sch.fold_north = 1 if fold_north else 0
+        sch.time_fraction, sch.time_fraction_increment = float(time_fraction), float(time_fraction_increment)
+        sch._keep = (oc, at, ocean_states, atmos_sets)
+        return sch
+
+    def time_steps(self, first_step, nsteps, schedule, src, weights, fluxes, net, ice=None):
+        """run!(simulation) of a prescribed-ocean model: nsteps × (halo rows → update_state!) inside libcoflux."""
+        s = self.source_struct(src, 0, 0, 0.0)
+        w = self.weights_struct(weights)
+        f, n, i = self.fluxes_struct(fluxes), self.net_struct(net), self.ice_struct(ice)
+        self._check(self.lib.cf_time_steps(self._h, first_step, nsteps, C.byref(schedule), C.byref(s), C.byref(w),
+                                           C.byref(f), C.byref(i) if i is not None else None, C.byref(n)),
+                    "cf_time_steps")
+
+    # -- peer-direct halo rows / tripolar fold -----------------------------------------------------
+    def peer_halo_export(self, max_fields=4, max_rows=2):
+        buf = C.create_string_buffer(abi.PEER_HANDLE_BYTES)
+        self._check(self.lib.cf_peer_halo_export(self._h, max_fields, max_rows, buf), "cf_peer_halo_export")
+        return buf.raw
+
+    def peer_halo_connect(self, south, north, rank, nranks):
+        sb = C.create_string_buffer(south, abi.PEER_HANDLE_BYTES) if south is not None else None
+        nb = C.create_string_buffer(north, abi.PEER_HANDLE_BYTES) if north is not None else None
+        self._check(self.lib.cf_peer_halo_connect(self._h, sb, nb, rank, nranks), "cf_peer_halo_connect")
+
+    def halo_exchange_rows_peer(self, tensors, rows=2):
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        self._check(self.lib.cf_halo_exchange_rows_peer(self._h, arr, len(tensors), rows), "cf_halo_exchange_rows_peer")
+
+    def fold_north_halo(self, tensors, locations, signs, rows=2):
+        n = len(tensors)
+        arr = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        loc = (C.c_int * n)(*locations)
+        sg = (C.c_double * n)(*signs)
+        self._check(self.lib.cf_fold_north_halo(self._h, arr, loc, sg, n, rows), "cf_fold_north_halo")
+
     # -- RCCL halo rows -------------------------------------------------------------------------
     def comm_init(self, unique_id: bytes, rank, nranks):
         buf = C.create_string_buffer(unique_id, abi.COMM_ID_BYTES)

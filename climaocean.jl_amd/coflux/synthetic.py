@@ -108,6 +108,19 @@ def ocean_state(nx, ny, hx, hy, *, ny_global=None, j_offset=0, latitude=(-70.0, 
     return {k: np.ascontiguousarray(a) for k, a in out.items()}
 
 
+def evolved_ocean_state(state, nx, ny, hx, hy, step, *, ny_global=None, j_offset=0, seed=SEED):
+    """The surface state `step` coupled steps (Δt = 20 min) after `state`: T, S, u, v drift by what an ocean
+    surface changes in twenty minutes (≈ 0.02 K, 0.002 g/kg, 5 mm/s per step, white in space — the synthetic
+    fields have no dynamics to evolve them with).  Same mask; a function of global indices like everything here."""
+    i, j = ocean_indices(nx, ny, hx, hy, j_offset)
+    out = dict(state)
+    out["T"] = np.maximum(-1.8, state["T"] + 0.02 * step * normal("To", i, j, 7, seed))
+    out["S"] = np.clip(state["S"] + 0.002 * step * normal("So", i, j, 7, seed), 30.0, 40.0)
+    out["u"] = state["u"] + 0.005 * step * normal("uo", i, j, 7, seed)
+    out["v"] = state["v"] + 0.005 * step * normal("vo", i, j, 7, seed)
+    return {k: np.ascontiguousarray(a) for k, a in out.items()}
+
+
 def sea_ice_state(nx, ny, hx, hy, *, ny_global=None, j_offset=0, latitude=(-70.0, 70.0), seed=SEED):
     """Synthetic ClimaSeaIce surface state on the ocean grid: thickness [m] (including ice thinner than the
     consolidation thickness), previous top temperature [°C], ice drift, per-cell albedo."""
@@ -123,27 +136,38 @@ def sea_ice_state(nx, ny, hx, hy, *, ny_global=None, j_offset=0, latitude=(-70.0
     return {k: np.ascontiguousarray(a) for k, a in out.items()}
 
 
-def jra55_snapshots(n_levels=2, nsx=JRA55_NX, nsy=JRA55_NY, seed=SEED):
-    """Synthetic JRA55 window: dict var -> float32 [n_levels, nsy, nsx] (jra55_data_staging.jl:8)."""
+def jra55_snapshots(n_levels=2, nsx=JRA55_NX, nsy=JRA55_NY, seed=SEED, temporal_correlation=None):
+    """Synthetic JRA55 window: dict var -> float32 [n_levels, nsy, nsx] (jra55_data_staging.jl:8).
+    Default: the snapshots are independent draws (every test and golden vector uses this).  With
+    `temporal_correlation` = ρ the noise of consecutive 3-hourly snapshots is correlated ρ (a rotation by
+    arccos ρ per snapshot in the plane of two independent fields, so every snapshot keeps the same marginal
+    distribution): synoptic fields decorrelate over days, not hours, and bench.py steps the clock through them."""
     i = np.arange(nsx)[None, :]
     j = np.arange(nsy)[:, None]
     phi = JRA55_LAT0 + j * (2 * 89.57 / (nsy - 1)) + 0 * i
     out = {k: np.empty((n_levels, nsy, nsx), np.float32)
            for k in ("tas", "huss", "psl", "uas", "vas", "rlds", "rsds", "prra", "prsn")}
+    if temporal_correlation is None:
+        noise = normal
+    else:
+        theta = np.arccos(temporal_correlation)
+
+        def noise(field, ii, jj, n, sd):
+            return np.cos(n * theta) * normal(field, ii, jj, 100, sd) + np.sin(n * theta) * normal(field, ii, jj, 101, sd)
     for n in range(n_levels):
-        Ta = 273.15 + np.maximum(-1.8, zonal_sst(phi)) - 1.0 + 2.0 * normal("Ta", i, j, n, seed)
-        pa = 101325.0 + 800.0 * normal("pa", i, j, n, seed)
-        qa = (0.8 + 0.05 * normal("qa", i, j, n, seed)) * _qsat_tetens(Ta, pa)
+        Ta = 273.15 + np.maximum(-1.8, zonal_sst(phi)) - 1.0 + 2.0 * noise("Ta", i, j, n, seed)
+        pa = 101325.0 + 800.0 * noise("pa", i, j, n, seed)
+        qa = (0.8 + 0.05 * noise("qa", i, j, n, seed)) * _qsat_tetens(Ta, pa)
         out["tas"][n] = Ta
         out["psl"][n] = pa
         out["huss"][n] = np.maximum(qa, 1e-5)
-        out["uas"][n] = 7.0 * normal("ua", i, j, n, seed)
-        out["vas"][n] = 7.0 * normal("va", i, j, n, seed)
-        out["rsds"][n] = np.maximum(0.0, 300.0 * np.cos(np.deg2rad(phi)) + 50.0 * normal("Qs", i, j, n, seed))
-        out["rlds"][n] = 350.0 + 30.0 * normal("Ql", i, j, n, seed)
-        out["prra"][n] = np.maximum(0.0, 3e-5 * (1.0 + normal("rain", i, j, n, seed)))
+        out["uas"][n] = 7.0 * noise("ua", i, j, n, seed)
+        out["vas"][n] = 7.0 * noise("va", i, j, n, seed)
+        out["rsds"][n] = np.maximum(0.0, 300.0 * np.cos(np.deg2rad(phi)) + 50.0 * noise("Qs", i, j, n, seed))
+        out["rlds"][n] = 350.0 + 30.0 * noise("Ql", i, j, n, seed)
+        out["prra"][n] = np.maximum(0.0, 3e-5 * (1.0 + noise("rain", i, j, n, seed)))
         out["prsn"][n] = np.where(np.abs(phi) > 60.0,
-                                  np.maximum(0.0, 1e-5 * (1.0 + normal("snow", i, j, n, seed))), 0.0)
+                                  np.maximum(0.0, 1e-5 * (1.0 + noise("snow", i, j, n, seed))), 0.0)
     return out
 
 

@@ -13,11 +13,15 @@ int cf_fail(cf_ctx* ctx, int code, const char* fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_error = buf;
-    if (ctx) ctx->error = buf;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->error_mutex);
+        ctx->error = buf;
+    }
     return code;
 }
 
 static int wait_for_halos(cf_ctx* ctx);
+int cf_flush_deferred_prefetch(cf_ctx* ctx);  // coflux_steps.cpp
 
 static bool roughness_ok(const cf_roughness& r, bool scalar) {
     if (scalar) {
@@ -248,7 +252,15 @@ extern "C" {
 
 int cf_version(void) { return CF_ABI_VERSION; }
 
-const char* cf_last_error(const cf_ctx* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+const char* cf_last_error(const cf_ctx* ctx) {
+    if (!ctx) return g_error.c_str();
+    static thread_local std::string copy;  // the text may be rewritten by another thread (window reader) after we return
+    {
+        std::lock_guard<std::mutex> lock(const_cast<cf_ctx*>(ctx)->error_mutex);
+        copy = ctx->error;
+    }
+    return copy.c_str();
+}
 
 int cf_default_flux_params(cf_flux_params* p) {
     if (!p) return fail(nullptr, CF_ERR_INVALID, "params is NULL");
@@ -386,6 +398,17 @@ int cf_destroy(cf_ctx* ctx) {
         (void)hipEventDestroy(ctx->ev_main_idle);
         (void)hipEventDestroy(ctx->ev_comm_done);
     }
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+        (void)hipEventDestroy(ctx->ev_aux_gate);
+        for (auto& p : ctx->prefetch)
+            if (p.done) (void)hipEventDestroy(p.done);
+    }
+    if (ctx->peer_south_mapped) (void)hipIpcCloseMemHandle(ctx->peer.south);
+    if (ctx->peer_north_mapped) (void)hipIpcCloseMemHandle(ctx->peer.north);
+    if (ctx->peer.mine) (void)hipFree(ctx->peer.mine);
+    if (ctx->d_peer_status) (void)hipFree(ctx->d_peer_status);
     if (ctx->d_hint) (void)hipFree(ctx->d_hint);
     if (ctx->d_chunk_sums) (void)hipFree(ctx->d_chunk_sums);
     if (ctx->d_chunk_begins) (void)hipFree(ctx->d_chunk_begins);
@@ -417,7 +440,8 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->launch.solver = value;
             return CF_OK;
         case CF_OPT_INTERP_TILE_CAP:
-            if (value != 0 && (value < 16 || value > 512)) return fail(ctx, CF_ERR_INVALID, "interp tile cap %d: 0 (LDS-free gather kernel) or 16…512", value);
+            // 4 waves × 9 variables × cap × 8 B of dynamic LDS must fit a workgroup's 64 KB
+            if (value != 0 && (value < 16 || value > 224)) return fail(ctx, CF_ERR_INVALID, "interp tile cap %d: 0 (LDS-free gather kernel) or 16…224", value);
             ctx->launch.interp_cap = value;
             return CF_OK;
         case CF_OPT_MAX_BLOCKS:
@@ -461,7 +485,15 @@ int cf_sync(cf_ctx* ctx) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (int rc = wait_for_halos(ctx)) return rc;
+    CHECK(cf_flush_deferred_prefetch(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream));
+    if (ctx->d_peer_status && ctx->peer_seq) {  // a peer-direct exchange whose neighbour never arrived
+        int st = 0;
+        HIP_TRY(ctx, hipMemcpy(&st, ctx->d_peer_status, sizeof st, hipMemcpyDeviceToHost));
+        if (st) return fail(ctx, CF_ERR_COMM, "peer-direct halo exchange timed out waiting for the %s neighbour's rows",
+                            st == 1 ? "south" : "north");
+    }
     return CF_OK;
 }
 
@@ -604,10 +636,23 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     const bool rec = ctx->prof_count < ctx->prof_capacity && (ctx->prof_calls++ % ctx->prof_stride) == 0;
     hipEvent_t* ev = rec ? &ctx->prof_events[4 * (size_t)ctx->prof_count] : nullptr;
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-    HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
+    // a prefetched atmosphere state (cf_prefetch_atmosphere_state) for exactly this step and this set of exchange
+    // fields is already on its way on the auxiliary stream: wait for it instead of interpolating again
+    bool prefetched = false;
+    if (ctx->deferred.valid && ctx->deferred.out.u == atmos->u) CHECK(cf_flush_deferred_prefetch(ctx));  // asked for THIS step
+    for (auto& p : ctx->prefetch) {
+        if (!p.valid || p.key != atmos->u) continue;
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p.done, 0));  // also orders a mismatched prefetch before our writes
+        prefetched = p.level1 == src->level1 && p.level2 == src->level2 && p.tf == src->time_fraction;
+        p.valid = false;
+    }
+    if (!prefetched) HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     CHECK(wait_for_halos(ctx));  // the interpolation above overlapped the halo rows
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes));
+    // the next step's interpolation goes out behind the solver: its workgroups are dispatched first, the gather kernel
+    // takes the registers and issue slots they leave free
+    CHECK(cf_flush_deferred_prefetch(ctx));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net));
     if (rec) {
@@ -699,8 +744,14 @@ static int load_rccl(cf_ctx* ctx) {
     if (g_rccl.handle) return CF_OK;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
+    // a copy the host process already holds (torch ships its own librccl.so) comes first: two RCCL instances in one
+    // process would each keep their own bootstrap state and shared-memory segments
     for (const char* n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
+    if (!h && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) h = dlopen(nullptr, RTLD_NOW);
+    if (!h)
+        for (const char* n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!h) return fail(ctx, CF_ERR_COMM, "cannot dlopen librccl.so: %s", dlerror());
 #define SYM(field, name)                                                     \
     g_rccl.field = (decltype(g_rccl.field))dlsym(h, name);                   \

@@ -12,11 +12,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/coflux.h"
 #include "coflux_fast.hpp"
+#include "coflux_kernel_types.hpp"
 #include "coflux_kernels.h"
 #include "coflux_tables.h"
 
@@ -73,6 +75,34 @@ struct cf_ctx {
     double* d_tables = nullptr;
     int tables_kind = -1;
     std::string error;
+    std::mutex error_mutex;  // cf_window_wait_slot may fail on a reader thread while the stepping thread reads the text
+    // auxiliary stream: the next step's interpolation runs here while the current step's solver runs on `stream`
+    // (cf_prefetch_atmosphere_state); one record per exchange-field set, matched by cf_update_state
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_aux_gate = nullptr;
+    struct Prefetch {
+        const double* key = nullptr;  // exchange set, identified by its u pointer
+        int level1 = 0, level2 = 0;
+        double tf = 0.0;
+        hipEvent_t done = nullptr;
+        bool valid = false;
+    } prefetch[2];
+    // a prefetch that has been requested but not launched yet: it goes out right AFTER the next solver launch, so
+    // that the solver's workgroups are dispatched first and the interpolation only fills what they leave free
+    struct Deferred {
+        bool valid = false;
+        cf_atmos_source src{};
+        cf_interp_weights w{};
+        cf_exchange_fields out{};
+    } deferred;
+    // peer-direct halo rows (coflux_halo.hip)
+    PeerMailbox peer{};
+    size_t peer_bytes = 0;
+    int peer_max_fields = 0, peer_max_rows = 0;
+    bool peer_connected = false;
+    bool peer_south_mapped = false, peer_north_mapped = false;  // opened through HIP IPC (to be closed)
+    unsigned long long peer_seq = 0;
+    int* d_peer_status = nullptr;
     // RCCL
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;

@@ -75,6 +75,28 @@ struct NetOut {
     double* sw_down;
 };
 
+// peer-direct halo rows (coflux_halo.hip)
+constexpr int PEER_BLOCK = 1024;
+constexpr int PEER_MAX_FIELDS = 8;
+constexpr int PEER_FLAG_BYTES = 4 * 64;  // [side][parity] sequence numbers, one 64-byte line each
+struct PeerMailbox {
+    char* mine;    // this rank's mailbox: flags, then [side][parity][field][row][sj] doubles
+    char* south;   // the south / north neighbours' mailboxes mapped into this process (nullptr: none)
+    char* north;
+    size_t data_offset;   // bytes from the mailbox base to the row storage
+    size_t slot_doubles;  // doubles per (side, parity) slot = max_fields · max_rows · sj
+};
+struct PeerFields {
+    double* ptr[PEER_MAX_FIELDS];
+    int n;
+};
+struct FoldFields {
+    double* ptr[PEER_MAX_FIELDS];
+    double sign[PEER_MAX_FIELDS];
+    int location[PEER_MAX_FIELDS];
+    int n;
+};
+
 inline SourceDesc make_source(const cf_atmos_source* s) {
     SourceDesc S;
     for (int v = 0; v < CF_JRA55_NVARS; ++v) S.data[v] = s->data[v];

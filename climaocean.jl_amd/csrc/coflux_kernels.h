@@ -54,6 +54,12 @@ hipError_t launch_salinity_partial_sums(hipStream_t st, const DevParams& P, cons
                                         int nblocks, double* sums);
 hipError_t launch_salinity_subtract(hipStream_t st, const GridDesc& G, double* flux, const double* sums, double* mean_out);
 hipError_t launch_debug_eval(hipStream_t st, const LaunchCfg& L, int fn, int n, const double* x, double* y);
+struct PeerMailbox;
+struct PeerFields;
+struct FoldFields;
+hipError_t launch_peer_halo(hipStream_t st, const PeerMailbox& M, const PeerFields& F, const GridDesc& G, int rows,
+                            unsigned long long seq, int* d_status);
+hipError_t launch_fold_north(hipStream_t st, const FoldFields& F, const GridDesc& G, int rows);
 hipError_t launch_copy(hipStream_t st, void* dst, const void* src, size_t bytes);
 
 }  // namespace coflux

@@ -87,6 +87,7 @@ int cf_window_commit(cf_window* w, int32_t slot, int64_t time_index) {
     if (!w) return fail(nullptr, CF_ERR_INVALID, "window is NULL");
     cf_ctx* ctx = w->ctx;
     if (slot < 0 || slot >= w->n_slots) return fail(ctx, CF_ERR_INVALID, "slot %d outside [0, %d)", slot, w->n_slots);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     // the device copy of this slot may only be overwritten once every interpolation already queued has read it
     HIP_TRY(ctx, hipEventRecord(w->ev_compute, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(w->copy_stream, w->ev_compute, 0));
@@ -125,6 +126,7 @@ int cf_window_source(cf_window* w, int64_t n1, int64_t n2, double time_fraction,
                     (long long)(s1 < 0 ? n1 : n2), w->n_slots);
     if (!(time_fraction >= 0.0 && time_fraction <= 1.0))
         return fail(ctx, CF_ERR_INVALID, "time fraction %g outside [0, 1]", time_fraction);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, w->ev_uploaded[s1], 0));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, w->ev_uploaded[s2], 0));
     for (int v = 0; v < CF_JRA55_NVARS; ++v) out->data[v] = w->d_data[v];

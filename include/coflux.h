@@ -321,7 +321,7 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 
 /* Implementation options (none of them changes what is computed beyond the stated tolerance).  */
 #define CF_OPT_SOLVER 0           /* CF_SOLVER_*                                                   */
-#define CF_OPT_INTERP_TILE_CAP 1  /* source nodes per variable in a wave's LDS JRA55 tile (128; 16…512), or 0:
+#define CF_OPT_INTERP_TILE_CAP 1  /* source nodes per variable in a wave's LDS JRA55 tile (128; 16…224: 4 waves × 9 variables × cap × 8 B of LDS), or 0:
                                      the LDS-free one-cell-per-lane gather kernel (≤ 56 VGPRs: small enough to run
                                      beside the resident solver workgroups from a second stream)            */
 #define CF_OPT_MAX_BLOCKS 2       /* reserved for persistent-grid experiments (multiple of 8)        */
@@ -522,8 +522,86 @@ int cf_comm_unique_id(void* id128);
 int cf_comm_init(cf_ctx* ctx, const void* id128, int rank, int nranks);
 int cf_comm_destroy(cf_ctx* ctx);
 /* Exchange `rows` boundary rows of `nfields` ocean-grid arrays with the south (rank−1) and north
- * (rank+1) neighbours: my first/last interior rows → their north/south halos.                   */
+ * (rank+1) neighbours: my first/last interior rows → their north/south halos.  With ring = 1 the kernels
+ * also compute the ring row j = ny, whose cell-centre v needs the y-face at j = ny + 1: exchange
+ * rows = ring + 1 of the ocean state (cf_time_steps insists on it).                                */
 int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int rows);
+
+/* Peer-direct halo rows (the reference's analogue is the CUDA-IPC transport of its GPU-aware MPI,
+ * experiments/OMIPSimulations/scripts/launch.sh:270-290).  At 46 KB per neighbour the exchange is latency bound, so
+ * beside the RCCL path there is one that needs no collective library at all: every rank owns a MAILBOX in
+ * fine-grained device memory, exported as a HIP IPC handle; a neighbour maps it and one kernel per step (i) stores
+ * this rank's boundary rows straight into both neighbours' mailboxes over xGMI, (ii) publishes a sequence number with
+ * a system-scope release, (iii) waits (bounded spin) for the neighbours' sequence numbers and (iv) copies their rows
+ * into the halo rows — one launch, no host round trip.  Mailboxes are double-buffered by sequence parity; a rank can
+ * only write parity p again after its own step-(s+1) wait, which implies the neighbour has drained step s.
+ *   cf_peer_halo_export   allocate this rank's mailbox for at most `max_fields` fields × `max_rows` rows, write its
+ *                         IPC handle (CF_PEER_HANDLE_BYTES) — the host distributes handles (MPI / torch.distributed)
+ *   cf_peer_halo_connect  map the south (rank−1) and north (rank+1) mailboxes; NULL at the ends of the slab ring.
+ *                         `fold` != 0 on the LAST rank of a tripolar grid: its north boundary is the fold
+ *                         (one_degree_tripolar.jl:48-51), served locally by cf_fold_north_halo, not by a peer.
+ *   cf_halo_exchange_rows_peer   the per-step exchange, same meaning as cf_halo_exchange_rows.
+ * A spin that exceeds its bound sets a sticky error that the next cf_sync reports (CF_ERR_COMM).            */
+#define CF_PEER_HANDLE_BYTES 64
+int cf_peer_halo_export(cf_ctx* ctx, int max_fields, int max_rows, void* handle_out);
+int cf_peer_halo_connect(cf_ctx* ctx, const void* south_handle, const void* north_handle, int rank, int nranks);
+int cf_halo_exchange_rows_peer(cf_ctx* ctx, double* const* d_fields, int nfields, int rows);
+
+/* Tripolar fold (TripolarGrid(arch; size=(360,180,Nz)), OceanConfigurations/one_degree_tripolar.jl:48-51; the
+ * fold itself lives in Oceananigans' zipper boundary condition, [UPSTREAM-RECALL] fold_north_center_center! /
+ * _face_center! / _center_face!).  The northern boundary of the global grid is folded onto itself about the LAST
+ * row of tracer points (that row is its own mirror image), so the north halo rows of the last latitude slab come
+ * from that slab's own northern interior rows mirrored in i.  0-based interior indices, r = 1…rows:
+ *   centres (T, S, fluxes):  f[i, ny−1+r] = sign · f[nx−1−i, ny−1−r]
+ *   x-faces (u):             f[i, ny−1+r] = s    · f[(nx−i) mod nx, ny−1−r],  s = |sign| where nx−i wraps (i = 0)
+ *   y-faces (v):             f[i, ny−1+r] = sign · f[nx−1−i, ny−r]
+ * `sign` = −1 for the components of a vector (u, v change sign across the fold), +1 for scalars.  The periodic
+ * x-halos of the written rows are filled from the written interior columns.  Folding is an involution on the
+ * mirrored rows (tests/test_tripolar.py).                                                                    */
+#define CF_FOLD_CENTER 0
+#define CF_FOLD_X_FACE 1
+#define CF_FOLD_Y_FACE 2
+/* `nfields` fields in one launch: locations[f] ∈ CF_FOLD_*, signs[f] = ±1. */
+int cf_fold_north_halo(cf_ctx* ctx, double* const* d_fields, const int* locations, const double* signs, int nfields,
+                       int rows);
+
+/* ------------------------------------------------------------------------------------------
+ * run!(simulation) for a coupled model whose ocean component is prescribed (README.md:76-77): `nsteps` × time_step!
+ * without returning to the host language — per step (optional halo rows) → cf_update_state.  What varies from step
+ * to step is what varies in a coupled run: the clock (the JRA55 time fraction ñ advances by Δt/Δt_snapshot and the
+ * bracketing snapshots move through the window) and the ocean surface state (step s reads ocean_states[s mod n]).
+ * With `pipeline` = 1 the atmosphere state of step s+1 is interpolated on the context's auxiliary stream while the
+ * solver of step s runs (the prescribed atmosphere does not depend on the ocean); this needs two sets of exchange
+ * fields, step s uses atmos[s mod 2].  All launches are stream ordered; nothing synchronises with the host.       */
+#define CF_HALO_NONE 0
+#define CF_HALO_RCCL 1
+#define CF_HALO_PEER 2
+typedef struct cf_run_schedule {
+    int32_t struct_size;             /* sizeof(cf_run_schedule) */
+    int32_t n_ocean_states;          /* ≥ 1 */
+    const cf_ocean_surface* ocean_states;
+    int32_t n_atmos_sets;            /* 1, or 2 with pipeline */
+    int32_t pipeline;
+    const cf_exchange_fields* atmos; /* n_atmos_sets entries */
+    int32_t first_level;             /* memory level of snapshot n₁ at step 0; levels advance cyclically */
+    int32_t halo_backend;            /* CF_HALO_* */
+    int32_t halo_rows;               /* rows exchanged per step (ring + 1) */
+    int32_t fold_north;              /* 1: tripolar grid, this rank owns the fold (last rank) */
+    double time_fraction;            /* ñ at step 0 */
+    double time_fraction_increment;  /* Δt / Δt_snapshot: 20 min / 3 h = 1/9 (README.md:76) */
+} cf_run_schedule;
+int cf_time_steps(cf_ctx* ctx, int64_t first_step, int nsteps, const cf_run_schedule* schedule,
+                  const cf_atmos_source* src /* levels / fraction are overridden per step */,
+                  const cf_interp_weights* w, const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice,
+                  const cf_net_ocean_fluxes* net);
+
+/* The pipelined form of update_state! for callers that drive the steps themselves: start the interpolation of the
+ * NEXT step's atmosphere state into `out` on the auxiliary stream now; the next cf_update_state whose (levels, time
+ * fraction, exchange fields) match finds it done (it waits on an event instead of launching the interpolation).
+ * `out` must not be the set the current step's kernels still read.  cf_update_state's signature — the reference
+ * seam — is unchanged.                                                                                          */
+int cf_prefetch_atmosphere_state(cf_ctx* ctx, const cf_atmos_source* src_next, const cf_interp_weights* w,
+                                 const cf_exchange_fields* out);
 
 #ifdef __cplusplus
 }

@@ -482,7 +482,7 @@ int oracle_compute_atmosphere_ocean_fluxes(const cf_grid* g, const cf_flux_param
     (void)nthreads;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 1)
 #endif
     for (int j = -r; j < g->ny + r; ++j) {
         for (int i = -r; i < g->nx + r; ++i) {
@@ -747,7 +747,7 @@ int oracle_compute_atmosphere_sea_ice_fluxes(const cf_grid* g, const cf_flux_par
                                              const cf_exchange_fields* a, const cf_interface_fluxes* out) {
     int r = g->ring;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 1)
 #endif
     for (int j = -r; j < g->ny + r; ++j)
         for (int i = -r; i < g->nx + r; ++i) {

@@ -117,9 +117,10 @@ def _weights_struct(w, keep):
     return s
 
 
-def interpolate_atmosphere_state(g, src, weights, level1=0, level2=1, time_fraction=0.37):
+def interpolate_atmosphere_state(g, src, weights, level1=0, level2=1, time_fraction=0.37, out=None):
     lib, keep = load(), []
-    out = {n: np.zeros(_shape(g)) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
+    if out is None:   # (bench.py's timed CPU leg passes preallocated outputs)
+        out = {n: np.zeros(_shape(g)) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
     s = _source_struct(src, level1, level2, time_fraction, keep)
     w = _weights_struct(weights, keep)
     e = _exchange_struct(out)
@@ -128,14 +129,15 @@ def interpolate_atmosphere_state(g, src, weights, level1=0, level2=1, time_fract
     return out
 
 
-def compute_atmosphere_ocean_fluxes(g, params, ocean, atmos, nthreads=1, scales=True):
+def compute_atmosphere_ocean_fluxes(g, params, ocean, atmos, nthreads=1, scales=True, out=None):
     lib, keep = load(), []
     names = ["sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum", "temperature"]
     if scales:
         names += ["friction_velocity", "temperature_scale", "humidity_scale"]
-    out = {n: np.zeros(_shape(g)) for n in names}
-    if scales:
-        out["iterations"] = np.zeros(_shape(g), np.int32)
+    if out is None:
+        out = {n: np.zeros(_shape(g)) for n in names}
+        if scales:
+            out["iterations"] = np.zeros(_shape(g), np.int32)
     o = _ocean_struct(ocean, keep)
     a = {n: _f64(atmos[n]) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp") if n in atmos}
     for n in ("Qs", "Ql", "Mp"):
@@ -150,11 +152,12 @@ def compute_atmosphere_ocean_fluxes(g, params, ocean, atmos, nthreads=1, scales=
     return out
 
 
-def compute_net_ocean_fluxes(g, params, ocean, atmos, fluxes, ice=None, weights=None):
+def compute_net_ocean_fluxes(g, params, ocean, atmos, fluxes, ice=None, weights=None, out=None):
     lib, keep = load(), []
     names = ["u", "v", "T", "S", "shortwave_surface_flux", "upwelling_longwave",
              "downwelling_longwave", "downwelling_shortwave"]
-    out = {n: np.zeros(_shape(g)) for n in names}
+    if out is None:
+        out = {n: np.zeros(_shape(g)) for n in names}
     o = _ocean_struct(ocean, keep)
     a = {n: _f64(atmos[n]) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
     e = _exchange_struct(a)

@@ -1,0 +1,219 @@
+"""GPU tests of what surrounds update_state! in a multi-step, multi-slab run (include/coflux.h): the C-side step
+loop cf_time_steps, the pipelined interpolation (cf_prefetch_atmosphere_state), the peer-direct halo rows
+(cf_peer_halo_* — two slabs on ONE device here: in one process, and in two processes through HIP IPC), and the
+tripolar fold.  Everything is compared bit for bit with the host-driven three-launch path / the single-domain
+state, which the parity tests in turn hold against the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from coflux import abi
+from coflux import interface_computations as ic
+from coflux import synthetic as syn
+from coflux.distributed import fold_north_halo_torch, slab_bounds
+from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, NET_NAMES, FluxContext
+
+pytestmark = pytest.mark.gpu
+
+NX, NY, H = 192, 48, 4
+INC = 1.0 / 9.0
+
+
+def _setup(nx=NX, ny=NY, ny_global=None, j_offset=0, n_levels=4, device=0):
+    P = ic.flux_params()
+    ctx = FluxContext(nx, ny, H, H, P, ring=1, device=device)
+    o0 = syn.ocean_state(nx, ny, H, H, ny_global=ny_global, j_offset=j_offset)
+    o1 = syn.evolved_ocean_state(o0, nx, ny, H, H, 1, ny_global=ny_global, j_offset=j_offset)
+    states = [{k: ctx.to_device(o[k]) for k in ("T", "S", "u", "v", "mask")} for o in (o0, o1)]
+    states[1]["mask"] = states[0]["mask"]
+    src = {k: ctx.to_device(v) for k, v in syn.jra55_snapshots(n_levels).items()}
+    fi, fj, phi = syn.latlon_fractional_indices(nx, ny, H, H, ny_global=ny_global, j_offset=j_offset)
+    w = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj), latitude=ctx.to_device(phi))
+    return ctx, states, src, w, (o0, o1)
+
+
+def _host_steps(ctx, states, src, w, n, n_levels=4):
+    """The reference sequence: n × update_state! driven from the host, one set of exchange fields."""
+    atmos, fl, net = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+    for s in range(n):
+        tot = s * INC
+        l1 = int(tot) % n_levels
+        ctx.update_state(src, w, states[s % 2], atmos, fl, net, level1=l1, level2=(l1 + 1) % n_levels,
+                         time_fraction=tot - int(tot))
+    ctx.sync()
+    return atmos, fl, net
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_time_steps_reproduces_host_loop_bitwise(pipeline):
+    """cf_time_steps (C loop, advancing clock through a 4-snapshot window, alternating ocean states, optionally
+    with the next step's interpolation on the auxiliary stream) == the host-driven cf_update_state loop."""
+    n = 21   # crosses two snapshot boundaries (9 steps per snapshot interval)
+    ctx, states, src, w, _ = _setup()
+    ref_atmos, ref_fl, ref_net = _host_steps(ctx, states, src, w, n)
+    sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2 if pipeline else 1)]
+    fl, net = ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+    sched = ctx.make_schedule(states, sets, first_level=0, time_fraction=0.0, time_fraction_increment=INC, pipeline=pipeline)
+    ctx.time_steps(0, 8, sched, src, w, fl, net)      # in two calls: the step counter carries the clock
+    ctx.time_steps(8, n - 8, sched, src, w, fl, net)
+    ctx.sync()
+    last = sets[(n - 1) % len(sets)]
+    for k in EXCHANGE_NAMES:
+        assert torch.equal(last[k], ref_atmos[k]), k
+    for k in FLUX_NAMES:
+        assert torch.equal(fl[k], ref_fl[k]), k
+    for k in NET_NAMES:
+        assert torch.equal(net[k], ref_net[k]), k
+    ctx.close()
+
+
+def test_prefetch_mismatch_is_ignored_not_used():
+    """A prefetched atmosphere state for ANOTHER time is never consumed by cf_update_state."""
+    ctx, states, src, w, _ = _setup()
+    a, fl, net = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+    ctx.update_state(src, w, states[0], a, fl, net, level1=1, level2=2, time_fraction=0.25)
+    ctx.sync()
+    want = {k: v.clone() for k, v in a.items()}
+    ctx.prefetch_atmosphere_state(src, w, a, level1=0, level2=1, time_fraction=0.5)      # wrong time for the next call
+    ctx.update_state(src, w, states[0], a, fl, net, level1=1, level2=2, time_fraction=0.25)
+    ctx.sync()
+    for k in EXCHANGE_NAMES:
+        assert torch.equal(a[k], want[k]), k
+    ctx.close()
+
+
+def _slab(rank, world, device=0):
+    j0, j1 = slab_bounds(NY, rank, world)
+    ctx, states, src, w, np_states = _setup(NX, j1 - j0, ny_global=NY, j_offset=j0, device=device)
+    return ctx, states, src, w, np_states, j0, j1
+
+
+def _poison_halos(fields, ny, rank, world):
+    for f in fields:
+        if rank > 0:
+            f[:H] = float("nan")
+        if rank < world - 1:
+            f[H + ny:] = float("nan")
+
+
+def test_peer_halo_rows_two_slabs_in_one_process():
+    """Two latitude slabs as two contexts on one device: mailboxes are handed over inside the process (no IPC
+    needed), rows travel by the peer kernel, and the slab solve with exchanged halos equals the single-domain solve."""
+    world = 2
+    slabs = [_slab(r, world) for r in range(world)]
+    torch.cuda.synchronize()
+    for s in slabs:   # each slab on its own stream: the two exchange kernels wait for each other and must overlap
+        s[0]._check(s[0].lib.cf_set_stream(s[0]._h, None), "cf_set_stream")
+    handles = [s[0].peer_halo_export(4, 2) for s in slabs]
+    for r, s in enumerate(slabs):
+        s[0].peer_halo_connect(handles[r - 1] if r > 0 else None, handles[r + 1] if r < world - 1 else None, r, world)
+    full = syn.ocean_state(NX, NY, H, H)
+    for step in range(3):          # sequence numbers and mailbox parity advance
+        for r, (ctx, states, *_rest, j0, j1) in enumerate(slabs):
+            fields = [states[0][k] for k in ("T", "S", "u", "v")]
+            _poison_halos(fields, j1 - j0, r, world)
+        torch.cuda.synchronize()
+        for r, (ctx, states, *_rest) in enumerate(slabs):      # both launched before either is waited for
+            ctx.halo_exchange_rows_peer([states[0][k] for k in ("T", "S", "u", "v")], rows=2)
+        for r, (ctx, states, *_rest, j0, j1) in enumerate(slabs):
+            ctx.sync()
+            ny = j1 - j0
+            lo = H - 2 if r > 0 else 0
+            hi = H + ny + 2 if r < world - 1 else ny + 2 * H
+            for k in ("T", "S", "u", "v"):
+                got = states[0][k].cpu().numpy()
+                np.testing.assert_array_equal(got[lo:hi], full[k][j0 + lo:j0 + hi], err_msg=f"step {step} rank {r} {k}")
+    # slab solve == rows of the single-domain solve (ring rows included on the seam)
+    gctx, gstates, gsrc, gw, _ = _setup()
+    ga, gf, gn = gctx.field_set(EXCHANGE_NAMES), gctx.field_set(FLUX_NAMES), gctx.field_set(NET_NAMES)
+    gctx.update_state(gsrc, gw, gstates[0], ga, gf, gn, time_fraction=0.37)
+    gctx.sync()
+    for r, (ctx, states, src, w, _np, j0, j1) in enumerate(slabs):
+        a, f, n = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+        torch.cuda.synchronize()     # the zero fills ran on torch's stream, the context has its own
+        ctx.update_state(src, w, states[0], a, f, n, time_fraction=0.37)
+        ctx.sync()
+        ny = j1 - j0
+        for k in FLUX_NAMES:     # interior + ring rows
+            assert torch.equal(f[k][H - 1:H + ny + 1, H - 1:H + NX + 1], gf[k][j0 + H - 1:j0 + H + ny + 1, H - 1:H + NX + 1]), (r, k)
+        for k in ("u", "v", "T", "S"):
+            assert torch.equal(n[k][H:H + ny, H:H + NX], gn[k][j0 + H:j0 + H + ny, H:H + NX]), (r, k)
+    for s in slabs:
+        s[0].close()
+    gctx.close()
+
+
+def _peer_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from coflux.distributed import SlabHaloExchanger
+        ctx, states, src, w, _np, j0, j1 = _slab(rank, world, device=0)   # both ranks on the one device of the box
+        ny = j1 - j0
+        ex = SlabHaloExchanger(ctx, ny, H, backend="peer")                 # handles travel through torch.distributed
+        full = syn.ocean_state(NX, NY, H, H)
+        ok = True
+        fields = [states[0][k] for k in ("T", "S", "u", "v")]
+        for step in range(4):
+            _poison_halos(fields, ny, rank, world)
+            ex(fields)
+            ctx.sync()
+            lo = H - 2 if rank > 0 else 0
+            hi = H + ny + 2 if rank < world - 1 else ny + 2 * H
+            for k, f in zip(("T", "S", "u", "v"), fields):
+                ok &= bool(np.array_equal(f.cpu().numpy()[lo:hi], full[k][j0 + lo:j0 + hi]))
+        # and inside the C step loop
+        sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2)]
+        fl, net = ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+        sched = ctx.make_schedule(states, sets, time_fraction_increment=INC, pipeline=True, halo_backend=abi.HALO_PEER, halo_rows=2)
+        ctx.time_steps(0, 6, sched, src, w, fl, net)
+        ctx.sync()
+        ok &= bool(torch.isfinite(net["T"][H:H + ny, H:H + NX]).all())
+        out[rank] = ok
+        dist.barrier()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_halo_rows_two_processes_hip_ipc():
+    """The same exchange between two PROCESSES (one rank per process, as on a multi-GPU node), mailboxes mapped through
+    hipIpcGetMemHandle / hipIpcOpenMemHandle; both ranks share the one device of the test box."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctxm = mp.get_context("spawn")
+    out = ctxm.Manager().dict()
+    procs = [ctxm.Process(target=_peer_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"peer worker exit code {p.exitcode}"
+    assert out.get(0) is True and out.get(1) is True, dict(out)
+
+
+@pytest.mark.parametrize("rows", [1, 2])
+def test_fold_north_halo_matches_host_fold(rows):
+    """cf_fold_north_halo vs the torch/NumPy statement of Oceananigans' zipper (centres, x-faces, y-faces; vector sign)."""
+    nx, ny = 96, 20
+    ctx = FluxContext(nx, ny, H, H, ic.flux_params(), ring=1)
+    rng = np.random.default_rng(3)
+    host = [rng.normal(size=ctx.shape) for _ in range(4)]
+    dev = [ctx.to_device(a) for a in host]
+    locs = [abi.FOLD_CENTER, abi.FOLD_CENTER, abi.FOLD_X_FACE, abi.FOLD_Y_FACE]
+    signs = [1.0, 1.0, -1.0, -1.0]
+    ctx.fold_north_halo(dev, locs, signs, rows=rows)
+    ctx.sync()
+    for a, d, loc, sg in zip(host, dev, ("center", "center", "x_face", "y_face"), signs):
+        t = torch.from_numpy(a.copy())
+        fold_north_halo_torch(t, nx, ny, H, H, rows, loc, sg)
+        np.testing.assert_array_equal(d.cpu().numpy(), t.numpy())
+    ctx.close()
