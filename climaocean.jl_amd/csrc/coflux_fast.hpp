@@ -129,7 +129,8 @@ struct PsiArg {
 // |ζ| > 4.3e9 (never a converged state) and NaN are evaluated at the table edge.
 __device__ __forceinline__ PsiArg psi_arg(double zeta) {
     PsiArg a;
-    const double x = fmin(__builtin_fma(PSI_A, fabs(zeta), 1.0), 0x1.fffffffffffffp35);
+    static_assert(PSI_BINADES == 34, "the clamp below is the largest double under 2^PSI_BINADES");
+    const double x = fmin(__builtin_fma(PSI_A, fabs(zeta), 1.0), 0x1.fffffffffffffp33);
     const int hi = __double2hiint(x);
     a.k = (hi >> 18) - (1023 << 2);
     a.t = x - __hiloint2double(hi & (int)0xfffc0000, 0);
@@ -177,6 +178,38 @@ __device__ __forceinline__ double2 psi_eval_mh(const double* psi, const PsiArg& 
         return make_double2(pm, ph);
     }
     return make_double2(psi_eval(psi, 0, a), psi_eval(psi, 1, b));
+}
+
+// ψ_m(zu), ψ_h(zq) for |zu|, |zq| < SMALL_Z0 and a common sign (both are a positive roughness length times 1/L★):
+// degree-SMALL_DEG polynomials in |ζ|, one 16-byte LDS read per coefficient pair (two distinct addresses per wave).
+__device__ __forceinline__ double2 psi_small_mh(const double* tab, bool unstable, double zu, double zq) {
+    const double2* c = reinterpret_cast<const double2*>(tab + SMALL_OFFSET) + (unstable ? 0 : SMALL_DEG + 1);
+    const double au = fabs(zu), aq = fabs(zq);
+    double2 v = c[SMALL_DEG];
+    double pm = v.x, ph = v.y;
+#pragma unroll
+    for (int j = SMALL_DEG - 1; j >= 0; --j) {
+        v = c[j];
+        pm = __builtin_fma(pm, au, v.x);
+        ph = __builtin_fma(ph, aq, v.y);
+    }
+    return make_double2(pm, ph);
+}
+
+// exp(x) to ≈ 1e-14 relative for moderate |x| (the scalar roughness length from its logarithm; it only enters the
+// iteration through ψ_h(ℓ_q/L★), a 1e-4-sized term): x = (32k' + k)·ln2/32 + r, |r| ≤ ln2/64, 2^(k/32) from LDS.
+__device__ __forceinline__ double fexp_tab(const double* tab, double x) {
+    const double kf = __builtin_rint(x * (EXP_SEG * 1.4426950408889634074));
+    const double r = __builtin_fma(-kf, 0.6931471805599453094 / EXP_SEG, x);
+    const int k = (int)kf;
+    const double t = tab[EXP_OFFSET + (k & (EXP_SEG - 1))];
+    double p = 1.0 / 120.0;
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(t * p, k >> 5);
 }
 
 // Cooperative copy of the tables into LDS (call once per workgroup, then __syncthreads()).
@@ -344,7 +377,7 @@ struct Scales {
 template <bool COARE, int SPEC>
 __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellConsts& c, const double* tab, bool active) {
     const double* psi = tab;
-    const double* logt = tab + 4 * PSI_TABLE;
+    const double* logt = tab + LOG_OFFSET;
     double us = 1e-4, ts = 1e-4, qq = 1e-4;
     double drift = 0.0;
     int it = 0;
@@ -403,14 +436,34 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
             double Dq = L.log_h - log_lq - psi_hh;
             double Dt = L.log_h - log_lt - psi_hh;
             if constexpr (!COARE) {
-                Du += psi_eval(psi, 0, psi_arg(lu * inv_L));
-                const double psi_lq = psi_eval(psi, 1, psi_arg(fexp(log_lq) * inv_L));
-                Dq += psi_lq;
-                if constexpr (SPEC == SOLVER_OCEAN)
+                const double zu = lu * inv_L;
+                if constexpr (SPEC == SOLVER_OCEAN) {
+                    // the roughness-length arguments are tiny after the first iterates: low-degree polynomials
+                    // (wave-uniform choice; the table path is bitwise what it always was)
+                    const double zq = fexp_tab(tab, log_lq) * inv_L;
+                    // After the first iterates the roughness-length arguments are tiny (|ζ| < 1e-3 in 99.9 % of the
+                    // cells): a PER-LANE choice between a degree-5 polynomial and the general table, so that a cell's
+                    // result never depends on which cells share its wave; a wave whose lanes all agree — four out of
+                    // five — executes only one side (the empty asm keeps the compiler from evaluating both and
+                    // selecting, which would issue the LDS reads of both sides).
+                    double2 pl;
+                    if (fabs(zu) < SMALL_Z0 && fabs(zq) < SMALL_Z0) {
+                        asm volatile("" ::: "memory");
+                        pl = psi_small_mh(tab, inv_L < 0.0, zu, zq);
+                    } else {
+                        asm volatile("" ::: "memory");
+                        pl = psi_eval_mh(psi, psi_arg(zu), psi_arg(zq));
+                    }
+                    Du += pl.x;
+                    Dq += pl.y;
                     Dt = Dq;
-                else
+                } else {
+                    Du += psi_eval(psi, 0, psi_arg(zu));
+                    const double psi_lq = psi_eval(psi, 1, psi_arg(fexp(log_lq) * inv_L));
+                    Dq += psi_lq;
                     Dt += (L.same_scalar && SPEC != SOLVER_ICE) ? psi_lq
                                                                 : psi_eval(psi, 1, psi_arg(fexp(log_lt) * inv_L));
+                }
             }
             Du = fmax(Du, L.profile_floor);
             Dq = fmax(Dq, L.profile_floor);
@@ -493,7 +546,7 @@ __device__ __forceinline__ double svp_ice_fast(const DevParams& P, const double*
 template <bool COARE>
 __device__ __forceinline__ Scales ice_iterate(const DevParams& P, const LoopParams& L, const IceParams& I,
                                               const IceConsts& c, const double* tab, bool active, double& Ts) {
-    const double* logt = tab + 4 * PSI_TABLE;
+    const double* logt = tab + LOG_OFFSET;
     double us = 1e-4, ts = 1e-4, qq = 1e-4, drift = 0.0;
     int it = 0;
     for (;;) {

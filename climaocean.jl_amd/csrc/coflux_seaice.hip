@@ -39,7 +39,7 @@ __global__ __launch_bounds__(AI_BLOCK) void ai_flux_kernel(LoopParams L, IcePara
     for (int n = tid; n < (int)(sizeof(DevParams) / sizeof(double)); n += AI_BLOCK)
         reinterpret_cast<double*>(lp)[n] = reinterpret_cast<const double*>(g_params)[n];
     const DevParams& P = *lp;
-    const double* logt = tab + 4 * PSI_TABLE;
+    const double* logt = tab + LOG_OFFSET;
 
     const int wx = G.nx + 2 * G.ring;
     const int ncells = wx * (G.ny + 2 * G.ring);

@@ -214,7 +214,7 @@ int chunk_sums_capacity(int ncells) { return (ncells + CT_CELLS - 1) / CT_CELLS 
 
 // ---- production solver: LDS tables, one workgroup per chunk of the table above -----------------
 template <bool COARE, int SPEC>
-__global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, GridDesc G, OceanIn O, Exchange E,
+__global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(LoopParams L, GridDesc G, OceanIn O, Exchange E,
                                                                 FluxOut F, const double* __restrict__ g_tab,
                                                                 const DevParams* __restrict__ g_params,
                                                                 uint8_t* __restrict__ hint,
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(AO_BLOCK) void ao_flux_fast_kernel(LoopParams L, Gr
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only: vmcnt / expcnt fields left at their maxima
     __builtin_amdgcn_s_barrier();
     const DevParams& P = *lp;  // prologue-only parameters live in LDS, not in SGPRs
-    const double* logt = tab + 4 * PSI_TABLE;
+    const double* logt = tab + LOG_OFFSET;
 
     const int wx = G.nx + 2 * G.ring;
     const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
@@ -353,7 +353,7 @@ __global__ void debug_eval_kernel(int fn, int n, const double* __restrict__ x, d
     double* tab = reinterpret_cast<double*>(smem);
     stage_tables(tab, g_tab, threadIdx.x, blockDim.x);
     __syncthreads();
-    const double* logt = tab + 4 * PSI_TABLE;
+    const double* logt = tab + LOG_OFFSET;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const double v = x[k];
         double r;

@@ -3,8 +3,8 @@
 // The Monin–Obukhov iteration spends its time in ψ_m(ζ), ψ_h(ζ) and log().  On CDNA4 an FP64
 // libm call costs 40–120 instructions (double-double arithmetic), and the stability functions
 // need 3 log + 2 atan + cbrt + 2 sqrt each.  Instead, every ψ is tabulated once per context as
-// piecewise degree-9 polynomials in  x = 1 + 16|ζ|  (every binade of x ∈ [1, 2^36) cut into 4 equal
-// pieces ⇒ 144 segments, |ζ| ≤ 4.3e9; one table per sign of ζ), which reproduces the analytic functions
+// piecewise degree-9 polynomials in  x = 1 + 16|ζ|  (every binade of x ∈ [1, 2^34) cut into 4 equal
+// pieces ⇒ 136 segments, |ζ| ≤ 1.07e9; one table per sign of ζ), which reproduces the analytic functions
 // to ≤ 3e-14 relative to max(|ψ|, 1) — five orders below the 1e-9 parity tolerance.  The segment index is
 // the exponent and the two top mantissa bits of x and the polynomial variable is u = x − (segment start)
 // (an exact subtraction), so an evaluation costs ≈ 10 integer/FP64 instructions + 10 LDS reads + 9 FMAs and
@@ -13,6 +13,7 @@
 //
 // log() itself uses a 128-entry (1/c, log c) table on the mantissa.
 #include <cmath>
+#include <utility>
 #include <vector>
 
 #include "../../include/coflux.h"
@@ -161,7 +162,39 @@ std::vector<double> build_solver_tables(int stability_kind) {
                 t[(((size_t)side * (PSI_DEG + 1) + c) * PSI_SEG + k) * 2 + fn] = coef[c];
         }
     }
-    double* lt = t.data() + 4 * PSI_TABLE;
+    // small-argument polynomials: ψ(±a) = Σ c_j a^j on a ∈ [0, SMALL_Z0], interpolation at Chebyshev nodes in long double
+    {
+        constexpr int N = SMALL_DEG + 1;
+        for (int side = 0; side < 2; ++side)
+            for (int fn = 0; fn < 2; ++fn) {
+                long double node[N], A[N][N + 1];
+                for (int k = 0; k < N; ++k) {
+                    node[k] = 0.5L * (cosl(PI_L * (k + 0.5L) / N) + 1.0L);  // a / Z0 ∈ (0, 1)
+                    const long double a = node[k] * (long double)SMALL_Z0;
+                    long double p = 1.0L;
+                    for (int c = 0; c < N; ++c, p *= node[k]) A[k][c] = p;  // Vandermonde row in s = a / Z0
+                    A[k][N] = fn ? psi_h_exact(stability_kind, side == 0, a) : psi_m_exact(stability_kind, side == 0, a);
+                }
+                for (int i = 0; i < N; ++i) {  // Gauss–Jordan with partial pivoting
+                    int piv = i;
+                    for (int r = i + 1; r < N; ++r)
+                        if (fabsl(A[r][i]) > fabsl(A[piv][i])) piv = r;
+                    for (int c = 0; c <= N; ++c) std::swap(A[i][c], A[piv][c]);
+                    const long double d = A[i][i];
+                    for (int c = 0; c <= N; ++c) A[i][c] /= d;
+                    for (int r = 0; r < N; ++r)
+                        if (r != i) {
+                            const long double m = A[r][i];
+                            for (int c = 0; c <= N; ++c) A[r][c] -= m * A[i][c];
+                        }
+                }
+                long double zpow = 1.0L;
+                for (int c = 0; c < N; ++c, zpow *= (long double)SMALL_Z0)
+                    t[SMALL_OFFSET + (side * N + c) * 2 + fn] = (double)(A[c][N] / zpow);
+            }
+    }
+    for (int k = 0; k < EXP_SEG; ++k) t[EXP_OFFSET + k] = (double)exp2l((long double)k / EXP_SEG);
+    double* lt = t.data() + LOG_OFFSET;
     for (int k = 0; k < LOG_SEG; ++k) {
         long double c = 1.0L + (k + 0.5L) / LOG_SEG;  // centre of the k-th mantissa interval of [1, 2)
         double inv_c = (double)(1.0L / c);

@@ -183,7 +183,7 @@ def test_launch_geometry_does_not_change_results():
     case = util.build_case(200, 37, 4, 4)
     ref = run_gpu(case, params, fused=True)
     for options in (((abi.OPT_MAX_BLOCKS, 8),), ((abi.OPT_MAX_BLOCKS, 24), (abi.OPT_INTERP_TILE_CAP, 16)),
-                    ((abi.OPT_INTERP_TILE_CAP, 512),), ((abi.OPT_INTERP_TILE_CAP, 0),), ((abi.OPT_AO_CHUNK, 256),), ((abi.OPT_AO_CHUNK, 512),),
+                    ((abi.OPT_INTERP_TILE_CAP, 224),), ((abi.OPT_INTERP_TILE_CAP, 0),), ((abi.OPT_AO_CHUNK, 256),), ((abi.OPT_AO_CHUNK, 512),),
                     ((abi.OPT_AO_CHUNK, 768),)):
         for fused in (False, True):
             got = run_gpu(case, params, fused=fused, options=options)
