@@ -205,6 +205,8 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_sums, sizeof(int) * chunk_sums_capacity(ncells)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_begins, sizeof(int) * chunk_table_capacity(ncells)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_meta, sizeof(int) * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wet_pos, sizeof(uint32_t) * wet_list_capacity(ncells)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trip, wet_list_capacity(ncells)));
     }
     int wet = 0, n = 0;
     HIP_TRY(ctx, build_chunk_table(ctx->stream, ctx->d_params, ctx->grid, mask, ctx->launch.cu_count, ctx->launch.ao_chunk,
@@ -217,6 +219,11 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
     ctx->chunk_valid = true;
     ctx->launch.d_chunk_begins = ctx->d_chunk_begins;
     ctx->launch.n_chunks = n;
+    int overflow = 0;
+    HIP_TRY(ctx, build_wet_lists(ctx->stream, ctx->d_params, ctx->grid, mask, n, ctx->d_chunk_begins, ctx->d_wet_pos, ctx->d_trip,
+                                 ctx->d_chunk_meta, &overflow));
+    ctx->launch.d_wet_pos = overflow ? nullptr : ctx->d_wet_pos;
+    ctx->launch.d_trip = ctx->trip_hints ? ctx->d_trip : nullptr;
     if (std::getenv("COFLUX_DEBUG"))
         std::fprintf(stderr, "[coflux] chunk table: %d chunks of %d wet cells (%d CUs)\n", n, wet, ctx->launch.cu_count);
     return CF_OK;
@@ -371,12 +378,6 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
         cf_destroy(ctx);
         return rc;
     }
-    const size_t hint_bytes = (size_t)ctx->grid.sj * (grid->ny + 2 * grid->hy);
-    if (hipMalloc((void**)&ctx->d_hint, hint_bytes) != hipSuccess || hipMemset(ctx->d_hint, 0, hint_bytes) != hipSuccess) {
-        cf_destroy(ctx);
-        return fail(nullptr, CF_ERR_HIP, "hipMalloc of the trip-count hints failed");
-    }
-    ctx->launch.d_hint = ctx->d_hint;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         ctx->launch.max_blocks = ((4 * prop.multiProcessorCount + 7) / 8) * 8;
@@ -409,7 +410,8 @@ int cf_destroy(cf_ctx* ctx) {
     if (ctx->peer_north_mapped) (void)hipIpcCloseMemHandle(ctx->peer.north);
     if (ctx->peer.mine) (void)hipFree(ctx->peer.mine);
     if (ctx->d_peer_status) (void)hipFree(ctx->d_peer_status);
-    if (ctx->d_hint) (void)hipFree(ctx->d_hint);
+    if (ctx->d_trip) (void)hipFree(ctx->d_trip);
+    if (ctx->d_wet_pos) (void)hipFree(ctx->d_wet_pos);
     if (ctx->d_chunk_sums) (void)hipFree(ctx->d_chunk_sums);
     if (ctx->d_chunk_begins) (void)hipFree(ctx->d_chunk_begins);
     if (ctx->d_chunk_meta) (void)hipFree(ctx->d_chunk_meta);
@@ -449,7 +451,11 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->launch.max_blocks = value;
             return CF_OK;
         case CF_OPT_TRIP_HINTS:
-            ctx->launch.d_hint = value ? ctx->d_hint : nullptr;
+            ctx->trip_hints = value != 0;
+            ctx->launch.d_trip = ctx->trip_hints ? ctx->d_trip : nullptr;
+            return CF_OK;
+        case CF_OPT_FUSED_NET:
+            ctx->fused_net = value != 0;
             return CF_OK;
         case CF_OPT_PROFILE_STRIDE:
             if (value < 1) return fail(ctx, CF_ERR_INVALID, "profile stride %d must be >= 1", value);
@@ -649,12 +655,20 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     if (!prefetched) HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     CHECK(wait_for_halos(ctx));  // the interpolation above overlapped the halo rows
-    HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes));
+    // Fused form: the cell-local part of compute_net_ocean_fluxes! (everything but the two face stresses, which
+    // need the west / south neighbour's ρτ) is computed in the solver's epilogue from registers, and a thin stress
+    // kernel follows — bitwise the same numbers as the three-launch sequence (shared arithmetic, contraction off).
+    const bool fuse = ctx->fused_net && ctx->launch.solver == CF_SOLVER_TABLES && ctx->dev.albedo_kind == CF_ALBEDO_CONSTANT;
+    HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes,
+                                  fuse ? ice : nullptr, fuse ? net : nullptr));
     // the next step's interpolation goes out behind the solver: its workgroups are dispatched first, the gather kernel
     // takes the registers and issue slots they leave free
     CHECK(cf_flush_deferred_prefetch(ctx));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
-    HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net));
+    if (fuse)
+        HIP_TRY(ctx, launch_net_stress(ctx->stream, ctx->dev, ctx->grid, ocean, fluxes, ice, net));
+    else
+        HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net));
     if (rec) {
         HIP_TRY(ctx, hipEventRecord(ev[3], ctx->stream));
         ++ctx->prof_count;

@@ -46,8 +46,11 @@ struct cf_ctx {
     hipStream_t stream = nullptr;
     LoopParams fast{};
     DevParams* d_params = nullptr;
-    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, 0, 256, nullptr, nullptr, nullptr, nullptr, 0};
-    uint8_t* d_hint = nullptr;
+    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, 0, 256, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    uint8_t* d_trip = nullptr;       // trip count of the previous call per wet-list entry
+    uint32_t* d_wet_pos = nullptr;   // static wet lists of the solver's chunks
+    bool trip_hints = true;
+    bool fused_net = false;          // cf_update_state: net fluxes in the solver's epilogue + a stress kernel (measured slower: off)
     // cost-balanced chunk table of the solver, rebuilt when the wet mask (pointer / kind / surface z) changes
     int* d_chunk_sums = nullptr;
     int* d_chunk_begins = nullptr;

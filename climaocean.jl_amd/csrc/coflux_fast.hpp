@@ -452,7 +452,9 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
                         pl = psi_small_mh(tab, inv_L < 0.0, zu, zq);
                     } else {
                         asm volatile("" ::: "memory");
-                        pl = psi_eval_mh(psi, psi_arg(zu), psi_arg(zq));
+                        // (the first iterates only: two plain 8-byte chains — fewer registers in flight than the paired form)
+                        pl.x = psi_eval(psi, 0, psi_arg(zu));
+                        pl.y = psi_eval(psi, 1, psi_arg(zq));
                     }
                     Du += pl.x;
                     Dq += pl.y;

@@ -143,4 +143,54 @@ __device__ __forceinline__ void store_fluxes(const FluxOut& F, size_t k, const C
     if (F.iters) F.iters[k] = R.iterations;
 }
 
+// ---------------------------------------------------------------------------------------------
+// compute_net_ocean_fluxes!, per cell.  Two kernels evaluate it — net_flux_kernel (coflux_net.hip) and the
+// solver's fused epilogue (coflux_solver.hip) — and must agree bit for bit, so the arithmetic lives here with
+// floating-point contraction switched off: every product and sum is rounded the same way wherever it is inlined.
+// ---------------------------------------------------------------------------------------------
+struct NetCell {
+    double JT, JS, sw, lw_up, lw_down, sw_down;
+};
+
+__device__ __forceinline__ NetCell net_cell_local(const DevParams& P, double alb, double aice, double So, double Ts_kelvin,
+                                                  double Mp, double Qs, double Ql, double Qc, double Qv, double Mv,
+                                                  double Qio, double Jsio) {
+#pragma clang fp contract(off)
+    NetCell C;
+    const double T2 = Ts_kelvin * Ts_kelvin;
+    const double Qu = P.emissivity * P.sigma * T2 * T2;
+    const double Qal = -P.emissivity * Ql;
+    const double Qts = -(1.0 - alb) * Qs * (1.0 - aice);
+    const double Qss = P.penetrating_sw ? 0.0 : Qts;
+    const double SQao = (Qu + Qc + Qv + Qal) * (1.0 - aice) + Qss;
+    const double SFao = -Mp * P.rho_f_inv + Mv * P.rho_f_inv;
+    const double SFs = (So < P.S_min && SFao < 0.0) ? 0.0 : SFao;
+    const double roc = P.rho_o_inv * P.c_o_inv;
+    C.JT = SQao * roc + Qio * roc;
+    C.JS = (1.0 - aice) * (-So * SFs) + Jsio;
+    C.sw = Qts * roc;
+    C.lw_up = Qu;
+    C.lw_down = -Qal;
+    C.sw_down = -Qts;
+    return C;
+}
+
+// kinematic stress at a face from the two adjacent cell-centre stresses ρτ and the ice cover on the face
+__device__ __forceinline__ double net_face_stress(const DevParams& P, double rho_tau_a, double rho_tau_b, double aice_a,
+                                                  double aice_b, double tau_io) {
+#pragma clang fp contract(off)
+    const double tao = 0.5 * (rho_tau_a + rho_tau_b) * P.rho_o_inv;
+    const double a = 0.5 * (aice_a + aice_b);
+    return (1.0 - a) * tao + a * tau_io;
+}
+
+__device__ __forceinline__ void store_net_cell(const NetOut& N, size_t k, const NetCell& C) {
+    N.T[k] = C.JT;
+    N.S[k] = C.JS;
+    if (N.sw) N.sw[k] = C.sw;
+    if (N.lw_up) N.lw_up[k] = C.lw_up;
+    if (N.lw_down) N.lw_down[k] = C.lw_down;
+    if (N.sw_down) N.sw_down[k] = C.sw_down;
+}
+
 }  // namespace coflux

@@ -18,16 +18,23 @@ struct LaunchCfg {
     int cu_count;            // compute units of the device (sizes the automatic chunk)
     const double* d_tables;  // device copy of the solver tables (coflux_tables.cpp)
     const DevParams* d_params;  // device copy of DevParams (the solver stages it in LDS)
-    uint8_t* d_hint;            // per-cell trip count of the previous call (scheduling hint) or NULL
+    uint8_t* d_trip;            // per-wet-cell trip count of the previous call (scheduling hint) or NULL
     const int* d_chunk_begins;  // cost-balanced chunk table of the solver (coflux_solver.hip), n_chunks + 1 entries
     int n_chunks;
+    const uint32_t* d_wet_pos;  // static wet lists of the chunks, fixed stride (coflux_solver.hip), or NULL
 };
 
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
                               const cf_interp_weights* w, const cf_exchange_fields* e);
 hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
-                            const cf_interface_fluxes* f);
+                            const cf_interface_fluxes* f, const cf_sea_ice_fields* ice = nullptr,
+                            const cf_net_ocean_fluxes* net = nullptr);
+hipError_t launch_net_stress(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
+                             const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* n);
+hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks,
+                           const int* d_begins, uint32_t* d_wet_pos, uint8_t* d_trip, int* d_scratch, int* overflow_out);
+size_t wet_list_capacity(int ncells);
 hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                                  const cf_exchange_fields* e, const cf_interface_fluxes* f);
 hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,

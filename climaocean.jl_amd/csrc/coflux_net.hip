@@ -26,49 +26,50 @@ __global__ __launch_bounds__(NET_BLOCK) void net_flux_kernel(DevParams P, GridDe
     const double aice = I.conc ? I.conc[k] : 0.0;
     const double aice_w = I.conc ? I.conc[kw] : 0.0;
     const double aice_s = I.conc ? I.conc[ks] : 0.0;
-    const double So = O.S[k];
-    const double Ts = F.Ts[k] + P.T_offset;
-    const double Mp = E.Mp[k], Qs = E.Qs[k], Ql = E.Ql[k];
-    const double Qc = F.Qc[k], Qv = F.Qv[k], Mv = F.Fv[k];
 
     double alb = P.albedo;
     if (P.albedo_kind == CF_ALBEDO_LATITUDE_DEPENDENT) {
         double phi = Wt.separable ? Wt.latitude[j + G.hy] : Wt.latitude[k];
         alb = P.albedo_diffuse - P.albedo_direct * cos(2.0 * phi * (CF_PI / 180.0));
     }
-    const double T2 = Ts * Ts;
-    const double Qu = P.emissivity * P.sigma * T2 * T2;
-    const double Qal = -P.emissivity * Ql;
-    const double Qts = -(1.0 - alb) * Qs * (1.0 - aice);
-    const double Qss = P.penetrating_sw ? 0.0 : Qts;
-    const double SQao = (Qu + Qc + Qv + Qal) * (1.0 - aice) + Qss;
-
-    const double SFao = -Mp * P.rho_f_inv + Mv * P.rho_f_inv;
-    const double SFs = (So < P.S_min && SFao < 0.0) ? 0.0 : SFao;
-
-    const double Qio = I.Qio ? I.Qio[k] : 0.0;
-    const double Jsio = I.Jsio ? I.Jsio[k] : 0.0;
-    const double roc = P.rho_o_inv * P.c_o_inv;
-    const double JT = SQao * roc + Qio * roc;
-    const double JS = (1.0 - aice) * (-So * SFs) + Jsio;
-
-    const double txao = 0.5 * (F.tx[kw] + F.tx[k]) * P.rho_o_inv;
-    const double tyao = 0.5 * (F.ty[ks] + F.ty[k]) * P.rho_o_inv;
-    const double ax = 0.5 * (aice_w + aice), ay = 0.5 * (aice_s + aice);
-    const double txio = I.txio ? I.txio[k] : 0.0;
-    const double tyio = I.tyio ? I.tyio[k] : 0.0;
-
-    const double wf = wet ? 1.0 : 0.0;
-    N.u[k] = wf * ((1.0 - ax) * txao + ax * txio);
-    N.v[k] = wf * ((1.0 - ay) * tyao + ay * tyio);
-    N.T[k] = wf * JT;
-    N.S[k] = wf * JS;
-    if (N.sw) N.sw[k] = wf * Qts * roc;
-    if (N.lw_up) N.lw_up[k] = wf * Qu;
-    if (N.lw_down) N.lw_down[k] = wf * (-Qal);
-    if (N.sw_down) N.sw_down[k] = wf * (-Qts);
+    const NetCell C = net_cell_local(P, alb, aice, O.S[k], F.Ts[k] + P.T_offset, E.Mp[k], E.Qs[k], E.Ql[k], F.Qc[k], F.Qv[k],
+                                     F.Fv[k], I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0);
+    const double tx = net_face_stress(P, F.tx[kw], F.tx[k], aice_w, aice, I.txio ? I.txio[k] : 0.0);
+    const double ty = net_face_stress(P, F.ty[ks], F.ty[k], aice_s, aice, I.tyio ? I.tyio[k] : 0.0);
+    NetCell Z{};
+    N.u[k] = wet ? tx : 0.0;
+    N.v[k] = wet ? ty : 0.0;
+    store_net_cell(N, k, wet ? C : Z);
 }
 
+// The stresses alone: what is left of compute_net_ocean_fluxes! when the solver's epilogue has already written the
+// cell-local fluxes (cf_update_state's fused path).  Reads ρτ of the cell and of its west / south neighbour.
+__global__ __launch_bounds__(NET_BLOCK) void net_stress_kernel(DevParams P, GridDesc G, const void* mask,
+                                                               const double* __restrict__ rtx, const double* __restrict__ rty,
+                                                               IceIn I, double* __restrict__ tau_x, double* __restrict__ tau_y) {
+    const int ncells = G.nx * G.ny;
+    const int idx = (int)blockIdx.x * NET_BLOCK + (int)threadIdx.x;
+    if (idx >= ncells) return;
+    const int j = idx / G.nx;
+    const size_t k = cell_index(G, idx - j * G.nx, j);
+    const size_t kw = k - 1, ks = k - (size_t)G.sj;
+    const bool wet = cell_is_wet(P, mask, k);
+    const double aice = I.conc ? I.conc[k] : 0.0;
+    const double tx = net_face_stress(P, rtx[kw], rtx[k], I.conc ? I.conc[kw] : 0.0, aice, I.txio ? I.txio[k] : 0.0);
+    const double ty = net_face_stress(P, rty[ks], rty[k], I.conc ? I.conc[ks] : 0.0, aice, I.tyio ? I.tyio[k] : 0.0);
+    tau_x[k] = wet ? tx : 0.0;
+    tau_y[k] = wet ? ty : 0.0;
+}
+
+hipError_t launch_net_stress(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
+                             const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* n) {
+    IceIn I{};
+    if (ice) I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress};
+    const int ncells = G.nx * G.ny;
+    hipLaunchKernelGGL(net_stress_kernel, dim3((ncells + NET_BLOCK - 1) / NET_BLOCK), dim3(NET_BLOCK), 0, st, P, G, o->mask,
+                       f->x_momentum, f->y_momentum, I, n->u, n->v);
+    return hipGetLastError();
+}
 
 hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_exchange_fields* e, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,

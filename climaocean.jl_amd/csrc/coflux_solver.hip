@@ -19,7 +19,7 @@ constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 constexpr int AO_BLOCK = 256;
 constexpr int AO_CHUNK = 1024;  // capacity of a workgroup's wet-cell list = the most wet cells a chunk can hold
 constexpr int AO_BINS = 32;    // trip-count bins of the per-chunk counting sort
-constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + 16 + 2 * AO_BINS * 4;
+constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + AO_CHUNK * 2 + 16 + 2 * AO_BINS * 4;
 constexpr int AO_LDS_BYTES = AO_PARAMS_OFFSET + (int)sizeof(DevParams);
 static_assert(AO_LDS_BYTES <= 53760, "three solver workgroups must fit the CU's 160 KB of LDS");
 
@@ -165,7 +165,9 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
     const long need = total > 0 ? total : 1;
     if (forced_wet_per_chunk > 0) {
         add_round(forced_wet_per_chunk, chunks(need, forced_wet_per_chunk), true);  // forced uniform size
-    } else if (need <= cap(256)) {
+    } else if (need <= 3 * cap(256)) {
+        // small surface (a slab of a strongly scaled run): every chunk resident at once, one batch per wave — the
+        // kernel is as long as its slowest batch, so nothing may queue behind anything
         add_round(256, chunks(need, 256), true);
     } else if (need <= cap(512)) {
         add_round(512, chunks(need, 512), true);
@@ -212,32 +214,169 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
 int chunk_table_capacity(int ncells) { return (int)(((long)ncells * AO_WET_COST) / (256L * AO_WET_COST)) + 16; }
 int chunk_sums_capacity(int ncells) { return (ncells + CT_CELLS - 1) / CT_CELLS + 1; }
 
+// ---------------------------------------------------------------------------------------------
+// Static wet lists.  The wet mask is static, so besides the chunk boundaries the builder also writes, once per
+// mask, every chunk's wet cells in index order (wet_pos, 4 B per wet cell) and the prefix of the chunks' wet
+// counts (wet_start).  A per-wet-cell byte array (trip) carries each cell's iteration count from one call to the
+// next.  The solver's start phase is then two coalesced loads per thread and a counting sort in LDS — no mask
+// reads, no index arithmetic, no dependent scattered loads while every workgroup of the device starts at once.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chunk_wet_fill_kernel(const DevParams* __restrict__ g_params, GridDesc G,
+                                                             const void* mask, const int* __restrict__ begins,
+                                                             uint32_t* __restrict__ wet_pos, int* __restrict__ overflow) {
+    __shared__ int wave_count[4];
+    const DevParams& P = *g_params;
+    const int wx = G.nx + 2 * G.ring, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int begin = begins[blockIdx.x], end = begins[blockIdx.x + 1];
+    uint32_t* out = wet_pos + (size_t)blockIdx.x * AO_CHUNK;
+    int base = 0;
+    for (int strip = begin; strip < end; strip += 256) {  // index order: strips in order, waves in order, lanes in order
+        const int idx = strip + (int)threadIdx.x;
+        bool wet = false;
+        if (idx < end) {
+            const int jj = idx / wx;
+            wet = cell_is_wet(P, mask, cell_index(G, idx - jj * wx - G.ring, jj - G.ring));
+        }
+        const unsigned long long m = __ballot(wet);
+        if (lane == 0) wave_count[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_count[w];
+        const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (wet && p < AO_CHUNK) out[p] = (uint32_t)idx;
+        base += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        __syncthreads();
+    }
+    for (int p = base + (int)threadIdx.x; p < AO_CHUNK; p += 256) out[p] = 0xffffffffu;  // sentinel: no cell
+    if (threadIdx.x == 0 && base > AO_CHUNK) atomicAdd(overflow, 1);
+}
+
+// Chunk c's list occupies entries [c·AO_CHUNK, (c+1)·AO_CHUNK) of wet_pos / trip — a fixed stride, so the solver
+// needs no lookup before it can request its list.  *overflow_out != 0: some chunk holds more wet cells than a list
+// (cannot happen with the cost-balanced table; the solver then classifies per call).
+hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks,
+                           const int* d_begins, uint32_t* d_wet_pos, uint8_t* d_trip, int* d_scratch, int* overflow_out) {
+    hipError_t e = hipMemsetAsync(d_scratch, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(chunk_wet_fill_kernel, dim3(nchunks), dim3(256), 0, st, d_params, G, mask, d_begins, d_wet_pos, d_scratch);
+    if ((e = hipMemsetAsync(d_trip, 0, (size_t)nchunks * AO_CHUNK, st)) != hipSuccess) return e;
+    int overflow = 0;
+    if ((e = hipMemcpyAsync(&overflow, d_scratch, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    *overflow_out = overflow;
+    return hipGetLastError();
+}
+
+size_t wet_list_capacity(int ncells) { return (size_t)chunk_table_capacity(ncells) * AO_CHUNK; }
+
+// zero_interface_state of a land cell: all fluxes 0, T = 0 K (and, in the fused path, zero net fluxes inside the interior)
+template <bool FUSE_NET>
+__device__ __forceinline__ void zero_cell(const LoopParams& L, const DevParams& P, const GridDesc& G, const FluxOut& F,
+                                          const NetOut& N, size_t k, int i, int j) {
+    CellFluxes Z{};
+    Z.Ts_ocean = -P.T_offset;
+    Z.iterations = L.fixed ? L.maxiter : 0;
+    store_fluxes(F, k, Z);
+    if constexpr (FUSE_NET) {
+        if (i >= 0 && i < G.nx && j >= 0 && j < G.ny) store_net_cell(N, k, NetCell{});
+    }
+}
+
 // ---- production solver: LDS tables, one workgroup per chunk of the table above -----------------
-template <bool COARE, int SPEC>
-__global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(LoopParams L, GridDesc G, OceanIn O, Exchange E,
-                                                                FluxOut F, const double* __restrict__ g_tab,
-                                                                const DevParams* __restrict__ g_params,
-                                                                uint8_t* __restrict__ hint,
-                                                                const int* __restrict__ chunk_begins) {
-    // Land cells (≈30 % of a global grid) must not occupy lanes for 10–20 iterations: the chunk is first
-    // compacted to the list of its wet cells (land gets its zeros there and then), counting-sorted by the
-    // trip-count hint, and waves then pull 64 list entries at a time from an LDS cursor, so every lane that
-    // enters the solver holds an ocean cell and the lanes of a batch finish together.
+// LDS: tables | list of cell indices | list of wet positions | counters, histogram, bin cursors | DevParams
+constexpr int AO_LIST_E_OFFSET = TABLE_BYTES + AO_CHUNK * 4;
+constexpr int AO_COUNTERS_OFFSET = AO_LIST_E_OFFSET + AO_CHUNK * 2;
+
+struct WetLists {
+    const uint32_t* pos;    // wet cells of chunk c in index order at [c·AO_CHUNK, …), 0xffffffff-padded; nullptr: classify per call
+    uint8_t* trip;          // iteration count of the previous call per list entry (scheduling hint), or nullptr
+};
+
+// Everything the kernel is handed, as ONE by-value argument: the kernarg segment then IS this struct, and the
+// kernel reads its ≈ 40 pointers from there with scalar loads where it uses them (through a pointer the compiler
+// cannot see through, so that it reloads them per batch instead of hoisting 80 SGPRs' worth out of the loops and
+// spilling them into VGPR lanes — 185 SGPR spills and ≈ 300 v_readlane per batch were measured that way).  Only
+// the iteration's scalars (LoopParams) are copied into registers for the kernel's lifetime.
+struct SolverArgs {
+    LoopParams L;
+    GridDesc G;
+    OceanIn O;
+    Exchange E;
+    FluxOut F;
+    const double* g_tab;
+    const DevParams* g_params;
+    WetLists W;
+    const int* chunk_begins;
+    IceIn I;
+    NetOut N;
+};
+typedef const SolverArgs __attribute__((address_space(4)))* SolverArgsPtr;
+
+// by-value copy of a member of the kernarg struct: scalar loads of its 8-byte words
+template <class T>
+__device__ __forceinline__ T kread(const __attribute__((address_space(4))) T* p) {
+    static_assert(sizeof(T) % 8 == 0, "argument bundles are made of 8-byte words");
+    T v;
+    const __attribute__((address_space(4))) unsigned long long* src = (const __attribute__((address_space(4))) unsigned long long*)p;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&v);
+#pragma unroll
+    for (size_t n = 0; n < sizeof(T) / 8; ++n) dst[n] = src[n];
+    return v;
+}
+
+__device__ __forceinline__ SolverArgsPtr opaque(SolverArgsPtr p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+template <bool COARE, int SPEC, bool FUSE_NET>
+__global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
+    SolverArgsPtr K = opaque((SolverArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
+    const LoopParams L = kread(&K->L);
+    const GridDesc G = kread(&K->G);
+    const WetLists W = kread(&K->W);
+    const double* __restrict__ g_tab = K->g_tab;
+    const DevParams* __restrict__ g_params = K->g_params;
+    const int* __restrict__ chunk_begins = K->chunk_begins;
+    const void* mask = K->O.mask;
+    // Land cells (≈30 % of a global grid) must not occupy lanes for 10–20 iterations: a workgroup works on the
+    // LIST of its chunk's wet cells, counting-sorted by the trip count of the previous call (longest first), and
+    // its waves pull 64 list entries at a time from an LDS cursor, so every lane that enters the solver holds an
+    // ocean cell and the lanes of a batch finish together.  Land gets its zeros in a pass at the END of the
+    // workgroup's life (other workgroups' iterations hide it), which also re-counts the wet cells of the range:
+    // a mask rewritten in place makes the static list stale, the count or a listed cell gives it away, and the
+    // workgroup redoes its range by classifying it — a stale list costs time, never correctness.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tab = reinterpret_cast<double*>(smem);
     int* list = reinterpret_cast<int*>(smem + TABLE_BYTES);
-    int* counters = list + AO_CHUNK;  // [0] wet count, [1] cursor
+    unsigned short* list_e = reinterpret_cast<unsigned short*>(smem + AO_LIST_E_OFFSET);
+    int* counters = reinterpret_cast<int*>(smem + AO_COUNTERS_OFFSET);  // [0] wet count, [1] cursor, [2] wet cells seen, [3] stale
     int* hist = counters + 4;
     int* bin_start = hist + AO_BINS;
     DevParams* lp = reinterpret_cast<DevParams*>(smem + AO_PARAMS_OFFSET);
     const int tid = threadIdx.x, lane = tid & 63;
-    // Parameters first (ordinary loads), then the 47 KB of tables as LDS-DMA (global_load_lds, 1 KB per wave
-    // instruction, no VGPR round trip).  The tables are first read in the batch phase, two barriers later, so
-    // the first barrier below deliberately does NOT drain the DMA: the classification's own loads run while the
-    // tables stream in.
+    const int wx = G.nx + 2 * G.ring;
+    const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
+    bool use_static = W.pos != nullptr;
+    // Order of the start phase: (1) my share of the chunk's static list — entries tid, tid + 256, … of a fixed-stride
+    // array, so nothing has to be looked up first: coalesced 4-byte and 1-byte loads, consumed after the barrier;
+    // (2) the parameters (ordinary loads into LDS); (3) the 45 KB of tables as LDS-DMA (global_load_lds, 1 KB per wave
+    // instruction, no VGPR round trip).  Vector memory returns in issue order, so the list arrives ahead of the table
+    // stream, and the first barrier deliberately does NOT drain the DMA: the tables are first read in the batch phase.
+    constexpr int PER_THREAD = AO_CHUNK / AO_BLOCK;
+    int my_idx[PER_THREAD], my_trip[PER_THREAD];
+    if (use_static) {
+        const size_t base = (size_t)chunk * AO_CHUNK + tid;
+#pragma unroll
+        for (int n = 0; n < PER_THREAD; ++n) {
+            my_idx[n] = (int)W.pos[base + n * AO_BLOCK];
+            my_trip[n] = W.trip ? (int)W.trip[base + n * AO_BLOCK] : AO_BINS - 1;
+        }
+    }
+    const int range_begin = chunk_begins[chunk], range_end = chunk_begins[chunk + 1];
     for (int n = tid; n < (int)(sizeof(DevParams) / sizeof(double)); n += AO_BLOCK)
         reinterpret_cast<double*>(lp)[n] = reinterpret_cast<const double*>(g_params)[n];
-    if (tid < 2) counters[tid] = 0;
+    if (tid < 4) counters[tid] = 0;
     if (tid < AO_BINS) hist[tid] = 0;
     static_assert(TABLE_BYTES % 1024 == 0, "the table stage copies whole 1 KB pieces");
     {
@@ -251,34 +390,18 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(LoopParams L,
     const DevParams& P = *lp;  // prologue-only parameters live in LDS, not in SGPRs
     const double* logt = tab + LOG_OFFSET;
 
-    const int wx = G.nx + 2 * G.ring;
-    const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
-    const int range_end = chunk_begins[chunk + 1];
-    int begin = chunk_begins[chunk], end = range_end;
-    bool first_piece = true;
-    for (;;) {
-        if (!first_piece) {
-            if (tid < 2) counters[tid] = 0;
-            if (tid < AO_BINS) hist[tid] = 0;
-            __syncthreads();
-        }
-        first_piece = false;
-        // ---- phase 1: classify, zero land, histogram of the trip-count hints -----------------------
-        // (the hint is the cell's iteration count in the previous call — fields evolve slowly from one
-        // coupled step to the next; it only orders the list and cannot change any result)
-        for (int idx = begin + tid; idx < end; idx += AO_BLOCK) {
-            const int jj = idx / wx;
-            const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
-            if (cell_is_wet(P, O.mask, k)) {
-                const int bin = hint ? AO_BINS - 1 - min((int)hint[k], AO_BINS - 1) : 0;  // longest first (LPT)
-                atomicAdd(&hist[bin], 1);
-            } else {  // zero_interface_state: all fluxes 0, T = 0 K
-                CellFluxes Z{};
-                Z.Ts_ocean = -P.T_offset;
-                Z.iterations = L.fixed ? L.maxiter : 0;
-                store_fluxes(F, k, Z);
+    int nwet = 0;
+    bool have_list = false;
+    if (use_static) {
+        // ---- counting sort of the static list by trip-count bin (all in LDS), longest first (LPT) ---------
+        bool dry = false;
+#pragma unroll
+        for (int n = 0; n < PER_THREAD; ++n)
+            if (my_idx[n] >= 0) {
+                atomicAdd(&hist[AO_BINS - 1 - min(my_trip[n], AO_BINS - 1)], 1);
+                const int jj = my_idx[n] / wx;  // the mask byte of every listed cell is requested now and looked at below
+                dry |= !cell_is_wet(P, mask, cell_index(G, my_idx[n] - jj * wx - G.ring, jj - G.ring));
             }
-        }
         __syncthreads();
         if (tid < 64) {  // exclusive scan of the AO_BINS (≤ 64) bin counts by one wave
             const int v = lane < AO_BINS ? hist[lane] : 0;
@@ -292,55 +415,159 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(LoopParams L,
             if (lane == 63) counters[0] = incl;
         }
         __syncthreads();
-        const int nwet = counters[0];
-        if (nwet > AO_CHUNK) {  // only with a stale chunk table: retry on a piece that cannot overflow the list
-            end = begin + AO_CHUNK;
-            __syncthreads();
-            continue;
-        }
-        // ---- phase 2: scatter the wet cells into their bins ----------------------------------------
-        for (int idx = begin + tid; idx < end; idx += AO_BLOCK) {
-            const int jj = idx / wx;
-            const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
-            if (cell_is_wet(P, O.mask, k)) {
-                const int bin = hint ? AO_BINS - 1 - min((int)hint[k], AO_BINS - 1) : 0;
-                list[atomicAdd(&bin_start[bin], 1)] = idx;
+#pragma unroll
+        for (int n = 0; n < PER_THREAD; ++n)
+            if (my_idx[n] >= 0) {
+                const int p = atomicAdd(&bin_start[AO_BINS - 1 - min(my_trip[n], AO_BINS - 1)], 1);
+                list[p] = my_idx[n];
+                list_e[p] = (unsigned short)(tid + n * AO_BLOCK);
+            }
+        // ---- land of the range gets its zeros; the same pass re-counts the wet cells: a mask rewritten in place
+        // makes the static list stale, the count or a listed cell gives it away (all of this hides under the table DMA)
+        int seen = 0;
+        {
+            SolverArgsPtr Kz = opaque(K);
+            const FluxOut F = kread(&Kz->F);
+            const NetOut N = kread(&Kz->N);
+            constexpr int LAND_UNROLL = 8;  // the mask bytes of eight strips are requested together
+            for (int base = range_begin + tid; base < range_end; base += AO_BLOCK * LAND_UNROLL) {
+                unsigned land = 0;  // bit n: strip n's cell is inside the range and dry
+#pragma unroll
+                for (int n = 0; n < LAND_UNROLL; ++n) {
+                    const int idx = base + n * AO_BLOCK;
+                    const int ic = min(idx, range_end - 1);
+                    const int jj = ic / wx;
+                    const bool w = cell_is_wet(P, mask, cell_index(G, ic - jj * wx - G.ring, jj - G.ring));
+                    if (idx < range_end) {
+                        seen += w ? 1 : 0;
+                        land |= w ? 0u : 1u << n;
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < LAND_UNROLL; ++n) {
+                    if (land & (1u << n)) {
+                        const int idx = base + n * AO_BLOCK;
+                        const int jj = idx / wx;
+                        const int i = idx - jj * wx - G.ring, j = jj - G.ring;
+                        zero_cell<FUSE_NET>(L, P, G, F, N, cell_index(G, i, j), i, j);
+                    }
+                }
             }
         }
+        for (int d = 32; d; d >>= 1) seen += __shfl_xor(seen, d);
+        if (lane == 0) atomicAdd(&counters[2], seen);
+        if (__any(dry) && lane == 0) atomicOr(&counters[3], 1);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the table DMA has landed
         __syncthreads();
-        // ---- phase 3: waves pull 64 wet cells at a time --------------------------------------------
-        // (requesting the next batch's inputs before iterating the current one was tried: +20 VGPRs cost the
-        // third wave per SIMD or spills, 107 → 122–142 µs)
+        nwet = counters[0];
+        have_list = counters[2] == nwet && counters[3] == 0;  // the list is the range's wet set
+        if (!have_list) {  // stale list: redo the range the slow way
+            use_static = false;
+            __syncthreads();
+            if (tid < 4) counters[tid] = 0;
+            __syncthreads();
+        }
+    }
+    int begin = range_begin, end = range_end;
+    for (;;) {
+        if (!have_list) {
+            // ---- no (valid) static list: classify the piece [begin, end), zero its land ------------------
+            for (int base = begin; base < end; base += AO_BLOCK) {
+                const int idx = base + tid;
+                bool wet = false;
+                if (idx < end) {
+                    const int jj = idx / wx;
+                    const int i = idx - jj * wx - G.ring, j = jj - G.ring;
+                    const size_t k = cell_index(G, i, j);
+                    wet = cell_is_wet(P, mask, k);
+                    if (!wet) {
+                        SolverArgsPtr Kz = opaque(K);
+                        const FluxOut F = kread(&Kz->F);
+                        const NetOut N = kread(&Kz->N);
+                        zero_cell<FUSE_NET>(L, P, G, F, N, k, i, j);
+                    }
+                }
+                const unsigned long long m = __ballot(wet);
+                int wave_base = 0;
+                if (lane == 0 && m) wave_base = atomicAdd(&counters[0], __popcll(m));
+                wave_base = __shfl(wave_base, 0);
+                if (wet) {
+                    const int p = wave_base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (p < AO_CHUNK) list[p] = idx;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the table DMA has landed
+            __syncthreads();
+            nwet = counters[0];
+            if (nwet > AO_CHUNK) {  // more wet cells than the list holds: retry on a piece that cannot overflow it
+                end = begin + AO_CHUNK;
+                __syncthreads();
+                if (tid < 2) counters[tid] = 0;
+                __syncthreads();
+                continue;
+            }
+        }
+        // ---- waves pull 64 wet cells at a time ---------------------------------------------------------
         for (;;) {
             int start = 0;
             if (lane == 0) start = atomicAdd(&counters[1], 64);
             start = __shfl(start, 0);
             if (start >= nwet) break;
-            const int e = start + lane;
-            const bool in_range = e < nwet;
-            const int idx = list[in_range ? e : nwet - 1];
-            const int jj = idx / wx;
-            const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+            const int q = start + lane;
+            const bool in_range = q < nwet;
+            const int qc = in_range ? q : nwet - 1;
+            CellConsts c;
+            double So;
+            {
+                const int idx = list[qc];
+                const int jj = idx / wx;
+                const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+                SolverArgsPtr Kb = opaque(K);  // this batch's view of the arguments: pointers are (re)loaded here, scalar loads
             // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
-            const double uo = 0.5 * (O.u[k] + O.u[k + 1]);
-            const double vo = 0.5 * (O.v[k] + O.v[k + (size_t)G.sj]);
-            const CellConsts c = cell_prologue(P, L.min_gust, logt, E.u[k], E.v[k], E.T[k], E.p[k], E.q[k], uo, vo,
-                                               O.T[k], O.S[k]);
+            const double* __restrict__ Ou = Kb->O.u;
+            const double* __restrict__ Ov = Kb->O.v;
+            const double uo = 0.5 * (Ou[k] + Ou[k + 1]);
+            const double vo = 0.5 * (Ov[k] + Ov[k + (size_t)G.sj]);
+                So = Kb->O.S[k];
+                c = cell_prologue(P, L.min_gust, logt, Kb->E.u[k], Kb->E.v[k], Kb->E.T[k], Kb->E.p[k], Kb->E.q[k], uo, vo,
+                                  Kb->O.T[k], So);
+            }
             Scales s;
             if constexpr (SPEC == SOLVER_LY)
                 s = ly_iterate(L, c, tab);
             else
                 s = mo_iterate<COARE, SPEC>(L, c, tab, in_range);
             if (in_range) {
-                store_fluxes(F, k, cell_epilogue(c, P.T_offset, s));
-                if (hint) hint[k] = (uint8_t)min(s.it, 255);
+                SolverArgsPtr Ke = opaque(K);
+                // (cell coordinates recomputed from the list entry: cheaper than four registers held across the iteration)
+                const int idx2 = list[qc];
+                const int jj2 = idx2 / wx;
+                const int ci = idx2 - jj2 * wx - G.ring, cj = jj2 - G.ring;
+                const size_t k = cell_index(G, ci, cj);
+                const CellFluxes R = cell_epilogue(c, P.T_offset, s);
+                {
+                    const FluxOut F = kread(&Ke->F);
+                    store_fluxes(F, k, R);
+                }
+                if (use_static && W.trip) W.trip[(size_t)chunk * AO_CHUNK + list_e[qc]] = (uint8_t)min(s.it, 255);
+                if constexpr (FUSE_NET) {
+                    // compute_net_ocean_fluxes!, the part that needs no neighbour: interior cells only
+                    if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {
+                        const IceIn I = kread(&Ke->I);
+                        const NetOut N = kread(&Ke->N);
+                        store_net_cell(N, k, net_cell_local(P, P.albedo, I.conc ? I.conc[k] : 0.0, So, R.Ts_ocean + P.T_offset,
+                                                            Ke->E.Mp[k], Ke->E.Qs[k], Ke->E.Ql[k], R.Qc, R.Qv, R.Fv,
+                                                            I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0));
+                    }
+                }
             }
         }
-        if (end >= range_end) break;
-        begin = end;  // stale-table path: the rest of the range
+        if (use_static || end >= range_end) break;  // no barrier at the end: a wave that runs out of batches retires
+        begin = end;  // classification path: the rest of the range
         end = range_end;
         __syncthreads();  // list and counters are reused
+        if (tid < 2) counters[tid] = 0;
+        __syncthreads();
     }
 }
 
@@ -378,42 +605,47 @@ __global__ void debug_eval_kernel(int fn, int n, const double* __restrict__ x, d
 }
 
 
-template <bool COARE>
+template <bool COARE, bool FUSE>
 static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const LoopParams& C, const GridDesc& G,
-                           const OceanIn& O, const Exchange& E, const FluxOut& F) {
+                           const OceanIn& O, const Exchange& E, const FluxOut& F, const IceIn& I, const NetOut& N) {
+    const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip}, L.d_chunk_begins, I, N};
+#define CF_LAUNCH(COARE_, SPEC_) \
+    hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, FUSE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A)
     switch (C.specialization) {
-        case SOLVER_OCEAN:
-            hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_OCEAN>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O,
-                               E, F, L.d_tables, L.d_params, L.d_hint, L.d_chunk_begins);
-            break;
-        case SOLVER_ICE:
-            hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_ICE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O, E,
-                               F, L.d_tables, L.d_params, L.d_hint, L.d_chunk_begins);
-            break;
-        case SOLVER_LY:
-            hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_LY>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G, O, E,
-                               F, L.d_tables, L.d_params, L.d_hint, L.d_chunk_begins);
-            break;
-        default:
-            hipLaunchKernelGGL((ao_flux_fast_kernel<COARE, SOLVER_GENERIC>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, C, G,
-                               O, E, F, L.d_tables, L.d_params, L.d_hint, L.d_chunk_begins);
+        case SOLVER_OCEAN: CF_LAUNCH(COARE, SOLVER_OCEAN); break;
+        case SOLVER_ICE: CF_LAUNCH(COARE, SOLVER_ICE); break;
+        case SOLVER_LY: CF_LAUNCH(true, SOLVER_LY); break;
+        default: CF_LAUNCH(COARE, SOLVER_GENERIC);
     }
+#undef CF_LAUNCH
 }
 
+// `net` != nullptr: the fused form — the solver's epilogue also writes the cell-local net ocean fluxes (JT, JS,
+// shortwave, diagnostics; constant ocean albedo only), leaving the face stresses to launch_net_stress.
 hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
-                            const cf_interface_fluxes* f) {
-    if (L.solver == CF_SOLVER_LIBM) return launch_ao_fluxes_libm(st, P, G, o, e, f);
+                            const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net) {
+    if (L.solver == CF_SOLVER_LIBM) return net ? hipErrorInvalidValue : launch_ao_fluxes_libm(st, P, G, o, e, f);
     OceanIn O = make_ocean(o);
     Exchange E = make_exchange(e);
     FluxOut F = make_fluxes(f);
+    IceIn I{};
+    if (ice) I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress};
+    NetOut N{};
+    if (net)
+        N = NetOut{net->u, net->v, net->T, net->S, net->shortwave_surface_flux, net->upwelling_longwave,
+                   net->downwelling_longwave, net->downwelling_shortwave};
     // one workgroup per chunk of the cost-balanced table: the hardware dispatcher is the dynamic load balancer
     if (!L.d_chunk_begins || L.n_chunks <= 0) return hipErrorInvalidValue;
     dim3 grid(L.n_chunks);
-    if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
-        launch_ao_spec<true>(st, grid, L, C, G, O, E, F);
-    else
-        launch_ao_spec<false>(st, grid, L, C, G, O, E, F);
+    const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
+    if (net) {
+        if (coare) launch_ao_spec<true, true>(st, grid, L, C, G, O, E, F, I, N);
+        else launch_ao_spec<false, true>(st, grid, L, C, G, O, E, F, I, N);
+    } else {
+        if (coare) launch_ao_spec<true, false>(st, grid, L, C, G, O, E, F, I, N);
+        else launch_ao_spec<false, false>(st, grid, L, C, G, O, E, F, I, N);
+    }
     return hipGetLastError();
 }
 

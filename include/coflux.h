@@ -330,6 +330,10 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 #define CF_OPT_AO_CHUNK 4         /* wet cells per workgroup of the flux solver: 256, 512, 768 or 0 = automatic */
 #define CF_OPT_PROFILE_STRIDE 5   /* cf_profile_enable: bracket only every n-th cf_update_state with events (1); the event
                                      records between the kernels cost ≈ 4 µs of stream time each               */
+#define CF_OPT_FUSED_NET 6        /* 1: cf_update_state computes the cell-local net ocean fluxes in the solver's epilogue and
+                                     follows with a face-stress kernel; 0 (default): the three-launch sequence.  Bitwise the
+                                     same results; measured SLOWER on MI355X (the epilogue's nine extra scattered 8-byte
+                                     accesses per cell cost the solver 18 µs and save 14 µs of net-flux kernel). */
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path, LDS-tabulated ψ/log, ≤1e-12 of libm */
 #define CF_SOLVER_LIBM 1    /* same iteration on ocml's libm (slow; cross-check)                     */
 int cf_set_option(cf_ctx* ctx, int option, int value);

@@ -20,25 +20,25 @@ for label in ("default", "fixed0", "fixed12"):
     for _ in range(5): ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
     ms = ctx.time_stage(abi.STAGE_AO_FLUXES, 20, ocean=ocean, atmos=atmos, fluxes=fluxes)
     ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
-    NWG = int(os.environ.get('NWG', '760'))
+    NWG = int(os.environ.get('NWG', '752'))
     n = NWG * 4 * 8
     out = (C.c_ulonglong * n)()
     ctx.lib.cf_debug_phase_read(out, n)
     raw = np.array(out, dtype=np.float64).reshape(NWG * 4, 8)
-    st = raw[:, :4]
-    d = np.diff(st, axis=1)            # per-wave durations (counters have per-XCD bases: only differences are meaningful)
-    total = st[:, 3] - st[:, 0]
-    tick = total.max() / (ms * 1e3)    # ticks per µs, assuming the longest-lived wave spans the kernel
+    tick = (raw[:, 6] - raw[:, 0]).max() / (ms * 1e3)    # ticks per µs, assuming the longest-lived wave spans the kernel
     print(f"{label}: kernel {ms*1e3:.1f} us; {tick:.1f} ticks/us")
-    for q, name in enumerate(("stage tables + sync", "classify + sort", "batches (load/prologue/iterate/store)")):
+    st = raw[:, [0, 1, 2, 3, 6]]
+    d = np.diff(st, axis=1)
+    total = st[:, 4] - st[:, 0]
+    for q, name in enumerate(("entry -> first barrier (params, list loads issued)", "sort + table DMA landed", "batches (load/prologue/iterate/store)", "land pass + validation")):
         a_ = d[:, q] / tick
-        print(f"   {name:40s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
-    for nm, v in (("  classify: own pass-1 loop", raw[:, 6] - raw[:, 1]), ("  classify: wait at sync + bin scan", raw[:, 7] - raw[:, 6]), ("  classify: scatter pass + sync", raw[:, 2] - raw[:, 7])):
+        print(f"   {name:52s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
+    for nm, v in (("   entry -> list loads issued", raw[:, 4] - raw[:, 0]), ("   list loads issued -> params + DMA issued", raw[:, 5] - raw[:, 4]), ("   wait lgkm + barrier", raw[:, 1] - raw[:, 5])):
         a_ = v / tick
-        print(f"   {nm:40s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
+        print(f"   {nm:52s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
     a_ = total / tick
     print(f"   {'wave lifetime':40s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
-    wg_life = (st[:, 3].reshape(NWG, 4).max(axis=1) - st[:, 0].reshape(NWG, 4).min(axis=1)) / tick
+    wg_life = (st[:, 4].reshape(NWG, 4).max(axis=1) - st[:, 0].reshape(NWG, 4).min(axis=1)) / tick
     wave_b = d[:, 2].reshape(NWG, 4) / tick
     print("   WG lifetime by XCD (blockIdx % 8): " + " ".join(f"{np.median(wg_life[x::8]):.0f}/{wg_life[x::8].max():.0f}" for x in range(8)))
     order = np.arange(NWG)

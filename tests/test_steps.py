@@ -217,3 +217,23 @@ def test_fold_north_halo_matches_host_fold(rows):
         fold_north_halo_torch(t, nx, ny, H, H, rows, loc, sg)
         np.testing.assert_array_equal(d.cpu().numpy(), t.numpy())
     ctx.close()
+
+
+def test_fused_net_epilogue_is_bitwise_the_three_launch_sequence():
+    """CF_OPT_FUSED_NET: cell-local net fluxes in the solver's epilogue + the face-stress kernel == the separate
+    compute_net_ocean_fluxes! kernel, bit for bit (shared arithmetic with contraction off), with and without sea ice."""
+    ctx, states, src, w, np_states = _setup()
+    ice = {k: ctx.to_device(np_states[0]["ice_" + k]) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")}
+    for use_ice in (None, ice):
+        outs = []
+        for fused in (0, 1):
+            ctx.set_option(abi.OPT_FUSED_NET, fused)
+            a, fl, net = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+            ctx.update_state(src, w, states[0], a, fl, net, ice=use_ice, time_fraction=0.37)
+            ctx.sync()
+            outs.append((fl, net))
+        for k in FLUX_NAMES:
+            assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+        for k in NET_NAMES:
+            assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+    ctx.close()
