@@ -68,6 +68,16 @@ def main():
                                        penetrating=False, ice=ice, latitude2d=case["ocean"]["latitude"])
             for k, v in net.items():
                 out[f"net_ice.{name}.{k}"] = v
+    # the same inputs as plain .npy files for climaocean.jl_amd/julia/oracle_dump.jl (Julia reads .npy with twenty lines
+    # of code, a zipped .npz would need a package): run THERE, it writes tests/golden/upstream/*.npy
+    inp = os.path.join(HERE, "upstream_inputs")
+    os.makedirs(inp, exist_ok=True)
+    for k in ("T", "S", "u", "v", "mask"):
+        np.save(os.path.join(inp, f"ocean_{k}.npy"), np.ascontiguousarray(case["ocean"][k], dtype=np.float64))
+    for k, v in atmos.items():
+        np.save(os.path.join(inp, f"atmos_{k}.npy"), np.ascontiguousarray(v, dtype=np.float64))
+    np.save(os.path.join(inp, "latitude.npy"), np.ascontiguousarray(w["latitude"], dtype=np.float64))
+    np.save(os.path.join(inp, "shape.npy"), np.array([NX, NY, H, RING], dtype=np.float64))
     path = os.path.join(HERE, "flux_path_24x12.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
