@@ -125,7 +125,25 @@ class NetSeaIceFluxes(C.Structure):
 
 
 class SeaIceState(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("concentration", "thickness", "top_temperature", "u", "v", "albedo")]
+    _fields_ = [(n, C.c_void_p) for n in ("concentration", "thickness", "top_temperature", "u", "v", "albedo",
+                                          "snow_thickness")]
+
+
+class SeaIceAlbedoParams(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_double) for n in (
+        "ice_visible", "ice_near_infrared", "snow_visible", "snow_near_infrared", "ocean_albedo", "reference_thickness",
+        "melt_temperature_range", "ice_melt_change", "snow_melt_change_visible", "snow_melt_change_near_infrared",
+        "snow_patch_thickness", "visible_fraction", "melting_temperature")]
+
+
+class IceOceanParams(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_double) for n in (
+        "heat_transfer_coefficient", "salt_transfer_coefficient", "minimum_friction_velocity", "ice_density",
+        "latent_heat_of_fusion", "ice_salinity", "liquidus_slope", "top_cell_thickness", "time_step")]
+
+
+class IceOceanFluxes(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("interface_heat", "salt_flux", "frazil_heat", "friction_velocity")]
 
 
 class NetOceanFluxes(C.Structure):
@@ -170,6 +188,8 @@ EXPORTED_SYMBOLS = (
     "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
     "cf_peer_halo_export", "cf_peer_halo_connect", "cf_halo_exchange_rows_peer", "cf_fold_north_halo",
     "cf_time_steps", "cf_prefetch_atmosphere_state",
+    "cf_default_sea_ice_albedo_params", "cf_set_sea_ice_albedo", "cf_compute_sea_ice_albedo",
+    "cf_default_ice_ocean_params", "cf_compute_sea_ice_ocean_fluxes",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
     "cf_window_upload", "cf_window_find", "cf_window_source",
 )
@@ -256,6 +276,12 @@ def load_library(path=None):
         vp, C.c_int64, C.c_int, C.POINTER(RunSchedule), C.POINTER(AtmosSource), C.POINTER(InterpWeights),
         C.POINTER(InterfaceFluxes), C.POINTER(SeaIceFields), C.POINTER(NetOceanFluxes)]
     lib.cf_prefetch_atmosphere_state.argtypes = [vp, C.POINTER(AtmosSource), C.POINTER(InterpWeights), C.POINTER(ExchangeFields)]
+    lib.cf_default_sea_ice_albedo_params.argtypes = [C.POINTER(SeaIceAlbedoParams)]
+    lib.cf_set_sea_ice_albedo.argtypes = [vp, C.POINTER(SeaIceAlbedoParams)]
+    lib.cf_compute_sea_ice_albedo.argtypes = [vp, C.POINTER(SeaIceAlbedoParams), vp, vp, vp, vp]
+    lib.cf_default_ice_ocean_params.argtypes = [C.POINTER(IceOceanParams)]
+    lib.cf_compute_sea_ice_ocean_fluxes.argtypes = [vp, C.POINTER(IceOceanParams), C.POINTER(OceanSurface), vp, vp, vp,
+                                                    C.POINTER(IceOceanFluxes)]
     lib.cf_window_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.cf_window_destroy.argtypes = [vp]
     lib.cf_window_host_buffer.argtypes = [vp, C.c_int32, C.c_int32]

@@ -286,6 +286,68 @@ class SeaIceInterfaceProperties:
         return p
 
 
+@dataclass
+class MomentumBasedFrictionVelocity:
+    """u★ from the actual ice–ocean stress (omip_simulation.jl:74-77)."""
+    minimum: float = 0.0
+
+
+@dataclass
+class ThreeEquationHeatFlux:
+    """ThreeEquationHeatFlux(; friction_velocity = MomentumBasedFrictionVelocity()) — corrected_ice_ocean_heat_flux(),
+    omip_simulation.jl:71-77.  Coefficients are the recalled ClimaSeaIce defaults (UNVERIFIED)."""
+    friction_velocity: MomentumBasedFrictionVelocity = field(default_factory=MomentumBasedFrictionVelocity)
+    heat_transfer_coefficient: float = 0.0095
+    salt_transfer_coefficient: float = 0.0095 / 35.0
+    ice_density: float = 917.0
+    latent_heat_of_fusion: float = 334000.0
+    ice_salinity: float = 4.0
+    liquidus_slope: float = 0.054
+
+    def to_params(self, top_cell_thickness, time_step):
+        import ctypes
+        p = abi.IceOceanParams()
+        p.struct_size = ctypes.sizeof(abi.IceOceanParams)
+        for name in ("heat_transfer_coefficient", "salt_transfer_coefficient", "ice_density", "latent_heat_of_fusion",
+                     "ice_salinity", "liquidus_slope"):
+            setattr(p, name, getattr(self, name))
+        p.minimum_friction_velocity = self.friction_velocity.minimum
+        p.top_cell_thickness, p.time_step = float(top_cell_thickness), float(time_step)
+        return p
+
+
+def corrected_ice_ocean_heat_flux():
+    """omip_simulation.jl:77."""
+    return ThreeEquationHeatFlux()
+
+
+@dataclass
+class SeaIceAlbedo:
+    """SeaIceAlbedo(hi, hs, Ts) — the CCSM3 albedo of atmosphere.jl:30-44; it reads the sea-ice model's live thickness,
+    snow thickness and top temperature, which here are the PrescribedSeaIce fields."""
+    ice_visible: float = 0.78
+    ice_near_infrared: float = 0.36
+    snow_visible: float = 0.98
+    snow_near_infrared: float = 0.70
+    ocean_albedo: float = 0.06
+    reference_thickness: float = 0.3
+    melt_temperature_range: float = 1.0
+    ice_melt_change: float = 0.075
+    snow_melt_change_visible: float = 0.10
+    snow_melt_change_near_infrared: float = 0.15
+    snow_patch_thickness: float = 0.02
+    visible_fraction: float = 0.5
+    melting_temperature: float = 0.0
+
+    def to_params(self):
+        import ctypes
+        p = abi.SeaIceAlbedoParams()
+        p.struct_size = ctypes.sizeof(abi.SeaIceAlbedoParams)
+        for f in self.__dataclass_fields__:
+            setattr(p, f, getattr(self, f))
+        return p
+
+
 def _roughness_block(r, scalar):
     b = abi.Roughness()
     if isinstance(r, (int, float)):

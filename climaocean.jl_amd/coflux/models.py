@@ -262,6 +262,7 @@ class PrescribedSeaIce:
     v: Optional[torch.Tensor] = None
     albedo: Optional[torch.Tensor] = None
     frazil_heat: Optional[torch.Tensor] = None
+    snow_thickness: Optional[torch.Tensor] = None            # sea_ice.model.snow_thickness (atmosphere.jl:34)
 
     def fields(self):
         return {k: getattr(self, k) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")
@@ -272,7 +273,7 @@ class PrescribedSeaIce:
 
     def surface_state(self):
         st = dict(concentration=self.concentration, thickness=self.thickness, top_temperature=self.top_surface_temperature)
-        for k in ("u", "v", "albedo"):
+        for k in ("u", "v", "albedo", "snow_thickness"):
             if getattr(self, k) is not None:
                 st[k] = getattr(self, k)
         return st
@@ -288,7 +289,8 @@ class ComponentInterfaces:
     def __init__(self, atmosphere, ocean, sea_ice=None, *, radiation=None, atmosphere_ocean_fluxes=None,
                  atmosphere_sea_ice_fluxes=None, atmosphere_ocean_velocity_difference=None,
                  atmosphere_sea_ice_velocity_difference=None, sea_ice_properties=None, ocean_minimum_salinity=0.0,
-                 ocean_properties=None, store_similarity_scales=False):
+                 ocean_properties=None, store_similarity_scales=False, sea_ice_ocean_heat_flux=None,
+                 sea_ice_albedo=None, time_step=20 * minutes):
         grid = ocean.grid
         (nx, ny, _), (hx, hy, _) = grid.size, grid.halo
         self.radiation = radiation or Radiation()
@@ -329,6 +331,17 @@ class ComponentInterfaces:
             net_ice = ctx.field_set(("top_heat", "bottom_heat"))
             self.net_fluxes.sea_ice = SimpleNamespace(**net_ice)
             self.net_fluxes._sea_ice_fields = net_ice
+            # SurfaceRadiationProperties(SeaIceAlbedo(hi, hs, Ts), 1.0), atmosphere.jl:39-44
+            if sea_ice_albedo is not None:
+                ctx.set_sea_ice_albedo(sea_ice_albedo.to_params())
+        # sea_ice_ocean_heat_flux = ThreeEquationHeatFlux(...) (omip_simulation.jl:145,154): the ice–ocean exchange and
+        # frazil are then computed here each step instead of being taken from the sea-ice component
+        self.sea_ice_ocean_heat_flux = None
+        if sea_ice is not None and sea_ice_ocean_heat_flux is not None:
+            dz = (grid.z[1] - grid.z[0]) / grid.size[2]
+            self.sea_ice_ocean_heat_flux = sea_ice_ocean_heat_flux
+            self.ice_ocean_params = sea_ice_ocean_heat_flux.to_params(dz, time_step)
+            self.sea_ice_ocean_fluxes = ctx.field_set(("interface_heat", "salt_flux", "frazil_heat", "friction_velocity"))
 
 
 class OceanSeaIceModel:
@@ -351,6 +364,13 @@ def update_state(model):
     """update_state!(coupled_model) — the accelerated path."""
     itf, atm = model.interfaces, model.atmosphere
     src, n1, n2, frac = atm.source(itf.context, model.clock.time)
+    if model.sea_ice is not None and itf.sea_ice_ocean_heat_flux is not None:
+        # compute_sea_ice_ocean_fluxes!: the three-equation exchange and frazil from the current ocean surface and the
+        # ice–ocean stress; its outputs ARE the partition's interface_heat / salt_flux and the ice's frazil heat
+        si, f = model.sea_ice, itf.sea_ice_ocean_fluxes
+        itf.context.compute_sea_ice_ocean_fluxes(itf.ice_ocean_params, model.ocean.surface_state(), si.concentration,
+                                                 si.x_stress, si.y_stress, f)
+        si.interface_heat, si.salt_flux, si.frazil_heat = f["interface_heat"], f["salt_flux"], f["frazil_heat"]
     ice = model.sea_ice.fields() if model.sea_ice is not None else None
     if itf.atmosphere_sea_ice_interface is not None:
         # the ocean path, then compute_atmosphere_sea_ice_fluxes! + compute_net_sea_ice_fluxes! in one ABI call; the

@@ -172,7 +172,7 @@ class FluxContext:
 
     def compute_atmosphere_sea_ice_fluxes(self, ice_state, ocean, atmos, fluxes):
         st = self._struct(abi.SeaIceState, ice_state,
-                          ("concentration", "thickness", "top_temperature", "u", "v", "albedo"))
+                          ("concentration", "thickness", "top_temperature", "u", "v", "albedo", "snow_thickness"))
         o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
         self._check(self.lib.cf_compute_atmosphere_sea_ice_fluxes(self._h, C.byref(st), C.byref(o), C.byref(e),
                                                                   C.byref(f)),
@@ -180,7 +180,7 @@ class FluxContext:
 
     def compute_net_sea_ice_fluxes(self, ice_state, ocean, atmos, ai_fluxes, out, frazil_heat=None, interface_heat=None):
         """compute_net_sea_ice_fluxes!: out = dict(top_heat=…, bottom_heat=…)."""
-        st = self._struct(abi.SeaIceState, ice_state, ("concentration", "albedo"))
+        st = self._struct(abi.SeaIceState, ice_state, ("concentration", "thickness", "top_temperature", "albedo", "snow_thickness"))
         o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(ai_fluxes)
         n = self._struct(abi.NetSeaIceFluxes, out, ("top_heat", "bottom_heat"))
         self._check(self.lib.cf_compute_net_sea_ice_fluxes(
@@ -188,6 +188,36 @@ class FluxContext:
             frazil_heat.data_ptr() if frazil_heat is not None else None,
             interface_heat.data_ptr() if interface_heat is not None else None, C.byref(n)),
             "cf_compute_net_sea_ice_fluxes")
+
+    def default_sea_ice_albedo_params(self):
+        p = abi.SeaIceAlbedoParams()
+        self._check(self.lib.cf_default_sea_ice_albedo_params(C.byref(p)), "cf_default_sea_ice_albedo_params")
+        return p
+
+    def set_sea_ice_albedo(self, params=None):
+        """SeaIceAlbedo(hi, hs, Ts) (CCSM3, atmosphere.jl:30-44) wherever the sea-ice state carries no albedo field."""
+        self._check(self.lib.cf_set_sea_ice_albedo(self._h, C.byref(params) if params is not None else None),
+                    "cf_set_sea_ice_albedo")
+
+    def compute_sea_ice_albedo(self, params, thickness, snow_thickness, top_temperature, out):
+        self._check(self.lib.cf_compute_sea_ice_albedo(self._h, C.byref(params), _ptr(thickness), _ptr(snow_thickness),
+                                                       _ptr(top_temperature), _ptr(out)), "cf_compute_sea_ice_albedo")
+
+    def default_ice_ocean_params(self, **kw):
+        p = abi.IceOceanParams()
+        self._check(self.lib.cf_default_ice_ocean_params(C.byref(p)), "cf_default_ice_ocean_params")
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def compute_sea_ice_ocean_fluxes(self, params, ocean, concentration, x_stress, y_stress, out):
+        """compute_sea_ice_ocean_fluxes!: ThreeEquationHeatFlux(MomentumBasedFrictionVelocity) + frazil
+        (omip_simulation.jl:71-77).  out: dict interface_heat, salt_flux[, frazil_heat, friction_velocity]."""
+        o = self.ocean_struct(ocean)
+        f = self._struct(abi.IceOceanFluxes, out, ("interface_heat", "salt_flux", "frazil_heat", "friction_velocity"))
+        self._check(self.lib.cf_compute_sea_ice_ocean_fluxes(self._h, C.byref(params), C.byref(o), _ptr(concentration),
+                                                             _ptr(x_stress), _ptr(y_stress), C.byref(f)),
+                    "cf_compute_sea_ice_ocean_fluxes")
 
     def compute_net_ocean_fluxes(self, ocean, atmos, fluxes, net, ice=None, weights=None):
         o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
@@ -219,7 +249,7 @@ class FluxContext:
         o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
         i = self.ice_struct(ice)
         n = self.net_struct(net)
-        st = self._struct(abi.SeaIceState, ice_state, ("concentration", "thickness", "top_temperature", "u", "v", "albedo"))
+        st = self._struct(abi.SeaIceState, ice_state, ("concentration", "thickness", "top_temperature", "u", "v", "albedo", "snow_thickness"))
         af = self.fluxes_struct(ai_fluxes)
         ni = self._struct(abi.NetSeaIceFluxes, net_ice, ("top_heat", "bottom_heat"))
         self._check(self.lib.cf_update_state_sea_ice(

@@ -415,6 +415,7 @@ int cf_destroy(cf_ctx* ctx) {
     if (ctx->d_chunk_sums) (void)hipFree(ctx->d_chunk_sums);
     if (ctx->d_chunk_begins) (void)hipFree(ctx->d_chunk_begins);
     if (ctx->d_chunk_meta) (void)hipFree(ctx->d_chunk_meta);
+    if (ctx->d_ice_albedo) (void)hipFree(ctx->d_ice_albedo);
     if (ctx->d_ice_tables) (void)hipFree(ctx->d_ice_tables);
     if (ctx->d_ice_params) (void)hipFree(ctx->d_ice_params);
     if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
@@ -876,13 +877,115 @@ int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, co
     return CF_OK;
 }
 
-int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, const cf_ocean_surface* ocean,
+int cf_default_sea_ice_albedo_params(cf_sea_ice_albedo_params* p) {
+    if (!p) return fail(nullptr, CF_ERR_INVALID, "params is NULL");
+    std::memset(p, 0, sizeof *p);
+    p->struct_size = (int32_t)sizeof *p;
+    p->ice_visible = 0.78;
+    p->ice_near_infrared = 0.36;
+    p->snow_visible = 0.98;
+    p->snow_near_infrared = 0.70;
+    p->ocean_albedo = 0.06;
+    p->reference_thickness = 0.3;
+    p->melt_temperature_range = 1.0;
+    p->ice_melt_change = 0.075;
+    p->snow_melt_change_visible = 0.10;
+    p->snow_melt_change_near_infrared = 0.15;
+    p->snow_patch_thickness = 0.02;
+    p->visible_fraction = 0.5;
+    p->melting_temperature = 0.0;
+    return CF_OK;
+}
+
+static int check_albedo_params(cf_ctx* ctx, const cf_sea_ice_albedo_params* p) {
+    if (p->struct_size != (int32_t)sizeof(cf_sea_ice_albedo_params))
+        return fail(ctx, CF_ERR_INVALID, "cf_sea_ice_albedo_params.struct_size = %d, library expects %zu", p->struct_size,
+                    sizeof(cf_sea_ice_albedo_params));
+    if (!(p->reference_thickness > 0) || !(p->melt_temperature_range > 0) || !(p->snow_patch_thickness > 0) ||
+        !(p->visible_fraction >= 0 && p->visible_fraction <= 1))
+        return fail(ctx, CF_ERR_INVALID, "sea-ice albedo: reference thickness, melt range, snow patch must be > 0, visible fraction in [0,1]");
+    return CF_OK;
+}
+
+int cf_set_sea_ice_albedo(cf_ctx* ctx, const cf_sea_ice_albedo_params* params) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    if (!params) {
+        ctx->ice_albedo_ccsm3 = false;
+        return CF_OK;
+    }
+    CHECK(check_albedo_params(ctx, params));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_ice_albedo)
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ice_albedo, sizeof(double) * (size_t)ctx->grid.sj * (ctx->grid.ny + 2 * ctx->grid.hy)));
+    ctx->ice_albedo = *params;
+    ctx->ice_albedo_ccsm3 = true;
+    return CF_OK;
+}
+
+int cf_compute_sea_ice_albedo(cf_ctx* ctx, const cf_sea_ice_albedo_params* params, const double* d_hi, const double* d_hs,
+                              const double* d_Ts, double* d_albedo) {
+    if (!ctx || !params || !d_hi || !d_Ts || !d_albedo) return fail(ctx, CF_ERR_INVALID, "cf_compute_sea_ice_albedo: NULL argument");
+    CHECK(check_albedo_params(ctx, params));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_sea_ice_albedo(ctx->stream, *params, ctx->grid, d_hi, d_hs, d_Ts, d_albedo));
+    return CF_OK;
+}
+
+// the sea-ice state the kernels see: with the CCSM3 scheme switched on and no albedo field given, the library's own
+static int resolve_ice_albedo(cf_ctx* ctx, const cf_sea_ice_state* in, cf_sea_ice_state* out) {
+    *out = *in;
+    if (in->albedo || !ctx->ice_albedo_ccsm3) return CF_OK;
+    if (!in->thickness || !in->top_temperature) return fail(ctx, CF_ERR_INVALID, "SeaIceAlbedo(hi, hs, Ts) needs ice thickness and top temperature");
+    HIP_TRY(ctx, launch_sea_ice_albedo(ctx->stream, ctx->ice_albedo, ctx->grid, in->thickness, in->snow_thickness, in->top_temperature,
+                                       ctx->d_ice_albedo));
+    out->albedo = ctx->d_ice_albedo;
+    return CF_OK;
+}
+
+int cf_default_ice_ocean_params(cf_ice_ocean_params* p) {
+    if (!p) return fail(nullptr, CF_ERR_INVALID, "params is NULL");
+    std::memset(p, 0, sizeof *p);
+    p->struct_size = (int32_t)sizeof *p;
+    p->heat_transfer_coefficient = 0.0095;
+    p->salt_transfer_coefficient = 0.0095 / 35.0;
+    p->minimum_friction_velocity = 0.0;
+    p->ice_density = 917.0;
+    p->latent_heat_of_fusion = 334000.0;
+    p->ice_salinity = 4.0;
+    p->liquidus_slope = 0.054;
+    p->top_cell_thickness = 10.0;
+    p->time_step = 0.0;
+    return CF_OK;
+}
+
+int cf_compute_sea_ice_ocean_fluxes(cf_ctx* ctx, const cf_ice_ocean_params* params, const cf_ocean_surface* ocean,
+                                    const double* d_concentration, const double* d_x_stress, const double* d_y_stress,
+                                    const cf_ice_ocean_fluxes* out) {
+    if (!ctx || !params || !ocean || !ocean->T || !ocean->S || !out || !out->interface_heat || !out->salt_flux)
+        return fail(ctx, CF_ERR_INVALID, "cf_compute_sea_ice_ocean_fluxes: NULL argument");
+    if (params->struct_size != (int32_t)sizeof(cf_ice_ocean_params))
+        return fail(ctx, CF_ERR_INVALID, "cf_ice_ocean_params.struct_size = %d, library expects %zu", params->struct_size,
+                    sizeof(cf_ice_ocean_params));
+    if (!(params->heat_transfer_coefficient > 0) || !(params->salt_transfer_coefficient > 0) || !(params->liquidus_slope > 0) ||
+        !(params->latent_heat_of_fusion > 0))
+        return fail(ctx, CF_ERR_INVALID, "ice-ocean transfer coefficients, liquidus slope and latent heat must be > 0");
+    if (ctx->dev.mask_kind != CF_MASK_NONE && !ocean->mask) return fail(ctx, CF_ERR_INVALID, "ocean mask is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CHECK(wait_for_halos(ctx));
+    HIP_TRY(ctx, launch_sea_ice_ocean_fluxes(ctx->stream, ctx->dev, *params, ctx->grid, ocean, d_concentration, d_x_stress, d_y_stress, out));
+    return CF_OK;
+}
+
+int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice_in, const cf_ocean_surface* ocean,
                                          const cf_exchange_fields* atmos, const cf_interface_fluxes* out) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
-    if (!ice || !ice->thickness || !ice->top_temperature)
+    if (!ice_in || !ice_in->thickness || !ice_in->top_temperature)
         return fail(ctx, CF_ERR_INVALID, "sea-ice thickness and top temperature are NULL");
+    cf_sea_ice_state resolved;
+    CHECK(resolve_ice_albedo(ctx, ice_in, &resolved));
+    const cf_sea_ice_state* ice = &resolved;
     if (!ocean || !ocean->S) return fail(ctx, CF_ERR_INVALID, "ocean salinity is NULL");
     if (ctx->ice_dev.mask_kind != CF_MASK_NONE && !ocean->mask) return fail(ctx, CF_ERR_INVALID, "ocean mask is NULL");
     CHECK(check_exchange(ctx, atmos, true));
@@ -893,14 +996,17 @@ int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ic
     return CF_OK;
 }
 
-int cf_compute_net_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice, const cf_ocean_surface* ocean,
+int cf_compute_net_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice_in, const cf_ocean_surface* ocean,
                                   const cf_exchange_fields* atmos, const cf_interface_fluxes* ai_fluxes,
                                   const double* frazil_heat, const double* interface_heat,
                                   const cf_net_sea_ice_fluxes* out) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
-    if (!ice || !ice->concentration) return fail(ctx, CF_ERR_INVALID, "sea-ice concentration is NULL");
+    if (!ice_in || !ice_in->concentration) return fail(ctx, CF_ERR_INVALID, "sea-ice concentration is NULL");
+    cf_sea_ice_state resolved;
+    CHECK(resolve_ice_albedo(ctx, ice_in, &resolved));
+    const cf_sea_ice_state* ice = &resolved;
     if (!atmos || !atmos->Qs || !atmos->Ql) return fail(ctx, CF_ERR_INVALID, "downwelling radiation fields are NULL");
     if (!ai_fluxes || !ai_fluxes->sensible_heat || !ai_fluxes->latent_heat || !ai_fluxes->temperature)
         return fail(ctx, CF_ERR_INVALID, "atmosphere-sea-ice interface fluxes are NULL");

@@ -68,6 +68,9 @@ struct cf_ctx {
     DevParams ice_dev{};
     LoopParams ice_loop{};
     IceParams ice_kernel{};
+    bool ice_albedo_ccsm3 = false;   // cf_set_sea_ice_albedo: SeaIceAlbedo(hi, hs, Ts) wherever no albedo field is given
+    cf_sea_ice_albedo_params ice_albedo{};
+    double* d_ice_albedo = nullptr;  // the albedo field of the current step (computed by the library)
     double* d_ice_tables = nullptr;
     DevParams* d_ice_params = nullptr;
     // halo rows travel on their own stream so that they overlap the interpolation kernel, which

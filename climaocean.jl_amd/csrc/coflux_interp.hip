@@ -72,10 +72,11 @@ __global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S
             const size_t k = cell_index(G, ic, jc);
             const double fi = Wt.separable ? Wt.fi[ic + G.hx] : Wt.fi[k];
             const double fj = Wt.separable ? Wt.fj[jc + G.hy] : Wt.fj[k];
-            // Oceananigans `interpolator`: i⁻ = trunc(f), i⁺ = i⁻ + sign(f), ξ = f − i⁻
+            // Oceananigans `interpolator`: i⁻ = trunc(f), i⁺ = i⁻ + sign(f), ξ = mod(f, 1) ∈ [0, 1) — for a negative
+            // fractional index (a column west of the first source node) that is f − floor(f), not f − trunc(f)
             const double ti = trunc(fi), tj = trunc(fj);
-            xi[r] = fi - ti;
-            eta[r] = fj - tj;
+            xi[r] = fi - floor(fi);
+            eta[r] = fj - floor(fj);
             const int i0 = (int)ti;
             di[r] = fi > 0.0 ? 1 : (fi < 0.0 ? -1 : 0);
             const int ja = (int)tj;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void interpolate_gather_kernel(SourceDesc S, W
     const double fi = Wt.separable ? Wt.fi[i + G.hx] : Wt.fi[k];
     const double fj = Wt.separable ? Wt.fj[j + G.hy] : Wt.fj[k];
     const double ti = trunc(fi), tj = trunc(fj);
-    const double xi = fi - ti, eta = fj - tj;
+    const double xi = fi - floor(fi), eta = fj - floor(fj);  // ξ = mod(f, 1), see interpolate_kernel
     unsigned g00, g10, g01, g11;   // offsets inside one (level, variable) plane
     {
         const int i0 = (int)ti, ja = (int)tj;

@@ -143,6 +143,21 @@ __device__ __forceinline__ void store_fluxes(const FluxOut& F, size_t k, const C
     if (F.iters) F.iters[k] = R.iterations;
 }
 
+// SeaIceAlbedo(hi, hs, Ts) — CCSM3 (include/coflux.h: cf_sea_ice_albedo_params).  `A` are the parameters by value.
+__device__ __forceinline__ double ccsm3_albedo(const cf_sea_ice_albedo_params& A, double hi, double hs, double Ts) {
+    const double fh = fmin(atan(4.0 * hi) / atan(4.0 * A.reference_thickness), 1.0);
+    const double ao = A.ocean_albedo * (1.0 - fh);
+    // fT = 0 below (T_melt − ΔT), −1 at the melting point
+    const double fT = fmin((A.melting_temperature - Ts) / A.melt_temperature_range - 1.0, 0.0);
+    const double ice_v = fmax(A.ice_visible * fh + ao + A.ice_melt_change * fT, A.ocean_albedo);
+    const double ice_n = fmax(A.ice_near_infrared * fh + ao + A.ice_melt_change * fT, A.ocean_albedo);
+    const double snow_v = A.snow_visible + A.snow_melt_change_visible * fT;
+    const double snow_n = A.snow_near_infrared + A.snow_melt_change_near_infrared * fT;
+    const double as = hs > 0.0 ? hs / (hs + A.snow_patch_thickness) : 0.0;
+    const double v = ice_v * (1.0 - as) + snow_v * as, n = ice_n * (1.0 - as) + snow_n * as;
+    return A.visible_fraction * v + (1.0 - A.visible_fraction) * n;
+}
+
 // ---------------------------------------------------------------------------------------------
 // compute_net_ocean_fluxes!, per cell.  Two kernels evaluate it — net_flux_kernel (coflux_net.hip) and the
 // solver's fused epilogue (coflux_solver.hip) — and must agree bit for bit, so the arithmetic lives here with

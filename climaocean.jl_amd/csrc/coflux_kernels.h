@@ -55,6 +55,11 @@ hipError_t launch_net_sea_ice_fluxes(hipStream_t st, const DevParams& P, const G
                                      const cf_sea_ice_state* ice, double albedo, double emissivity, double eps_sigma,
                                      double T_offset, const cf_exchange_fields* e, const cf_interface_fluxes* f,
                                      const double* frazil, const double* interface_heat, const cf_net_sea_ice_fluxes* out);
+hipError_t launch_sea_ice_albedo(hipStream_t st, const cf_sea_ice_albedo_params& A, const GridDesc& G, const double* hi,
+                                 const double* hs, const double* Ts, double* out);
+hipError_t launch_sea_ice_ocean_fluxes(hipStream_t st, const DevParams& P, const cf_ice_ocean_params& Q, const GridDesc& G,
+                                       const cf_ocean_surface* o, const double* conc, const double* tx, const double* ty,
+                                       const cf_ice_ocean_fluxes* out);
 constexpr int SALINITY_PARTIAL_BLOCKS = 512;
 hipError_t launch_salinity_partial_sums(hipStream_t st, const DevParams& P, const GridDesc& G, const double* flux,
                                         const double* additional, const double* area, const void* mask, double* partial,

@@ -127,6 +127,76 @@ hipError_t launch_net_sea_ice_fluxes(hipStream_t st, const DevParams& P, const G
 }
 
 // =============================================================================================
+// SeaIceAlbedo(hi, hs, Ts): the CCSM3 albedo field (pointwise)
+// =============================================================================================
+__global__ __launch_bounds__(NET_BLOCK) void sea_ice_albedo_kernel(cf_sea_ice_albedo_params A, size_t n, const double* __restrict__ hi,
+                                                                   const double* __restrict__ hs, const double* __restrict__ Ts,
+                                                                   double* __restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * NET_BLOCK + threadIdx.x;
+    if (k < n) out[k] = ccsm3_albedo(A, hi[k], hs ? hs[k] : 0.0, Ts[k]);
+}
+
+hipError_t launch_sea_ice_albedo(hipStream_t st, const cf_sea_ice_albedo_params& A, const GridDesc& G, const double* hi,
+                                 const double* hs, const double* Ts, double* out) {
+    const size_t n = (size_t)G.sj * (G.ny + 2 * G.hy);
+    hipLaunchKernelGGL(sea_ice_albedo_kernel, dim3((unsigned)((n + NET_BLOCK - 1) / NET_BLOCK)), dim3(NET_BLOCK), 0, st, A, n, hi, hs,
+                       Ts, out);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// compute_sea_ice_ocean_fluxes!: ThreeEquationHeatFlux with momentum-based friction velocity + frazil (pointwise)
+// =============================================================================================
+__global__ __launch_bounds__(NET_BLOCK) void sea_ice_ocean_flux_kernel(DevParams P, cf_ice_ocean_params Q, GridDesc G, OceanIn O,
+                                                                       const double* __restrict__ conc,
+                                                                       const double* __restrict__ tx, const double* __restrict__ ty,
+                                                                       double* __restrict__ Qio, double* __restrict__ Jsio,
+                                                                       double* __restrict__ Qfr, double* __restrict__ ustar_out) {
+    const int ncells = G.nx * G.ny;
+    const int idx = (int)blockIdx.x * NET_BLOCK + (int)threadIdx.x;
+    if (idx >= ncells) return;
+    const int j = idx / G.nx;
+    const size_t k = cell_index(G, idx - j * G.nx, j);
+    double q_io = 0.0, j_io = 0.0, q_fr = 0.0, us = 0.0;
+    if (cell_is_wet(P, O.mask, k)) {
+        const double rho_o = 1.0 / P.rho_o_inv, c_o = 1.0 / P.c_o_inv;
+        const double So = O.S[k];
+        double To = O.T[k];
+        const double Tf = -Q.liquidus_slope * So;
+        if (Q.time_step > 0.0 && To < Tf) {  // frazil: the deficit below freezing is handed to the ice model
+            q_fr = rho_o * c_o * Q.top_cell_thickness * (To - Tf) / Q.time_step;
+            To = Tf;
+        }
+        const double a = conc ? conc[k] : 0.0;
+        if (a > 0.0) {
+            const double txc = tx ? 0.5 * (tx[k] + tx[k + 1]) : 0.0, tyc = ty ? 0.5 * (ty[k] + ty[k + (size_t)G.sj]) : 0.0;
+            us = fmax(sqrt(sqrt(txc * txc + tyc * tyc)), Q.minimum_friction_velocity);
+            // α_s (S_o − S_b) = (c_o α_h / ℒ)(T_o + m S_b)(S_b − S_i): the positive root of A S_b² + B S_b − C = 0
+            const double ah = Q.heat_transfer_coefficient, as = Q.salt_transfer_coefficient, m = Q.liquidus_slope;
+            const double g = c_o * ah / Q.latent_heat_of_fusion;
+            const double A = g * m, B = g * To - g * m * Q.ice_salinity + as, C = g * To * Q.ice_salinity + as * So;
+            const double Sb = (-B + sqrt(B * B + 4.0 * A * C)) / (2.0 * A);
+            const double Tb = -m * Sb;
+            q_io = a * rho_o * c_o * ah * us * (To - Tb);
+            j_io = a * as * us * (So - Sb);
+        }
+    }
+    Qio[k] = q_io;
+    Jsio[k] = j_io;
+    if (Qfr) Qfr[k] = q_fr;
+    if (ustar_out) ustar_out[k] = us;
+}
+
+hipError_t launch_sea_ice_ocean_fluxes(hipStream_t st, const DevParams& P, const cf_ice_ocean_params& Q, const GridDesc& G,
+                                       const cf_ocean_surface* o, const double* conc, const double* tx, const double* ty,
+                                       const cf_ice_ocean_fluxes* out) {
+    const int ncells = G.nx * G.ny;
+    hipLaunchKernelGGL(sea_ice_ocean_flux_kernel, dim3((ncells + NET_BLOCK - 1) / NET_BLOCK), dim3(NET_BLOCK), 0, st, P, Q, G,
+                       make_ocean(o), conc, tx, ty, out->interface_heat, out->salt_flux, out->frazil_heat, out->friction_velocity);
+    return hipGetLastError();
+}
+
+// =============================================================================================
 // NormalizeSalinity: area-weighted mean over wet interior cells, then subtract from the whole parent
 // =============================================================================================
 constexpr int RED_BLOCK = 256;

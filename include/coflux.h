@@ -443,8 +443,77 @@ typedef struct cf_sea_ice_state {
     const double* top_temperature;  /* previous skin temperature [°C]: initial guess of the iteration */
     const double* u;                /* ice velocity [m/s] or NULL (⇒ 0)                              */
     const double* v;
-    const double* albedo;           /* per-cell albedo (SeaIceAlbedo(hi, hs, Ts), atmosphere.jl:39) or NULL */
+    const double* albedo;           /* per-cell albedo or NULL: then cf_set_sea_ice_albedo's scheme, else the constant */
+    const double* snow_thickness;   /* hₛ [m] (sea_ice.model.snow_thickness, atmosphere.jl:34) or NULL (⇒ 0): read by the
+                                       CCSM3 albedo only                                                            */
 } cf_sea_ice_state;
+
+/* SeaIceAlbedo(hi, hs, Ts) — the CCSM3 sea-ice albedo the reference hands to SurfaceRadiationProperties
+ * (atmosphere.jl:30-44; "reads live model fields").  The scheme itself lives in NumericalEarth; restated from its
+ * source, Briegleb et al. 2004 (NCAR/TN-463) as implemented in CICE's `ccsm3` option: thickness-dependent bare-ice
+ * albedo  α_ice = α_cold·f_h + α_ocean·(1 − f_h),  f_h = min(atan(4 hᵢ)/atan(4 h_max), 1);  both ice and snow darken
+ * linearly over the last ΔT_melt below the melting point;  snow covers the fraction hₛ/(hₛ + h_patch);  the two
+ * spectral bands are averaged with `visible_fraction` (JRA55 carries one broadband rsds).                          */
+typedef struct cf_sea_ice_albedo_params {
+    int32_t struct_size;
+    int32_t reserved;
+    double ice_visible, ice_near_infrared;     /* 0.78, 0.36  cold, thick, bare ice                       */
+    double snow_visible, snow_near_infrared;   /* 0.98, 0.70  cold snow                                   */
+    double ocean_albedo;                       /* 0.06        limit of vanishing thickness                */
+    double reference_thickness;                /* 0.3 m       h_max                                       */
+    double melt_temperature_range;             /* 1 K         ΔT_melt                                     */
+    double ice_melt_change;                    /* 0.075       darkening of ice at the melting point       */
+    double snow_melt_change_visible;           /* 0.10                                                    */
+    double snow_melt_change_near_infrared;     /* 0.15                                                    */
+    double snow_patch_thickness;               /* 0.02 m                                                  */
+    double visible_fraction;                   /* 0.5         weight of the visible band in the broadband albedo [UNVERIFIED] */
+    double melting_temperature;                /* 0 °C        in the units of top_temperature             */
+} cf_sea_ice_albedo_params;
+int cf_default_sea_ice_albedo_params(cf_sea_ice_albedo_params* p);
+/* Switch the atmosphere–sea-ice interface and the net sea-ice fluxes to this scheme wherever cf_sea_ice_state.albedo
+ * is NULL (params = NULL: back to the constant albedo of cf_sea_ice_params).                                       */
+int cf_set_sea_ice_albedo(cf_ctx* ctx, const cf_sea_ice_albedo_params* params);
+/* The albedo field on its own (diagnostics, tests): d_albedo[k] = SeaIceAlbedo(hᵢ, hₛ, Tₛ) for every ocean-grid cell. */
+int cf_compute_sea_ice_albedo(cf_ctx* ctx, const cf_sea_ice_albedo_params* params, const double* d_ice_thickness,
+                              const double* d_snow_thickness /* may be NULL */, const double* d_top_temperature,
+                              double* d_albedo);
+
+/* compute_sea_ice_ocean_fluxes!(coupled_model) with ThreeEquationHeatFlux(; friction_velocity =
+ * MomentumBasedFrictionVelocity()) (omip_simulation.jl:71-77: "three-equation ice-ocean heat flux with momentum-based
+ * friction velocity computed from actual ice-ocean stress, McPhee 1992, 2008") and frazil formation.  Per wet cell:
+ *   u★   = max(√|τ_io|, u★_min),  τ_io the kinematic ice–ocean stress averaged from its faces to the cell centre;
+ *   frazil: T_o < T_f(S_o) = −m S_o  ⇒  Q_frazil = ρ_o c_o Δz (T_o − T_f)/Δt (< 0: heat the ice model must supply by
+ *           freezing), and the exchange below sees T_o = T_f;
+ *   three equations (Holland & Jenkins 1999; McPhee et al. 2008) for the interface (T_b, S_b) and melt rate w:
+ *           ρ_o c_o α_h u★ (T_o − T_b) = ρ_i ℒ w,   ρ_o α_s u★ (S_o − S_b) = ρ_i w (S_b − S_i),   T_b = −m S_b
+ *           ⇒ a quadratic in S_b that does not depend on u★;
+ *   Q_io = ℵ ρ_o c_o α_h u★ (T_o − T_b)  [W m⁻², positive = the ocean loses heat],
+ *   Jˢ_io = ℵ α_s u★ (S_o − S_b)         [g/kg m s⁻¹, positive = the ocean loses salt (melt water dilutes it)].
+ * The outputs are exactly the fields cf_sea_ice_fields.interface_heat / salt_flux and cf_compute_net_sea_ice_fluxes'
+ * frazil_heat / interface_heat take.  Coefficients marked UNVERIFIED are the recalled ClimaSeaIce defaults.          */
+typedef struct cf_ice_ocean_params {
+    int32_t struct_size;
+    int32_t reserved;
+    double heat_transfer_coefficient;   /* α_h = 0.0095 [UNVERIFIED]                                   */
+    double salt_transfer_coefficient;   /* α_s = α_h / 35 [UNVERIFIED]                                  */
+    double minimum_friction_velocity;   /* 0 m/s                                                        */
+    double ice_density;                 /* 917 kg m⁻³                                                   */
+    double latent_heat_of_fusion;       /* 334 000 J kg⁻¹                                               */
+    double ice_salinity;                /* 4 g/kg                                                       */
+    double liquidus_slope;              /* m = 0.054 K per g/kg                                         */
+    double top_cell_thickness;          /* Δz of the ocean's top cell [m] (frazil)                      */
+    double time_step;                   /* Δt [s] (frazil); ≤ 0 disables frazil                         */
+} cf_ice_ocean_params;
+int cf_default_ice_ocean_params(cf_ice_ocean_params* p);
+typedef struct cf_ice_ocean_fluxes {
+    double* interface_heat;   /* Q_io                                             */
+    double* salt_flux;        /* Jˢ_io                                            */
+    double* frazil_heat;      /* Q_frazil (may be NULL)                           */
+    double* friction_velocity;/* u★ (optional diagnostic, may be NULL)           */
+} cf_ice_ocean_fluxes;
+int cf_compute_sea_ice_ocean_fluxes(cf_ctx* ctx, const cf_ice_ocean_params* params, const cf_ocean_surface* ocean,
+                                    const double* d_concentration, const double* d_x_stress /* u-faces, kinematic */,
+                                    const double* d_y_stress /* v-faces */, const cf_ice_ocean_fluxes* out);
 
 /* `ice_fluxes` = the atmosphere_sea_ice_fluxes formulation (e.g. corrected_atmosphere_sea_ice_fluxes). */
 int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, const cf_sea_ice_params* ice);

@@ -512,7 +512,7 @@ int oracle_compute_atmosphere_ocean_fluxes(const cf_grid* g, const cf_flux_param
 static double interp_one(const float* data, int nsx, int nsy, int l1, int l2, double tf, double fi,
                          double fj) {
     double ti = trunc(fi), tj = trunc(fj);
-    double xi = fi - ti, eta = fj - tj;
+    double xi = fi - floor(fi), eta = fj - floor(fj); /* ξ = mod(fractional_idx, 1) ∈ [0, 1), also for negative indices */
     long i0 = (long)ti, j0 = (long)tj;
     long i1 = i0 + (fi > 0 ? 1 : (fi < 0 ? -1 : 0));
     long j1 = j0 + (fj > 0 ? 1 : (fj < 0 ? -1 : 0));
@@ -856,4 +856,71 @@ int oracle_max_threads(void) {
 #else
     return 1;
 #endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * SeaIceAlbedo(hi, hs, Ts) — CCSM3 (reference: atmosphere.jl:30-44 hands it to SurfaceRadiationProperties; the scheme
+ * is Briegleb et al. 2004, NCAR/TN-463, as CICE's `ccsm3` option states it).  [UPSTREAM-RECALL for the band average.]
+ * ---------------------------------------------------------------------------------------- */
+static double ccsm3_albedo(const cf_sea_ice_albedo_params* A, double hi, double hs, double Ts) {
+    double fh = fmin(atan(4.0 * hi) / atan(4.0 * A->reference_thickness), 1.0);   /* thickness dependence of bare ice */
+    double ocean_part = A->ocean_albedo * (1.0 - fh);
+    double fT = fmin((A->melting_temperature - Ts) / A->melt_temperature_range - 1.0, 0.0); /* 0 cold … −1 melting */
+    double ice_v = fmax(A->ice_visible * fh + ocean_part + A->ice_melt_change * fT, A->ocean_albedo);
+    double ice_n = fmax(A->ice_near_infrared * fh + ocean_part + A->ice_melt_change * fT, A->ocean_albedo);
+    double snow_v = A->snow_visible + A->snow_melt_change_visible * fT;
+    double snow_n = A->snow_near_infrared + A->snow_melt_change_near_infrared * fT;
+    double as = hs > 0.0 ? hs / (hs + A->snow_patch_thickness) : 0.0;              /* fractional snow cover */
+    double v = ice_v * (1.0 - as) + snow_v * as, n = ice_n * (1.0 - as) + snow_n * as;
+    return A->visible_fraction * v + (1.0 - A->visible_fraction) * n;
+}
+
+int oracle_sea_ice_albedo(const cf_sea_ice_albedo_params* A, long n, const double* hi, const double* hs,
+                          const double* Ts, double* out) {
+    for (long k = 0; k < n; ++k) out[k] = ccsm3_albedo(A, hi[k], hs ? hs[k] : 0.0, Ts[k]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * compute_sea_ice_ocean_fluxes! with ThreeEquationHeatFlux(; friction_velocity = MomentumBasedFrictionVelocity())
+ * (omip_simulation.jl:71-77) + frazil.  Three-equation interface model: Holland & Jenkins 1999 eqs. 1–3,
+ * McPhee et al. 2008; see include/coflux.h for the statement.  out arrays in ocean-grid layout, interior cells.
+ * ---------------------------------------------------------------------------------------- */
+int oracle_sea_ice_ocean_fluxes(const cf_grid* g, const cf_flux_params* P, const cf_ice_ocean_params* Q,
+                                const cf_ocean_surface* o, const double* conc, const double* tx, const double* ty,
+                                double* Qio, double* Jsio, double* Qfr, double* ustar) {
+    const double rho_o = P->ocean_reference_density, c_o = P->ocean_heat_capacity;
+    for (int j = 0; j < g->ny; ++j)
+        for (int i = 0; i < g->nx; ++i) {
+            size_t k = IDX(g, i, j);
+            double q_io = 0, j_io = 0, q_fr = 0, us = 0;
+            int wet = 1;
+            if (P->mask_kind == CF_MASK_U8 && o->mask) wet = ((const uint8_t*)o->mask)[k] != 0;
+            if (P->mask_kind == CF_MASK_BOTTOM_HEIGHT && o->mask) wet = !(P->ocean_surface_z <= ((const double*)o->mask)[k]);
+            if (wet) {
+                double So = o->S[k], To = o->T[k], Tf = -Q->liquidus_slope * So;
+                if (Q->time_step > 0.0 && To < Tf) {
+                    q_fr = rho_o * c_o * Q->top_cell_thickness * (To - Tf) / Q->time_step;
+                    To = Tf;
+                }
+                double a = conc ? conc[k] : 0.0;
+                if (a > 0.0) {
+                    double txc = tx ? 0.5 * (tx[k] + tx[IDX(g, i + 1, j)]) : 0.0;
+                    double tyc = ty ? 0.5 * (ty[k] + ty[IDX(g, i, j + 1)]) : 0.0;
+                    us = fmax(sqrt(sqrt(txc * txc + tyc * tyc)), Q->minimum_friction_velocity);
+                    double ah = Q->heat_transfer_coefficient, as = Q->salt_transfer_coefficient, m = Q->liquidus_slope;
+                    double gam = c_o * ah / Q->latent_heat_of_fusion;
+                    double A = gam * m, B = gam * To - gam * m * Q->ice_salinity + as, C = gam * To * Q->ice_salinity + as * So;
+                    double Sb = (-B + sqrt(B * B + 4.0 * A * C)) / (2.0 * A);
+                    double Tb = -m * Sb;
+                    q_io = a * rho_o * c_o * ah * us * (To - Tb);
+                    j_io = a * as * us * (So - Sb);
+                }
+            }
+            Qio[k] = q_io;
+            Jsio[k] = j_io;
+            if (Qfr) Qfr[k] = q_fr;
+            if (ustar) ustar[k] = us;
+        }
+    return 0;
 }

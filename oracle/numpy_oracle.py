@@ -412,7 +412,7 @@ def interpolate_atmosphere_state(src, fi2d, fj2d, level1, level2, tf, cos_rot=No
     nsx = src["tas"].shape[2]
     nsy = src["tas"].shape[1]
     ti, tj = np.trunc(fi2d), np.trunc(fj2d)
-    xi, eta = fi2d - ti, fj2d - tj
+    xi, eta = np.mod(fi2d, 1.0), np.mod(fj2d, 1.0)   # ξ = mod(fractional_idx, 1) ∈ [0, 1), also for negative indices
     i0, j0 = ti.astype(np.int64), tj.astype(np.int64)
     i1 = i0 + np.sign(fi2d).astype(np.int64)
     j1 = j0 + np.sign(fj2d).astype(np.int64)
@@ -479,3 +479,42 @@ def net_ocean_fluxes(ocean, atmos, fl, *, hx, hy, ocean_properties, albedo, emis
         full[C] = np.where(wet, a, 0.0)
         out[k] = full
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# sea-ice albedo (CCSM3) and the three-equation ice–ocean exchange — second, independently typed restatements
+# ---------------------------------------------------------------------------------------------
+def sea_ice_albedo(hi, hs, Ts, *, ice=(0.78, 0.36), snow=(0.98, 0.70), ocean=0.06, h_ref=0.3, dT=1.0, d_ice=0.075,
+                   d_snow=(0.10, 0.15), patch=0.02, visible_fraction=0.5, T_melt=0.0):
+    """SeaIceAlbedo(hi, hs, Ts): Briegleb et al. 2004 / CICE `ccsm3`."""
+    hs = np.zeros_like(hi) if hs is None else hs
+    fh = np.minimum(np.arctan(4 * hi) / np.arctan(4 * h_ref), 1.0)
+    fT = np.minimum((T_melt - Ts) / dT - 1.0, 0.0)
+    bands = []
+    for a_i, a_s, ds in zip(ice, snow, d_snow):
+        bare = np.maximum(a_i * fh + ocean * (1 - fh) + d_ice * fT, ocean)
+        cover = np.where(hs > 0, hs / (hs + patch), 0.0)
+        bands.append(bare * (1 - cover) + (a_s + ds * fT) * cover)
+    return visible_fraction * bands[0] + (1 - visible_fraction) * bands[1]
+
+
+def sea_ice_ocean_fluxes(To, So, conc, tau_x_c, tau_y_c, *, rho_o=1026.0, c_o=3991.86795711963, alpha_h=0.0095,
+                         alpha_s=0.0095 / 35, us_min=0.0, L=334000.0, S_i=4.0, m=0.054, dz=10.0, dt=0.0):
+    """Three-equation interface model + frazil on cell-centre inputs (kinematic stress components at the centre).
+    Returns Q_io, Js_io, Q_frazil, u★, S_b."""
+    Tf = -m * So
+    frz = (To < Tf) & (dt > 0)
+    Qfr = np.where(frz, rho_o * c_o * dz * (To - Tf) / (dt if dt > 0 else 1.0), 0.0)
+    T = np.where(frz, Tf, To)
+    us = np.maximum(np.sqrt(np.hypot(tau_x_c, tau_y_c)), us_min)
+    g = c_o * alpha_h / L
+    # roots of g·m·Sb² + (g·T − g·m·S_i + α_s)·Sb − (g·T·S_i + α_s·So) = 0 via numpy's polynomial solver per cell is slow;
+    # the closed form with the numerically stable choice of root:
+    A, B, Cc = g * m, g * T - g * m * S_i + alpha_s, g * T * S_i + alpha_s * So
+    disc = np.sqrt(B * B + 4 * A * Cc)
+    Sb = np.where(B >= 0, 2 * Cc / (B + disc), (-B + disc) / (2 * A))
+    Tb = -m * Sb
+    ice = conc > 0
+    Qio = np.where(ice, conc * rho_o * c_o * alpha_h * us * (T - Tb), 0.0)
+    Js = np.where(ice, conc * alpha_s * us * (So - Sb), 0.0)
+    return Qio, Js, Qfr, np.where(ice, us, 0.0), Sb

@@ -196,7 +196,7 @@ def compute_atmosphere_sea_ice_fluxes(g, params, ice_params, ice, ocean, atmos):
     a = {n: _f64(atmos[n]) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
     e = _exchange_struct(a)
     st = abi.SeaIceState()
-    for n in ("concentration", "thickness", "top_temperature", "u", "v", "albedo"):
+    for n in ("concentration", "thickness", "top_temperature", "u", "v", "albedo", "snow_thickness"):
         if ice.get(n) is not None:
             arr = _f64(ice[n])
             keep.append(arr)
@@ -233,6 +233,32 @@ def compute_net_sea_ice_fluxes(g, params, ice_params, ice, ocean, atmos, ai_flux
                                                C.byref(e), C.byref(f), _ptr(fr), _ptr(ih), _ptr(top), _ptr(bottom))
     assert rc == 0
     return dict(top_heat=top, bottom_heat=bottom)
+
+
+def sea_ice_albedo(params, thickness, snow_thickness, top_temperature):
+    """SeaIceAlbedo(hi, hs, Ts), CCSM3."""
+    lib = load()
+    hi, Ts = _f64(thickness), _f64(top_temperature)
+    hs = None if snow_thickness is None else _f64(snow_thickness)
+    out = np.zeros(hi.shape)
+    rc = lib.oracle_sea_ice_albedo(C.byref(params), C.c_long(hi.size), _ptr(hi), _ptr(hs), _ptr(Ts), _ptr(out))
+    assert rc == 0
+    return out
+
+
+def sea_ice_ocean_fluxes(g, params, ice_ocean_params, ocean, concentration, x_stress=None, y_stress=None):
+    """compute_sea_ice_ocean_fluxes!: dict interface_heat, salt_flux, frazil_heat, friction_velocity."""
+    lib, keep = load(), []
+    o = _ocean_struct(ocean, keep)
+    conc = None if concentration is None else _f64(concentration)
+    tx = None if x_stress is None else _f64(x_stress)
+    ty = None if y_stress is None else _f64(y_stress)
+    out = {n: np.zeros(_shape(g)) for n in ("interface_heat", "salt_flux", "frazil_heat", "friction_velocity")}
+    rc = lib.oracle_sea_ice_ocean_fluxes(C.byref(g), C.byref(params), C.byref(ice_ocean_params), C.byref(o), _ptr(conc),
+                                         _ptr(tx), _ptr(ty), _ptr(out["interface_heat"]), _ptr(out["salt_flux"]),
+                                         _ptr(out["frazil_heat"]), _ptr(out["friction_velocity"]))
+    assert rc == 0
+    return out
 
 
 def normalize_salinity_flux(g, params, flux, mask, additional=None, area=None):

@@ -227,6 +227,30 @@ def test_time_interpolation_endpoints_and_window_levels():
         np.testing.assert_array_equal(got["atmos"][k], got2["atmos"][k])
 
 
+def test_negative_fractional_indices_match_the_oracle():
+    """ξ = mod(f, 1) for raw fractional indices below zero (both interpolation kernels) — ADVICE r1."""
+    nsx, nsy = 16, 8
+    rng = np.random.default_rng(5)
+    src = {k: rng.normal(size=(2, nsy, nsx)).astype(np.float32) for k in abi.JRA55_VARIABLES}
+    nx, ny, h = 6, 4, 2
+    fi = np.array([-2.75, -1.5, -0.25, 0.0, 0.5, 1.25, 2.0, 3.5, 14.75, 15.5])
+    fj = np.array([-1.25, -0.5, 0.0, 0.75, 1.5, 6.5, 7.0, 7.5])
+    g = orc.make_grid(nx, ny, h, h, 1)
+    ref = orc.interpolate_atmosphere_state(g, src, dict(separable=True, fi=fi, fj=fj), 0, 1, 0.3)
+    for cap in (128, 0):
+        ctx = FluxContext(nx, ny, h, h, ic.flux_params())
+        ctx.set_option(abi.OPT_INTERP_TILE_CAP, cap)
+        dsrc = {k: ctx.to_device(v) for k, v in src.items()}
+        w = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj))
+        at = ctx.field_set(EXCHANGE_NAMES)
+        ctx.interpolate_atmosphere_state(dsrc, w, at, 0, 1, 0.3)
+        ctx.sync()
+        for k in EXCHANGE_NAMES:
+            np.testing.assert_allclose(util.window(at[k].cpu().numpy(), h, h, nx, ny, 1), util.window(ref[k], h, h, nx, ny, 1),
+                                       rtol=0, atol=1e-12, err_msg=f"cap {cap} {k}")
+        ctx.close()
+
+
 def test_bottom_height_mask_encoding():
     params = ic.flux_params(mask_kind=abi.MASK_BOTTOM_HEIGHT)
     case = util.build_case(90, 40)

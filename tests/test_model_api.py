@@ -192,3 +192,69 @@ def test_sliding_window_bookkeeping_without_a_gpu(monkeypatch, prefetch, n_slots
     assert len(reads) <= 16 + (n_slots if prefetch else 0)        # ≈ one read per 3-hourly snapshot crossed, no thrashing
     assert (atm._reader is not None) == (prefetch and n_slots > 2)
     atm.close()
+
+
+@pytest.mark.gpu
+def test_config3_with_three_equation_exchange_and_ccsm3_albedo():
+    """BASELINE config 3 with nothing supplied from outside: sea_ice_ocean_heat_flux = ThreeEquationHeatFlux(…) computes
+    Q_io, Jˢ_io and frazil from the ocean surface and the ice–ocean stress (omip_simulation.jl:71-77,145), the sea-ice
+    albedo is SeaIceAlbedo(hi, hs, Ts) from the live ice / snow fields (atmosphere.jl:30-44).  One update_state! against
+    the oracle's replay of the same sequence."""
+    import torch
+    nx, ny, nz, h = 90, 40, 10, 3
+    grid = cm.LatitudeLongitudeGrid(size=(nx, ny, nz), halo=(h, h, h), latitude=(-70, 70), z=(-3000, 0))
+    ocean = cm.ocean_simulation(grid)
+    state = syn.ocean_state(nx, ny, h, h)
+    state["T"] = np.where(state["ice_concentration"] > 0, np.minimum(state["T"], -1.5 - 0.5 * (state["S"] % 1.0)), state["T"])
+    cm.set_surface(ocean, T=state["T"], S=state["S"], u=state["u"], v=state["v"], mask=state["mask"])
+    ice_np = syn.sea_ice_state(nx, ny, h, h)
+    snow = 0.2 * (ice_np["albedo"] - 0.3)           # some deterministic snow cover, 0 … 0.12 m
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to("cuda")  # noqa: E731
+    sea_ice = cm.PrescribedSeaIce(concentration=dev(state["ice_concentration"]), x_stress=dev(state["ice_x_stress"]),
+                                  y_stress=dev(state["ice_y_stress"]), thickness=dev(ice_np["thickness"]),
+                                  top_surface_temperature=dev(ice_np["top_temperature"]), u=dev(ice_np["u"]),
+                                  v=dev(ice_np["v"]), snow_thickness=dev(snow))
+    snaps = syn.jra55_snapshots(2)
+    atmosphere = cm.JRA55PrescribedAtmosphere(snaps)
+    interfaces = cm.ComponentInterfaces(atmosphere, ocean, sea_ice,
+                                        atmosphere_ocean_fluxes=ic.corrected_atmosphere_ocean_fluxes(),
+                                        atmosphere_sea_ice_fluxes=ic.corrected_atmosphere_sea_ice_fluxes(),
+                                        sea_ice_ocean_heat_flux=ic.corrected_ice_ocean_heat_flux(),
+                                        sea_ice_albedo=ic.SeaIceAlbedo(), time_step=20 * cm.minutes, store_similarity_scales=True)
+    model = cm.OceanSeaIceModel(ocean, sea_ice, atmosphere=atmosphere, interfaces=interfaces)   # update_state! once
+
+    g = orc.make_grid(nx, ny, h, h, 1)
+    fi, fj, phi = grid.fractional_indices()
+    w = dict(separable=True, fi=fi, fj=fj, latitude=phi)
+    props = ic.OceanProperties(surface_z=grid.surface_z)
+    at = orc.interpolate_atmosphere_state(g, snaps, w, 0, 1, 0.0)
+    p_ao = ic.flux_params(ic.corrected_atmosphere_ocean_fluxes(), ocean=props)
+    Q = ic.corrected_ice_ocean_heat_flux().to_params(300.0, 1200.0)
+    io = orc.sea_ice_ocean_fluxes(g, p_ao, Q, state, state["ice_concentration"], state["ice_x_stress"], state["ice_y_stress"])
+    fl = orc.compute_atmosphere_ocean_fluxes(g, p_ao, state, at)
+    ice_fields = dict(concentration=state["ice_concentration"], interface_heat=io["interface_heat"], salt_flux=io["salt_flux"],
+                      x_stress=state["ice_x_stress"], y_stress=state["ice_y_stress"])
+    net = orc.compute_net_ocean_fluxes(g, p_ao, state, at, fl, ice=ice_fields, weights=w)
+    alb = orc.sea_ice_albedo(ic.SeaIceAlbedo().to_params(), ice_np["thickness"], snow, ice_np["top_temperature"])
+    p_ai = ic.flux_params(ic.corrected_atmosphere_sea_ice_fluxes(), ocean=props)
+    iprops = ic.SeaIceInterfaceProperties().to_params()
+    ice_state = dict(ice_np, concentration=state["ice_concentration"], albedo=alb)
+    ai = orc.compute_atmosphere_sea_ice_fluxes(g, p_ai, iprops, ice_state, state, at)
+    nsi = orc.compute_net_sea_ice_fluxes(g, p_ai, iprops, ice_state, state, at, ai, io["frazil_heat"], io["interface_heat"])
+
+    W = lambda a, r=0: util.window(a, h, h, nx, ny, r)  # noqa: E731
+    f = model.interfaces.sea_ice_ocean_fluxes
+    for k, scale in (("interface_heat", 1.0), ("salt_flux", 1e-7), ("frazil_heat", 1.0)):
+        assert util.rel_err(W(f[k].cpu().numpy()), W(io[k]), scale) < 1e-12, k
+    assert np.abs(W(io["interface_heat"])).max() > 1.0 and (W(io["frazil_heat"]) < 0).any()      # both mechanisms active
+    bc = ocean.model.top_boundary_conditions
+    for name, tensor in (("u", bc.u), ("v", bc.v), ("T", bc.T), ("S", bc.S)):
+        assert util.rel_err(W(tensor.cpu().numpy()), W(net[name]), util.FIELD_SCALE[name]) < 1e-9, name
+    got_ai = {k: W(getattr(model.interfaces.atmosphere_sea_ice_interface.fluxes, k).cpu().numpy(), 1) for k in util.ICE_FLUX_FIELDS}
+    got_ai["iterations"] = W(ai["iterations"], 1)
+    util.compare_ice_fluxes(got_ai, {k: W(ai[k], 1) for k in list(util.ICE_FLUX_FIELDS) + ["iterations"]}, 1e-9)
+    conv = W(ai["iterations"]) < 100
+    top = model.interfaces.net_fluxes.sea_ice.top_heat.cpu().numpy()
+    bot = model.interfaces.net_fluxes.sea_ice.bottom_heat.cpu().numpy()
+    assert util.rel_err(W(top)[conv], W(nsi["top_heat"])[conv], 1.0) < 1e-8
+    assert util.rel_err(W(bot), W(nsi["bottom_heat"]), 1.0) < 1e-12
