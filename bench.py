@@ -257,10 +257,21 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
+    settle = {}
+
     def timed(name):
         sched = schedule_for(name)
-        run_steps(name, sched, 0, warmup)
-        first, samples = warmup, []
+        # Clocks first: a cold device needs tens of milliseconds of work before it holds its sustained clock, and a
+        # 20-step region is 3 ms.  Untimed steps until ≈ 0.15 s have passed, then the W warm-up steps the caller asked
+        # for, then exactly K timed steps — so that --steps 20 and --steps 1000 measure the same machine state.
+        done, t_start = 0, time.perf_counter()
+        while time.perf_counter() - t_start < 0.15:
+            run_steps(name, sched, done, 50)
+            ctx.sync()
+            done += 50
+        settle[name] = done
+        run_steps(name, sched, done, warmup)
+        first, samples = done + warmup, []
         for _ in range(reps):
             barrier()
             t0 = time.perf_counter()
@@ -352,7 +363,7 @@ def main():
                                rows_per_rank=ny, halo_backend=best, halo_verified=(sorted(exchangers) if world > 1 else None),
                                halo_rows=ring_rows if world > 1 else 0, pipelined_interpolation=pipeline,
                                step_loop="cf_time_steps (C)" if (a.config == "ocean" and best != "torch") else "host"),
-                   repetitions=reps, ms_per_step_samples=[s / steps * 1e3 for s in samples],
+                   settle_steps=settle.get(best), repetitions=reps, ms_per_step_samples=[s / steps * 1e3 for s in samples],
                    halo_paths_ms_per_step={k: v[0] / steps * 1e3 for k, v in results.items()} if world > 1 else None,
                    # dominant kernel = compute_atmosphere_ocean_fluxes! (SURVEY.md §8d contract figure 128 B/cell)
                    roofline=roof("ao_flux_fast_kernel (compute_atmosphere_ocean_fluxes!)", BYTES_AO, cells_rank, ao_ms,
