@@ -11,6 +11,7 @@ COMM_ID_BYTES = 128
 PEER_HANDLE_BYTES = 64
 HALO_NONE, HALO_RCCL, HALO_PEER = 0, 1, 2
 FOLD_CENTER, FOLD_X_FACE, FOLD_Y_FACE = 0, 1, 2
+SKIN_EXPLICIT, SKIN_SEMI_IMPLICIT = 0, 1
 
 # enums (values from include/coflux.h)
 SIMILARITY_LOGARITHMIC, SIMILARITY_COARE_LOGARITHMIC = 0, 1
@@ -113,7 +114,7 @@ class SeaIceFields(C.Structure):
 
 
 class SeaIceParams(C.Structure):
-    _fields_ = [("struct_size", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("struct_size", C.c_int32), ("skin_temperature_scheme", C.c_int32),
                 ("conductivity", C.c_double), ("consolidation_thickness", C.c_double),
                 ("maximum_temperature_change", C.c_double), ("ice_salinity", C.c_double),
                 ("liquidus_slope", C.c_double), ("freshwater_melting_temperature", C.c_double),

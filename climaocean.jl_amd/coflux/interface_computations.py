@@ -275,13 +275,15 @@ class SeaIceInterfaceProperties:
     albedo: float = 0.7
     emissivity: float = 1.0                      # atmosphere.jl:44
     temperature_offset: float = 273.15
+    skin_temperature_scheme: int = 0             # abi.SKIN_EXPLICIT (as recalled) / abi.SKIN_SEMI_IMPLICIT (damped form)
 
     def to_params(self):
         import ctypes
         p = abi.SeaIceParams()
         p.struct_size = ctypes.sizeof(abi.SeaIceParams)
         for name in ("conductivity", "consolidation_thickness", "maximum_temperature_change", "ice_salinity",
-                     "liquidus_slope", "freshwater_melting_temperature", "albedo", "emissivity", "temperature_offset"):
+                     "liquidus_slope", "freshwater_melting_temperature", "albedo", "emissivity", "temperature_offset",
+                     "skin_temperature_scheme"):
             setattr(p, name, getattr(self, name))
         return p
 

@@ -207,6 +207,7 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_meta, sizeof(int) * 4));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wet_pos, sizeof(uint32_t) * wet_list_capacity(ncells)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trip, wet_list_capacity(ncells)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trip_ice, wet_list_capacity(ncells)));
     }
     int wet = 0, n = 0;
     HIP_TRY(ctx, build_chunk_table(ctx->stream, ctx->d_params, ctx->grid, mask, ctx->launch.cu_count, ctx->launch.ao_chunk,
@@ -223,6 +224,7 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
     HIP_TRY(ctx, build_wet_lists(ctx->stream, ctx->d_params, ctx->grid, mask, n, ctx->d_chunk_begins, ctx->d_wet_pos, ctx->d_trip,
                                  ctx->d_chunk_meta, &overflow));
     ctx->launch.d_wet_pos = overflow ? nullptr : ctx->d_wet_pos;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_trip_ice, 0, (size_t)n * 1024, ctx->stream));
     ctx->launch.d_trip = ctx->trip_hints ? ctx->d_trip : nullptr;
     if (std::getenv("COFLUX_DEBUG"))
         std::fprintf(stderr, "[coflux] chunk table: %d chunks of %d wet cells (%d CUs)\n", n, wet, ctx->launch.cu_count);
@@ -411,6 +413,7 @@ int cf_destroy(cf_ctx* ctx) {
     if (ctx->peer.mine) (void)hipFree(ctx->peer.mine);
     if (ctx->d_peer_status) (void)hipFree(ctx->d_peer_status);
     if (ctx->d_trip) (void)hipFree(ctx->d_trip);
+    if (ctx->d_trip_ice) (void)hipFree(ctx->d_trip_ice);
     if (ctx->d_wet_pos) (void)hipFree(ctx->d_wet_pos);
     if (ctx->d_chunk_sums) (void)hipFree(ctx->d_chunk_sums);
     if (ctx->d_chunk_begins) (void)hipFree(ctx->d_chunk_begins);
@@ -843,6 +846,8 @@ int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, co
     if (ice->struct_size != (int32_t)sizeof(cf_sea_ice_params))
         return fail(ctx, CF_ERR_INVALID, "cf_sea_ice_params.struct_size = %d, library expects %zu", ice->struct_size,
                     sizeof(cf_sea_ice_params));
+    if (ice->skin_temperature_scheme != CF_SKIN_EXPLICIT && ice->skin_temperature_scheme != CF_SKIN_SEMI_IMPLICIT)
+        return fail(ctx, CF_ERR_INVALID, "Unknown skin_temperature_scheme: %d", ice->skin_temperature_scheme);
     if (!(ice->conductivity > 0) || !(ice->maximum_temperature_change > 0))
         return fail(ctx, CF_ERR_INVALID, "sea-ice conductivity and maximum temperature change must be > 0");
     DevParams d;
@@ -872,6 +877,7 @@ int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, co
     K.eps_sigma = ice->emissivity * ice_fluxes->stefan_boltzmann;
     K.albedo = ice->albedo;
     K.T_offset = ice->temperature_offset;
+    K.semi_implicit = ice->skin_temperature_scheme == CF_SKIN_SEMI_IMPLICIT ? 1.0 : 0.0;
     ctx->ice_kernel = K;
     ctx->ice_ready = true;
     return CF_OK;
@@ -991,8 +997,9 @@ int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ic
     CHECK(check_exchange(ctx, atmos, true));
     CHECK(check_fluxes(ctx, out));
     CHECK(wait_for_halos(ctx));
+    CHECK(ensure_chunk_table(ctx, ocean->mask));
     HIP_TRY(ctx, launch_ai_fluxes(ctx->stream, ctx->launch, ctx->ice_dev, ctx->ice_loop, ctx->ice_kernel, ctx->grid, ice, ocean,
-                                  atmos, out, ctx->d_ice_tables, ctx->d_ice_params));
+                                  atmos, out, ctx->d_ice_tables, ctx->d_ice_params, ctx->trip_hints ? ctx->d_trip_ice : nullptr));
     return CF_OK;
 }
 

@@ -71,6 +71,7 @@ struct cf_ctx {
     bool ice_albedo_ccsm3 = false;   // cf_set_sea_ice_albedo: SeaIceAlbedo(hi, hs, Ts) wherever no albedo field is given
     cf_sea_ice_albedo_params ice_albedo{};
     double* d_ice_albedo = nullptr;  // the albedo field of the current step (computed by the library)
+    uint8_t* d_trip_ice = nullptr;   // trip counts of the sea-ice interface solve per wet-list entry
     double* d_ice_tables = nullptr;
     DevParams* d_ice_params = nullptr;
     // halo rows travel on their own stream so that they overlap the interpolation kernel, which

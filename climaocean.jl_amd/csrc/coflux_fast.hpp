@@ -297,6 +297,7 @@ constexpr int SOLVER_OCEAN = 0;    // Charnock-type momentum roughness, identica
 constexpr int SOLVER_ICE = 1;      // constant roughness lengths, U_G,min > 0
 constexpr int SOLVER_GENERIC = 2;  // anything else (runtime kinds, u★ = 0 guards)
 constexpr int SOLVER_LY = 3;       // CoefficientBasedFluxes: Large & Yeager iteration on (Cd, Ch, Ce)
+constexpr int SOLVER_SEAICE = 4;   // atmosphere–sea-ice interface: skin temperature inside the iteration (ice_iterate)
 
 using FastConsts = LoopParams;  // name kept for the launcher signatures
 
@@ -533,6 +534,7 @@ struct IceParams {  // kernarg
     double hk_min;      // consolidation thickness / conductivity
     double inv_k;       // 1 / conductivity
     double dT_max, T_melt, T_fw, liquidus_slope, eps_sigma, emissivity, albedo, T_offset;
+    double semi_implicit;  // 1: upwelling longwave linearised about the previous skin temperature (CF_SKIN_SEMI_IMPLICIT)
 };
 
 struct IceConsts {
@@ -562,8 +564,15 @@ __device__ __forceinline__ Scales ice_iterate(const DevParams& P, const LoopPara
             // skin temperature from the energy balance with the previous scales
             const double T2 = Ts * Ts;
             const double rho_u = c.rho * us;
-            const double Qnet = -rho_u * c.Ls * qq + I.eps_sigma * T2 * T2 - rho_u * c.cp * ts + c.Qd;
-            double Tstar = __builtin_fma(-Qnet, c.hk, c.Ti);
+            double Tstar;
+            if (I.semi_implicit != 0.0) {
+                // k (Ti − T★)/h = Q_v + Q_c + Q_d + εσ Ts³ T★ : implicit in one factor of the upwelling longwave
+                const double Qrest = -rho_u * c.Ls * qq - rho_u * c.cp * ts + c.Qd;
+                Tstar = __builtin_fma(-Qrest, c.hk, c.Ti) * frcp(__builtin_fma(c.hk * I.eps_sigma, T2 * Ts, 1.0));
+            } else {
+                const double Qnet = -rho_u * c.Ls * qq + I.eps_sigma * T2 * T2 - rho_u * c.cp * ts + c.Qd;
+                Tstar = __builtin_fma(-Qnet, c.hk, c.Ti);
+            }
             Tstar = (Tstar != Tstar) ? Ts : Tstar;
             const double dT = fmin(fmax(Tstar - Ts, -I.dT_max), I.dT_max);
             Ts = fmin(Ts + dT, I.T_melt);

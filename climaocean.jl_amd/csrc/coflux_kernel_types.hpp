@@ -64,6 +64,14 @@ struct IceIn {
     const double* tyio;
 };
 
+struct IceStateIn {   // sea_ice.model fields the atmosphere–sea-ice interface reads (atmosphere.jl:34-39)
+    const double* thickness;
+    const double* top_temperature;
+    const double* u;
+    const double* v;
+    const double* albedo;
+};
+
 struct NetOut {
     double* u;
     double* v;

@@ -45,7 +45,7 @@ hipError_t launch_interpolate_background(hipStream_t st, const GridDesc& G, cons
 hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const IceParams& I,
                             const GridDesc& G, const cf_sea_ice_state* ice, const cf_ocean_surface* o,
                             const cf_exchange_fields* e, const cf_interface_fluxes* f, const double* d_tables,
-                            const DevParams* d_params);
+                            const DevParams* d_params, uint8_t* d_trip);
 hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
                              int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
                              int* nchunks_out);

@@ -309,6 +309,8 @@ struct SolverArgs {
     const int* chunk_begins;
     IceIn I;
     NetOut N;
+    IceStateIn S;   // SOLVER_SEAICE only
+    IceParams Ice;
 };
 typedef const SolverArgs __attribute__((address_space(4)))* SolverArgsPtr;
 
@@ -516,6 +518,71 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
             const int q = start + lane;
             const bool in_range = q < nwet;
             const int qc = in_range ? q : nwet - 1;
+            if constexpr (SPEC == SOLVER_SEAICE) {
+                // ---- atmosphere–sea-ice interface: same list, same batches, the skin temperature inside the loop ----
+                const IceParams Ice = kread(&K->Ice);
+                IceConsts c;
+                double Ts;
+                {
+                    const int idx = list[qc];
+                    const int jj = idx / wx;
+                    const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+                    SolverArgsPtr Kb = opaque(K);
+                    const IceStateIn S = kread(&Kb->S);
+                    const double ua = Kb->E.u[k], va = Kb->E.v[k], Ta = Kb->E.T[k], pa = Kb->E.p[k], qa = Kb->E.q[k];
+                    const double inv_Ta = frcp(Ta);
+                    const double lam_a = liquid_fraction_fast(P, logt, Ta);
+                    const AirState A = air_state_fast(P, pa, Ta, inv_Ta, qa, lam_a, svp_equil_fast(P, logt, Ta, inv_Ta, lam_a));
+                    c.rho = A.rho;
+                    c.cp = A.cp_m;
+                    c.qav = A.q_vap;
+                    c.Ls = P.LH_s0 + (P.cp_v - P.cp_i) * (Ta - P.T_0);
+                    c.Ti = Ice.T_fw - Ice.liquidus_slope * Kb->O.S[k];
+                    c.hk = fmax(S.thickness[k] * Ice.inv_k, Ice.hk_min);
+                    const double alb = S.albedo ? S.albedo[k] : Ice.albedo;
+                    c.Qd = -(1.0 - alb) * Kb->E.Qs[k] - Ice.emissivity * Kb->E.Ql[k];
+                    c.theta_a = Ta + P.g * P.h_ref * frcp(A.cp_m);
+                    c.pa = pa;
+                    c.du = ua;
+                    c.dv = va;
+                    if (P.velocity_difference == CF_VELOCITY_RELATIVE) {
+                        c.du = ua - (S.u ? S.u[k] : 0.0);
+                        c.dv = va - (S.v ? S.v[k] : 0.0);
+                    }
+                    c.dU2 = c.du * c.du + c.dv * c.dv;
+                    c.dU = fsqrt(c.dU2);
+                    double alpha = P.rm.charnock;
+                    if (P.rm.kind == CF_ROUGHNESS_WIND_CHARNOCK)
+                        alpha = fmax(P.rm.charnock, P.rm.wind_a1 * fmin(c.dU, P.rm.wind_umax) + P.rm.wind_a2);
+                    c.alpha_g = alpha * P.inv_g;
+                    Ts = S.top_temperature[k] + Ice.T_offset;
+                }
+                const Scales s = ice_iterate<COARE>(P, L, Ice, c, tab, in_range, Ts);
+                if (in_range) {
+                    SolverArgsPtr Ke = opaque(K);
+                    const int idx2 = list[qc];
+                    const int jj2 = idx2 / wx;
+                    const size_t k = cell_index(G, idx2 - jj2 * wx - G.ring, jj2 - G.ring);
+                    CellFluxes R;
+                    const double inv_dU = (c.dU == 0.0) ? 0.0 : frcp(c.dU);
+                    const double tau = -s.us * s.us * inv_dU;
+                    const double rho_u = c.rho * s.us;
+                    R.Fv = -rho_u * s.qq;
+                    R.Qv = R.Fv * c.Ls;
+                    R.Qc = -rho_u * c.cp * s.ts;
+                    R.rho_tau_x = c.rho * tau * c.du;
+                    R.rho_tau_y = c.rho * tau * c.dv;
+                    R.Ts_ocean = Ts - Ice.T_offset;
+                    R.ustar = s.us;
+                    R.tstar = s.ts;
+                    R.qstar = s.qq;
+                    R.iterations = s.it;
+                    const FluxOut F = kread(&Ke->F);
+                    store_fluxes(F, k, R);
+                    if (use_static && W.trip) W.trip[(size_t)chunk * AO_CHUNK + list_e[qc]] = (uint8_t)min(s.it, 255);
+                }
+                continue;
+            }
             CellConsts c;
             double So;
             {
@@ -608,7 +675,7 @@ __global__ void debug_eval_kernel(int fn, int n, const double* __restrict__ x, d
 template <bool COARE, bool FUSE>
 static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const LoopParams& C, const GridDesc& G,
                            const OceanIn& O, const Exchange& E, const FluxOut& F, const IceIn& I, const NetOut& N) {
-    const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip}, L.d_chunk_begins, I, N};
+    const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip}, L.d_chunk_begins, I, N, IceStateIn{}, IceParams{}};
 #define CF_LAUNCH(COARE_, SPEC_) \
     hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, FUSE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A)
     switch (C.specialization) {
@@ -646,6 +713,33 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
         if (coare) launch_ao_spec<true, false>(st, grid, L, C, G, O, E, F, I, N);
         else launch_ao_spec<false, false>(st, grid, L, C, G, O, E, F, I, N);
     }
+    return hipGetLastError();
+}
+
+// compute_atmosphere_sea_ice_fluxes!: the same kernel machinery (static lists, LDS-DMA tables, batches sorted by the
+// previous call's trip counts) with the sea-ice iteration; its own formulation block, tables and trip-count array.
+hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const IceParams& Ice,
+                            const GridDesc& G, const cf_sea_ice_state* ice, const cf_ocean_surface* o,
+                            const cf_exchange_fields* e, const cf_interface_fluxes* f, const double* d_tables,
+                            const DevParams* d_params, uint8_t* d_trip) {
+    if (!L.d_chunk_begins || L.n_chunks <= 0) return hipErrorInvalidValue;
+    SolverArgs A{};
+    A.L = C;
+    A.G = G;
+    A.O = make_ocean(o);
+    A.E = make_exchange(e);
+    A.F = make_fluxes(f);
+    A.g_tab = d_tables;
+    A.g_params = d_params;
+    A.W = WetLists{L.d_wet_pos, d_trip};
+    A.chunk_begins = L.d_chunk_begins;
+    A.S = IceStateIn{ice->thickness, ice->top_temperature, ice->u, ice->v, ice->albedo};
+    A.Ice = Ice;
+    dim3 grid(L.n_chunks);
+    if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
+        hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE, false>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A);
+    else
+        hipLaunchKernelGGL((ao_flux_fast_kernel<false, SOLVER_SEAICE, false>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A);
     return hipGetLastError();
 }
 

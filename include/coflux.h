@@ -419,9 +419,18 @@ int cf_window_source(cf_window* w, int64_t n1, int64_t n2, double time_fraction,
  * through the ice (SkinTemperature(ConductiveFlux)), humidity saturates over ice, latent heat is that of
  * sublimation.  The ice state itself (ClimaSeaIce) is prescribed input.
  * ---------------------------------------------------------------------------------------- */
+/* flux_balance_temperature(SkinTemperature(ConductiveFlux)) inside the iteration ([UPSTREAM-RECALL]; the pin of
+ * julia/oracle_dump.jl will tell which one upstream ships):
+ *   EXPLICIT       T★ = Tᵢ − (h/k)(Q_v + Q_c + Q_d + εσTₛ⁴) with every flux at the previous iterate; its gain
+ *                  (h/k)·∂Q/∂T exceeds 1 for ice thicker than ≈ 0.1–0.2 m in wind, where it orbits under the ±ΔT_max
+ *                  limiter until maxiter;
+ *   SEMI_IMPLICIT  the upwelling longwave linearised about the previous skin temperature,
+ *                  T★ = (Tᵢ − (h/k)(Q_v + Q_c + Q_d)) / (1 + (h/k) εσ Tₛ³)  — the damped form.                    */
+#define CF_SKIN_EXPLICIT 0
+#define CF_SKIN_SEMI_IMPLICIT 1
 typedef struct cf_sea_ice_params {
     int32_t struct_size;                   /* sizeof(cf_sea_ice_params) */
-    int32_t reserved;
+    int32_t skin_temperature_scheme;       /* CF_SKIN_* */
     double conductivity;                   /* 2.0 W m⁻¹ K⁻¹  (ClimaSeaIce ConductiveFlux)          */
     double consolidation_thickness;        /* 0.05 m: thinner ice conducts as if this thick          */
     double maximum_temperature_change;     /* 5 K per iteration (SkinTemperature limiter)            */

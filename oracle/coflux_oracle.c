@@ -697,7 +697,10 @@ static cell_result solve_ice_cell(const cf_flux_params* P, const cf_sea_ice_para
         double Qc = -rho_a * cp * ustar * tstar;
         double Qv = -rho_a * Ls * ustar * qstar;
         double Qnet = Qv + Qu + Qc + Qd;
-        double Tstar = Ti - Qnet * heff / I->conductivity; /* flux_balance_temperature(ConductiveFlux) */
+        double Tstar = Ti - Qnet * heff / I->conductivity; /* flux_balance_temperature(ConductiveFlux), explicit */
+        if (I->skin_temperature_scheme == CF_SKIN_SEMI_IMPLICIT) /* upwelling longwave linearised about the previous Ts */
+            Tstar = (Ti - (Qv + Qc + Qd) * heff / I->conductivity) /
+                    (1.0 + heff / I->conductivity * I->emissivity * P->stefan_boltzmann * Ts * Ts * Ts);
         if (isnan(Tstar)) Tstar = Ts;
         double dT = fmin(fmax(Tstar - Ts, -I->maximum_temperature_change), I->maximum_temperature_change);
         Ts = fmin(Ts + dT, Tm);

@@ -335,6 +335,9 @@ def atmosphere_sea_ice_fluxes(fluxes, iprops, ice, ocean, atmos, *, hx, hy, ring
         Qnet = -rho * Ls * us * qq + iprops.emissivity * sigma * Ts ** 4 - rho * cp * us * ts \
             - (1 - alb) * Qs - iprops.emissivity * Ql
         Tstar = Ti - Qnet * heff / iprops.conductivity
+        if getattr(iprops, "skin_temperature_scheme", 0) == 1:   # semi-implicit: longwave linearised about the previous Ts
+            rest = Qnet - iprops.emissivity * sigma * Ts ** 4
+            Tstar = (Ti - rest * heff / iprops.conductivity) / (1 + heff / iprops.conductivity * iprops.emissivity * sigma * Ts ** 3)
         Tn = np.minimum(Ts + np.clip(Tstar - Ts, -iprops.maximum_temperature_change, iprops.maximum_temperature_change), Tm)
         qs = th.svp(Tn, th.Ls0, th.cpv - th.cpi) / (rho * th.Rv * Tn)
         dq, dth = qav - qs, Ta + g * h / cp - Tn

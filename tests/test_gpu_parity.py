@@ -444,11 +444,11 @@ def test_c_driver_through_the_abi(tmp_path):
 TOL_ICE = 1e-9  # cells converging within 40 iterations; slower ones 1e-6 (util.compare_ice_fluxes)
 
 
-def run_ice(case, config, *, ring=1, albedo=True, drift=True, atmos_override=None):
+def run_ice(case, config, *, ring=1, albedo=True, drift=True, atmos_override=None, scheme=abi.SKIN_EXPLICIT):
     nx, ny, hx, hy = case["nx"], case["ny"], case["hx"], case["hy"]
     fluxes_f, vd = util.ICE_CONFIGS[config]()
     ice_params = ic.flux_params(fluxes_f, velocity_difference=vd)
-    props = ic.SeaIceInterfaceProperties()
+    props = ic.SeaIceInterfaceProperties(skin_temperature_scheme=scheme)
     g = orc.make_grid(nx, ny, hx, hy, ring)
     at = util.polar_atmosphere(orc.interpolate_atmosphere_state(g, case["src"], case["weights"], 0, 1, 0.37))
     if atmos_override:
@@ -481,6 +481,12 @@ def test_sea_ice_interface_90x40_all_formulations(config):
     got, ref = run_ice(util.build_case(90, 40), config)
     worst = util.compare_ice_fluxes(got, ref, TOL_ICE)
     print(config, worst)
+
+
+@pytest.mark.parametrize("config", ["sea_ice_corrected", "sea_ice_ncar"])
+def test_sea_ice_interface_semi_implicit_skin_scheme(config):
+    got, ref = run_ice(util.build_case(90, 40), config, scheme=abi.SKIN_SEMI_IMPLICIT)
+    util.compare_ice_fluxes(got, ref, TOL_ICE)
 
 
 def test_sea_ice_interface_defaults_and_ragged_size():

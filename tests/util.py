@@ -80,13 +80,14 @@ ICE_FLUX_FIELDS = ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", 
                    "friction_velocity", "temperature_scale", "humidity_scale")
 
 
-def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=1e-3, maxiter=100, tol_slow=1e-6, slow=40):
-    """Sea-ice interface comparison, same-shape windows.  The explicit skin-temperature balance does not
-    contract for thick ice (gain ≈ (h/k)·∂Q/∂T > 1): those cells orbit under the ±ΔTmax limiter until
-    `maxiter`, and the orbit amplifies rounding differences by ≈1.3× per iteration (two CPU restatements
-    already differ by 1e-5 there).  Cells the reference leaves unconverged are therefore held to
-    `tol_unconverged`; cells that do converge but need more than `slow` iterations (a weakly contracting
-    orbit, same amplification) to the north-star `tol_slow` = 1e-6; every other cell to `tol_converged`."""
+def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=None, maxiter=100, tol_slow=1e-6, slow=40):
+    """Sea-ice interface comparison, same-shape windows.  The recalled skin-temperature balance does not contract for
+    thick ice in wind (gain ≈ (h/k)·∂Q/∂T > 1, explicit and semi-implicit form alike): such cells orbit under the ±ΔTmax
+    limiter until `maxiter`, and the orbit amplifies rounding differences without bound.  Cells the reference leaves at
+    `maxiter` are therefore NOT compared in value — a loose tolerance there would be decoration, not parity —: both sides
+    must abandon the same cells and return finite numbers.  Cells that converge but need more than `slow` iterations (a
+    weakly contracting orbit, ≈ 1.3× amplification per iteration) are held to the north star's `tol_slow` = 1e-6, every
+    other cell to `tol_converged`; trip counts must be identical on all converged cells."""
     unconv = np.asarray(ref["iterations"]) >= maxiter
     # collapsed turbulence (u★ → 1e-11 on the −5ζ branch): ζ leaves the ψ tables' range |ζ| ≤ 4.3e9, where the
     # device clamps ψ; u★ then differs by ≈4e-11 m/s in absolute terms, all fluxes are < 1e-9 of their scale
@@ -102,5 +103,9 @@ def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=1e-3, maxiter=10
                     float(err[unconv].max(initial=0.0)))
         assert worst[k][0] <= tol_converged, (k, worst[k])
         assert worst[k][1] <= max(tol_slow, tol_converged), (k, worst[k])
-        assert worst[k][2] <= tol_unconverged, (k, worst[k])
+        if tol_unconverged is not None:
+            assert worst[k][2] <= tol_unconverged, (k, worst[k])
+        assert np.all(np.isfinite(g[unconv])), k
+    if tol_unconverged is None:   # orbiting cells are not compared in value: both sides must have given up on the same cells
+        assert np.array_equal(np.asarray(got["iterations"])[unconv], np.asarray(ref["iterations"])[unconv])
     return worst
