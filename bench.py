@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--nx", type=int, default=1440)
     ap.add_argument("--ny", type=int, default=560)
     ap.add_argument("--halo", type=int, default=7)  # README.md:58 halo=(7,7,7)
+    ap.add_argument("--grid", choices=("latlon", "tripolar"), default="latlon",
+                    help="tripolar: BASELINE configs[3]/[4] — general 2-D interpolation weights, wind rotation, and the fold on "
+                         "the last rank (use --nx 360 --ny 180 for the 1-degree grid, --nx 2160 --ny 1080 for the 1/6-degree one)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--halo-backend", choices=("auto", "rccl", "peer", "torch"), default="auto")
     ap.add_argument("--flux-configuration", choices=("default", "corrected", "ncar"), default="default")
@@ -150,19 +153,35 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region ---------------------------------
     n_levels = 4
-    ocean_np = [syn.ocean_state(nx, ny, h, h, ny_global=ny_global, j_offset=j0)]
-    ocean_np.append(syn.evolved_ocean_state(ocean_np[0], nx, ny, h, h, 1, ny_global=ny_global, j_offset=j0))
     # consecutive 3-hourly snapshots correlated 0.95: the atmosphere changes by ≈ 3 % of its variability per 20-min step
     src_np = syn.jra55_snapshots(n_levels, temporal_correlation=0.95)
-    fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h, ny_global=ny_global, j_offset=j0)
-    w_np = dict(separable=True, fi=fi, fj=fj, latitude=phi)
+    tripolar = a.grid == "tripolar"
+    if tripolar:
+        if a.scaling != "strong":
+            raise SystemExit("bench.py: --grid tripolar shards ONE folded surface (strong scaling)")
+        tc = syn.tripolar_case(nx, ny_global, h, h, j0=j0, j1=j1)
+        ocean_np = [dict(tc["ocean"])]
+        evolved = syn.evolved_ocean_state(syn.ocean_state(nx, ny_global, h, h, latitude=(-80.0, 90.0)), nx, ny_global, h, h, 1)
+        second = {}
+        for k in ("T", "S", "u", "v"):          # the second state folds like the first
+            gfull = evolved[k].copy()
+            syn.fold_north(gfull, nx, ny_global, h, h, 2, syn.FOLD_LOCATION[k], syn.FOLD_SIGN[k])
+            second[k] = np.ascontiguousarray(gfull[j0:j1 + 2 * h])
+        second["mask"] = tc["ocean"]["mask"]
+        ocean_np.append(second)
+        w_np = tc["weights"]
+    else:
+        ocean_np = [syn.ocean_state(nx, ny, h, h, ny_global=ny_global, j_offset=j0)]
+        ocean_np.append(syn.evolved_ocean_state(ocean_np[0], nx, ny, h, h, 1, ny_global=ny_global, j_offset=j0))
+        fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h, ny_global=ny_global, j_offset=j0)
+        w_np = dict(separable=True, fi=fi, fj=fj, latitude=phi)
 
     ctx = FluxContext(nx, ny, h, h, params, ring=1, device=local_rank)
     ring_rows = ctx.grid.ring + 1
     states = [{k: ctx.to_device(o[k]) for k in ("T", "S", "u", "v", "mask")} for o in ocean_np]
     states[1]["mask"] = states[0]["mask"]   # one static wet mask (the solver's chunk table is keyed on it)
     src = {k: ctx.to_device(v) for k, v in src_np.items()}
-    w = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj), latitude=ctx.to_device(phi))
+    w = {k: (ctx.to_device(v) if isinstance(v, np.ndarray) else v) for k, v in w_np.items()}
     pipeline = a.pipeline == "on" or (a.pipeline == "auto" and (nx + 2) * (ny + 2) < 300_000)
     atmos_sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2 if pipeline else 1)]
     fl = ctx.field_set(FLUX_NAMES)
@@ -233,7 +252,8 @@ def main():
     def schedule_for(name):
         return ctx.make_schedule(states, atmos_sets, first_level=0, time_fraction=0.0, time_fraction_increment=inc,
                                  pipeline=pipeline, halo_backend=backend_code.get(name, abi.HALO_NONE),
-                                 halo_rows=ring_rows if name in backend_code else 0)
+                                 halo_rows=ring_rows if name in backend_code else 0,
+                                 fold_north=tripolar and rank == world - 1)
 
     def run_steps(name, sched, first, n):
         if a.config == "sea_ice" or name == "torch":   # host-driven steps (five-launch sea-ice step; torch P2P halo)
@@ -241,6 +261,9 @@ def main():
                 st = states[s % 2]
                 if name == "torch":
                     exchangers["torch"]([st[k] for k in ("T", "S", "u", "v")])
+                if tripolar and rank == world - 1:
+                    ctx.fold_north_halo([st[k] for k in ("T", "S", "u", "v")],
+                                        [abi.FOLD_CENTER, abi.FOLD_CENTER, abi.FOLD_X_FACE, abi.FOLD_Y_FACE], [1.0, 1.0, -1.0, -1.0], rows=2)
                 tot = s * inc
                 l1 = int(tot) % n_levels
                 kw = dict(level1=l1, level2=(l1 + 1) % n_levels, time_fraction=tot - int(tot))
@@ -350,7 +373,9 @@ def main():
                         bytes_per_cell=nbytes, cells_per_launch=ncells, avg_launch_ms=ms,
                         cells_per_s=ncells / (ms * 1e-3), **extra)
 
-        workload = (f"1/4-degree LatitudeLongitudeGrid surface {nx}x{a.ny} per {'GPU' if a.scaling == 'weak' else 'job'}"
+        grid_name = (f"TripolarGrid surface {nx}x{a.ny} (synthetic mesh with the real fold; general weights + wind rotation)" if tripolar
+                     else f"1/4-degree LatitudeLongitudeGrid surface {nx}x{a.ny}")
+        workload = (f"{grid_name} per {'GPU' if a.scaling == 'weak' else 'job'}"
                     f"{' sharded into ' + str(world) + ' latitude slabs' if world > 1 and a.scaling == 'strong' else ''}, "
                     f"JRA55 640x320 f32 atmosphere ({n_levels}-snapshot window, clock advancing 20 min per step), "
                     f"SimilarityTheoryFluxes(:{a.flux_configuration}) + Radiation"

@@ -203,3 +203,117 @@ def tripolar_like_weights(nx, ny, hx, hy, *, ny_global=None, j_offset=0, nsx=JRA
     fj = (phi2 - JRA55_LAT0) / (2 * 89.57 / (nsy - 1))
     return (np.ascontiguousarray(fi), np.ascontiguousarray(fj), np.ascontiguousarray(np.cos(theta)),
             np.ascontiguousarray(np.sin(theta)), np.ascontiguousarray(phi2))
+
+
+# ---------------------------------------------------------------------------------------------
+# a tripolar grid with a REAL fold (BASELINE configs 4–5: TripolarGrid(size = (360, 180, Nz)),
+# OceanConfigurations/one_degree_tripolar.jl:48-51; size = (2160, 1080, Nz), sixth_degree_tripolar.jl:33-36)
+# ---------------------------------------------------------------------------------------------
+def tripolar_mesh(nx, ny, *, southernmost_latitude=-80.0, cap_latitude=55.0, cap_rows=None, pole_longitude=75.0):
+    """Cell-centre longitude / latitude and the rotation of the grid's i-axis against geographic east for a synthetic
+    tripolar grid, arrays (ny, nx) over the GLOBAL interior.
+
+    South of `cap_latitude` the mesh is latitude–longitude.  The cap is a bipolar mesh in the stereographic plane of the
+    north pole: confocal ellipses (rows) and hyperbolas (columns) about two grid poles on land at ±a on the axis
+    λ = pole_longitude, x = a cosh μ cos ν, y = a sinh μ sin ν.  The LAST row of cell centres lies on the segment
+    between the poles (μ = 0), where ν and −ν are the same point: column i and column nx − 1 − i coincide there — the
+    tracer-point pivot of Oceananigans' tripolar fold, which is what cf_fold_north_halo implements.  (The outermost
+    ellipse of the cap is circular to 1.3 %; the mesh is synthetic, its topology is the real one.)
+
+    The rotation follows experiments/OMIPSimulations/scripts/visualize/cache.jl:406-427: from the two x-face nodes
+    bracketing the cell, dE = cos φ · Δλ, dN = Δφ, (cos θ, sin θ) = (dE, dN)/‖·‖."""
+    nyc = cap_rows if cap_rows is not None else max(2, int(round(ny * (90.0 - cap_latitude) / (90.0 - southernmost_latitude))))
+    nys = ny - nyc
+    mu0 = 2.5
+    r0 = 2.0 * np.tan(np.deg2rad(90.0 - cap_latitude) / 2.0)       # stereographic radius of the cap's rim
+    a = r0 / np.cosh(mu0)
+
+    def position(fi, fj):
+        """(λ, φ) in degrees at fractional global indices: centres at integer + 0.5 in i, rows at integers in j."""
+        fi, fj = np.broadcast_arrays(np.asarray(fi, float), np.asarray(fj, float))
+        lam = (fi * (360.0 / nx) + pole_longitude) % 360.0     # column 0 starts on the meridian of the grid poles
+        phi = southernmost_latitude + (fj + 0.5) * (cap_latitude - southernmost_latitude) / nys
+        cap = fj > nys - 0.5
+        mu = np.clip((ny - 1 - fj) / (nyc - 0.5) * mu0, 0.0, None)      # 0 on the last row of centres, μ0 at the rim
+        nu = np.deg2rad(fi * (360.0 / nx))                      # ν ↦ −ν is i ↦ nx − 1 − i for the centres at i + ½
+        # (the fold segment is displaced off the geographic pole, tapering to zero at the rim: no cell straddles λ's singularity)
+        x, y = a * np.cosh(mu) * np.cos(nu), a * np.sinh(mu) * np.sin(nu) + 0.04 * r0 * (1.0 - mu / mu0)
+        lam_c = (np.rad2deg(np.arctan2(y, x)) + pole_longitude) % 360.0
+        phi_c = 90.0 - 2.0 * np.rad2deg(np.arctan(np.hypot(x, y) / 2.0))
+        return np.where(cap, lam_c, lam), np.where(cap, phi_c, phi)
+
+    i = np.arange(nx)[None, :] + 0.5
+    j = np.arange(ny)[:, None] + 0.0
+    lam, phi = position(i, j)
+    lw, pw = position(i - 0.5, j)
+    le, pe = position(i + 0.5, j)
+    dlam = (le - lw + 180.0) % 360.0 - 180.0
+    dE, dN = np.cos(np.deg2rad(phi)) * dlam, pe - pw
+    r = np.hypot(dE, dN)
+    cos_t = np.where(r > 0, dE / np.where(r > 0, r, 1.0), 1.0)
+    sin_t = np.where(r > 0, dN / np.where(r > 0, r, 1.0), 0.0)
+    return lam, phi, cos_t, sin_t
+
+
+def fold_north(a, nx, ny, hx, hy, rows, location="center", sign=1.0):
+    """NumPy statement of the tripolar fold (include/coflux.h: cf_fold_north_halo) on a halo-inclusive GLOBAL array,
+    in place: north halo rows from the mirrored interior rows, periodic x-halos of those rows included."""
+    i = np.arange(-hx, nx + hx) % nx
+    for r in range(1, rows + 1):
+        if location == "x_face":
+            src_i, src_j, sg = (nx - i) % nx, ny - 1 - r, np.where(i == 0, abs(sign), sign)
+        elif location == "y_face":
+            src_i, src_j, sg = nx - 1 - i, ny - r, sign
+        else:
+            src_i, src_j, sg = nx - 1 - i, ny - 1 - r, sign
+        a[hy + ny - 1 + r, :] = sg * a[hy + src_j, hx + src_i]
+    return a
+
+
+FOLD_LOCATION = dict(T="center", S="center", u="x_face", v="y_face")
+FOLD_SIGN = dict(T=1.0, S=1.0, u=-1.0, v=-1.0)
+
+
+def tripolar_case(nx, ny, hx, hy, *, j0=0, j1=None, rows=2, nsx=JRA55_NX, nsy=JRA55_NY, seed=SEED):
+    """Ocean state + general (2-D) interpolation weights + rotation on the synthetic tripolar grid for the latitude slab
+    [j0, j1) of the global nx × ny grid (default: the whole grid).  Halos: periodic in x; the LAST slab's north halo is
+    the fold of its own rows (only `rows` rows are meaningful, like after an exchange); inner slab seams carry the
+    neighbours' rows because every field is a function of the global index."""
+    j1 = ny if j1 is None else j1
+    lam, phi, cos_t, sin_t = tripolar_mesh(nx, ny)
+    full = ocean_state(nx, ny, hx, hy, latitude=(-80.0, 90.0), seed=seed)          # global, halo-inclusive, index-space fields
+    out = {}
+    for k in ("T", "S", "u", "v"):
+        g = full[k].copy()
+        fold_north(g, nx, ny, hx, hy, rows, FOLD_LOCATION[k], FOLD_SIGN[k])
+        out[k] = np.ascontiguousarray(g[j0:j1 + 2 * hy])
+    # a wet mask that is symmetric under the fold on the last row (a cell and its mirror image are the same water)
+    m = full["mask"].copy()
+    last = m[hy + ny - 1, hx:hx + nx]
+    m[hy + ny - 1, hx:hx + nx] = np.minimum(last, last[::-1])
+    for pole in (0, nx // 2):                  # the two grid poles sit on land, as on the real grid (mirror-symmetric patches)
+        cols = np.arange(pole - 3, pole + 3) % nx
+        m[hy + ny - 4:hy + ny, hx + cols] = 0
+    m[hy + ny - 1, :hx], m[hy + ny - 1, hx + nx:] = m[hy + ny - 1, nx:nx + hx], m[hy + ny - 1, hx:2 * hx]
+    fold_north(m, nx, ny, hx, hy, rows, "center", 1)
+    out["mask"] = np.ascontiguousarray(m[j0:j1 + 2 * hy])
+
+    def halo2d(a):          # (ny, nx) interior → halo-inclusive slab, periodic in x, edge rows repeated / folded in y
+        g = np.empty((ny + 2 * hy, nx + 2 * hx))
+        g[hy:hy + ny, hx:hx + nx] = a
+        g[:hy] = g[hy:hy + 1]
+        g[hy + ny:] = g[hy + ny - 1:hy + ny]
+        g[:, :hx], g[:, hx + nx:] = g[:, nx:nx + hx], g[:, hx:2 * hx]
+        return g
+    LAM, PHI, COS, SIN = (halo2d(a) for a in (lam, phi, cos_t, sin_t))
+    for a, loc, sg in ((LAM, "center", 1), (PHI, "center", 1), (COS, "center", 1), (SIN, "center", 1)):
+        fold_north(a, nx, ny, hx, hy, min(rows, hy), loc, sg)
+    # across the fold the grid's i-axis points the other way: the halo image's own rotation is the source cell's, reversed
+    COS[hy + ny:hy + ny + rows] *= -1.0
+    SIN[hy + ny:hy + ny + rows] *= -1.0
+    sl = slice(j0, j1 + 2 * hy)
+    fi = LAM[sl] / (360.0 / nsx)
+    fj = (PHI[sl] - JRA55_LAT0) / (2 * 89.57 / (nsy - 1))
+    weights = dict(separable=False, fi=np.ascontiguousarray(fi), fj=np.ascontiguousarray(fj), cos_rot=np.ascontiguousarray(COS[sl]),
+                   sin_rot=np.ascontiguousarray(SIN[sl]), latitude=np.ascontiguousarray(PHI[sl]))
+    return dict(nx=nx, ny=j1 - j0, hx=hx, hy=hy, ocean=out, weights=weights, src=jra55_snapshots(2, nsx, nsy, seed))

@@ -588,6 +588,12 @@ static int wait_for_halos(cf_ctx* ctx) {
     return CF_OK;
 }
 
+}  // extern "C"
+// (coflux_steps.cpp: the table is built before the first halo exchange of a step loop is queued — building it
+// synchronises the stream, which must not hold a peer-direct exchange that waits for a neighbour still to be launched)
+int cf_ensure_chunk_table(cf_ctx* ctx, const void* mask) { return ensure_chunk_table(ctx, mask); }
+extern "C" {
+
 int cf_interpolate_atmosphere_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
                                     const cf_exchange_fields* out) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");

@@ -13,6 +13,8 @@
 static std::mutex g_peer_mutex;
 static std::map<std::string, std::pair<char*, int>> g_peer_local;  // handle bytes → (mailbox, device)
 
+int cf_ensure_chunk_table(cf_ctx* ctx, const void* mask);  // coflux_abi.cpp
+
 static int ensure_aux_stream(cf_ctx* ctx) {
     if (ctx->aux_stream) return CF_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -250,6 +252,11 @@ int cf_time_steps(cf_ctx* ctx, int64_t first_step, int nsteps, const cf_run_sche
         s.time_fraction = total - whole;
         return s;
     };
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int n = 0; n < S->n_ocean_states; ++n) {
+        if (ctx->dev.mask_kind != CF_MASK_NONE && !S->ocean_states[n].mask) return fail(ctx, CF_ERR_INVALID, "ocean state %d has no mask", n);
+        if (n == 0) CHECK(cf_ensure_chunk_table(ctx, S->ocean_states[n].mask));
+    }
     static const int fold_loc[4] = {CF_FOLD_CENTER, CF_FOLD_CENTER, CF_FOLD_X_FACE, CF_FOLD_Y_FACE};
     static const double fold_sign[4] = {1.0, 1.0, -1.0, -1.0};
     if (S->pipeline && nsteps > 0) {  // the first step's atmosphere, unless a previous call already started it
