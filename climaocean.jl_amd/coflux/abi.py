@@ -160,6 +160,13 @@ class AtmosSource(C.Structure):
                 ("time_fraction", C.c_double)]
 
 
+class LandSource(C.Structure):
+    _fields_ = [("friver", C.c_void_p), ("licalvf", C.c_void_p),
+                ("ns_x", C.c_int32), ("ns_y", C.c_int32), ("n_levels", C.c_int32),
+                ("level1", C.c_int32), ("level2", C.c_int32), ("reserved", C.c_int32),
+                ("time_fraction", C.c_double)]
+
+
 class RunSchedule(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("n_ocean_states", C.c_int32),
                 ("ocean_states", C.POINTER(OceanSurface)),
@@ -191,6 +198,7 @@ EXPORTED_SYMBOLS = (
     "cf_time_steps", "cf_prefetch_atmosphere_state",
     "cf_default_sea_ice_albedo_params", "cf_set_sea_ice_albedo", "cf_compute_sea_ice_albedo",
     "cf_default_ice_ocean_params", "cf_compute_sea_ice_ocean_fluxes",
+    "cf_interpolate_land_freshwater", "cf_set_land_freshwater", "cf_materialize_salinity_restoring",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
     "cf_window_upload", "cf_window_find", "cf_window_source",
 )
@@ -283,6 +291,9 @@ def load_library(path=None):
     lib.cf_default_ice_ocean_params.argtypes = [C.POINTER(IceOceanParams)]
     lib.cf_compute_sea_ice_ocean_fluxes.argtypes = [vp, C.POINTER(IceOceanParams), C.POINTER(OceanSurface), vp, vp, vp,
                                                     C.POINTER(IceOceanFluxes)]
+    lib.cf_interpolate_land_freshwater.argtypes = [vp, C.POINTER(LandSource), C.POINTER(InterpWeights), vp]
+    lib.cf_set_land_freshwater.argtypes = [vp, vp]
+    lib.cf_materialize_salinity_restoring.argtypes = [vp, C.c_double, vp, C.POINTER(OceanSurface), vp]
     lib.cf_window_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.cf_window_destroy.argtypes = [vp]
     lib.cf_window_host_buffer.argtypes = [vp, C.c_int32, C.c_int32]

@@ -66,12 +66,35 @@ class LatitudeLongitudeGrid:
 # ---------------------------------------------------------------------------------------------
 # ocean (boundary only: surface state in, top-BC flux fields out)
 # ---------------------------------------------------------------------------------------------
+@dataclass
+class SurfaceFluxRestoring:
+    """SurfaceFluxRestoring(DatasetRestoring(…; rate = piston_velocity / (Δz days))) — salinity_surface_restoring,
+    omip_simulation.jl:507-523: a surface-only restoring toward `target` (2-D, halo-inclusive device array, g/kg) that rides
+    on the ocean's top-flux boundary condition through `additional_surface_fluxes`.  piston_velocity in m/day as there."""
+    target: torch.Tensor
+    piston_velocity: float = 1.0 / 6.0
+
+    @property
+    def velocity(self):
+        return self.piston_velocity / days
+
+
+@dataclass
+class MultipleFluxes:
+    """MultipleFluxes{flux_field, additional_fluxes} (omip_simulation.jl:175-206): the top boundary condition of a tracer
+    when `ocean_simulation(grid; additional_surface_fluxes = (; S = …))` is used.  The coupled model writes the bulk flux
+    into `flux_field`; the ocean applies flux_field + additional_fluxes."""
+    flux_field: torch.Tensor
+    additional_fluxes: object
+
+
 class OceanSimulation:
     """What `ocean_simulation(grid)` returns: `.model.tracers.{T,S}`, `.model.velocities.{u,v}` as
     (Nz+2Hz, Ny+2Hy, Nx+2Hx) device arrays (k slowest), `.model.clock`, and the top boundary
-    condition fields the coupled model writes (omip_simulation.jl:175-206: bare 2-D fields)."""
+    condition fields the coupled model writes (omip_simulation.jl:175-206: a bare 2-D field, or MultipleFluxes when
+    `additional_surface_fluxes` is given)."""
 
-    def __init__(self, grid, step_callback=None):
+    def __init__(self, grid, step_callback=None, additional_surface_fluxes=None):
         dev = torch.device("cuda", grid.device)
         nz, hz = grid.size[2], grid.halo[2]
         shape3 = (nz + 2 * hz,) + grid.surface_shape
@@ -88,6 +111,9 @@ class OceanSimulation:
             top_boundary_conditions=SimpleNamespace(u=z2(), v=z2(), T=z2(), S=z2()),
             shortwave_surface_flux=z2())  # radiation.surface_flux, KPP/kpp_surface_forcing.jl:47-51
         self.step_callback = step_callback
+        for name, extra in (additional_surface_fluxes or {}).items():
+            bc = self.model.top_boundary_conditions
+            setattr(bc, name, MultipleFluxes(getattr(bc, name), extra))
 
     def surface_state(self):
         m, k = self.model, self.k_top
@@ -311,7 +337,9 @@ class ComponentInterfaces:
         fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL if store_similarity_scales else ())
         self.atmosphere_ocean_interface = SimpleNamespace(fluxes=SimpleNamespace(**fluxes), _fields=fluxes)
         bc = ocean.model.top_boundary_conditions
-        net = dict(u=bc.u, v=bc.v, T=bc.T, S=bc.S, shortwave_surface_flux=ocean.model.shortwave_surface_flux,
+        field_of = lambda b: b.flux_field if isinstance(b, MultipleFluxes) else b  # noqa: E731
+        net = dict(u=field_of(bc.u), v=field_of(bc.v), T=field_of(bc.T), S=field_of(bc.S),
+                   shortwave_surface_flux=ocean.model.shortwave_surface_flux,
                    upwelling_longwave=ctx.zeros(), downwelling_longwave=ctx.zeros(), downwelling_shortwave=ctx.zeros())
         self.net_fluxes = SimpleNamespace(ocean=SimpleNamespace(**net), _ocean_fields=net)
         # atmosphere–sea-ice interface (omip_simulation.jl:145,154; atmosphere.jl:34-44)
@@ -348,8 +376,8 @@ class OceanSeaIceModel:
     """OceanSeaIceModel(ocean[, sea_ice]; atmosphere, radiation, interfaces) — README.md:75,
     examples/one_degree_tripolar_ocean_sea_ice.jl:42, omip_simulation.jl:132,163."""
 
-    def __init__(self, ocean, sea_ice=None, *, atmosphere, radiation=None, interfaces=None):
-        self.ocean, self.sea_ice, self.atmosphere = ocean, sea_ice, atmosphere
+    def __init__(self, ocean, sea_ice=None, *, atmosphere, radiation=None, interfaces=None, land=None):
+        self.ocean, self.sea_ice, self.atmosphere, self.land = ocean, sea_ice, atmosphere, land
         self.interfaces = interfaces or ComponentInterfaces(atmosphere, ocean, sea_ice, radiation=radiation)
         self.clock = SimpleNamespace(time=0.0, iteration=0)
         update_state(self)
@@ -364,6 +392,16 @@ def update_state(model):
     """update_state!(coupled_model) — the accelerated path."""
     itf, atm = model.interfaces, model.atmosphere
     src, n1, n2, frac = atm.source(itf.context, model.clock.time)
+    if getattr(model, "land", None) is not None:
+        # JRA55PrescribedLand: river discharge + calving at the model time, handed to compute_net_ocean_fluxes!
+        land = model.land
+        if not hasattr(itf, "land_freshwater"):
+            itf.land_freshwater = itf.context.zeros()
+        x = model.clock.time / land.time_interval
+        l1 = int(np.floor(x)) % land.n_levels
+        itf.context.interpolate_land_freshwater(land.data["friver"], land.data.get("licalvf"), itf.weights, itf.land_freshwater,
+                                                level1=l1, level2=(l1 + 1) % land.n_levels, time_fraction=x - np.floor(x))
+        itf.context.set_land_freshwater(itf.land_freshwater)
     if model.sea_ice is not None and itf.sea_ice_ocean_heat_flux is not None:
         # compute_sea_ice_ocean_fluxes!: the three-equation exchange and frazil from the current ocean surface and the
         # ice–ocean stress; its outputs ARE the partition's interface_heat / salt_flux and the ice's frazil heat
@@ -411,3 +449,40 @@ def run(simulation):
     while m.clock.time < simulation.stop_time and m.clock.iteration < simulation.stop_iteration:
         time_step(m, simulation.dt)
     m.interfaces.context.sync()
+
+
+class JRA55PrescribedLand:
+    """JRA55PrescribedLand(arch; …) — atmosphere.jl:46: river discharge and calving (friver, licalvf of
+    jra55_data_staging.jl:8) as 3-hourly Float32 windows on the JRA55 grid; OceanSeaIceModel(…; land) interpolates them
+    each step and the freshwater reaches the salinity flux."""
+
+    def __init__(self, snapshots=None, *, time_indices_in_memory=2, time_interval=3 * hours, device=0):
+        dev = torch.device("cuda", device)
+        if snapshots is None:
+            snapshots = synthetic.jra55_land_snapshots(time_indices_in_memory)
+        self.data = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in snapshots.items()}
+        self.n_levels = self.data["friver"].shape[0]
+        self.time_interval = time_interval
+
+
+class NormalizeSalinity:
+    """NormalizeSalinity (omip_simulation.jl:187-220): callable on the coupled model; subtracts the area-weighted global
+    mean of (bulk salinity flux + materialised additional flux) from the bulk flux field.  Dispatches on the salinity top
+    boundary condition as `salinity_normalizer` does: MultipleFluxes ⇒ the additional flux is materialised into a buffer
+    first (`_materialize_top_flux!`), bare field ⇒ no additional flux."""
+
+    def __init__(self, ocean, area=None):
+        bc = ocean.model.top_boundary_conditions.S
+        self.flux_field = bc.flux_field if isinstance(bc, MultipleFluxes) else bc
+        self.additional_fluxes = bc.additional_fluxes if isinstance(bc, MultipleFluxes) else None
+        self.additional_buffer = torch.zeros_like(self.flux_field) if self.additional_fluxes is not None else None
+        self.area = area
+        self.mean_total = torch.zeros(1, dtype=torch.float64, device=self.flux_field.device)
+
+    def __call__(self, model):
+        ctx, ocean = model.interfaces.context, model.ocean
+        if self.additional_fluxes is not None:
+            r = self.additional_fluxes
+            ctx.materialize_salinity_restoring(r.velocity, r.target, ocean.surface_state(), self.additional_buffer)
+        ctx.normalize_salinity_flux(self.flux_field, ocean.model.wet_mask, additional=self.additional_buffer, area=self.area,
+                                    mean_out=self.mean_total)

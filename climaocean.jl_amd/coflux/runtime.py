@@ -219,6 +219,28 @@ class FluxContext:
                                                              _ptr(x_stress), _ptr(y_stress), C.byref(f)),
                     "cf_compute_sea_ice_ocean_fluxes")
 
+    def interpolate_land_freshwater(self, friver, licalvf, weights, out, level1=0, level2=1, time_fraction=0.0):
+        """JRA55PrescribedLand (atmosphere.jl:46): friver + licalvf windows [n, ns_y, ns_x] float32 → one ocean-grid field."""
+        s = abi.LandSource()
+        assert friver.dtype == torch.float32 and friver.is_cuda and friver.is_contiguous()
+        s.friver = friver.data_ptr()
+        s.licalvf = licalvf.data_ptr() if licalvf is not None else None
+        s.n_levels, s.ns_y, s.ns_x = friver.shape
+        s.level1, s.level2, s.time_fraction = level1, level2, float(time_fraction)
+        w = self.weights_struct(weights)
+        self._check(self.lib.cf_interpolate_land_freshwater(self._h, C.byref(s), C.byref(w), _ptr(out)),
+                    "cf_interpolate_land_freshwater")
+
+    def set_land_freshwater(self, field):
+        self._land = field      # keep the tensor alive: the library borrows the pointer
+        self._check(self.lib.cf_set_land_freshwater(self._h, _ptr(field)), "cf_set_land_freshwater")
+
+    def materialize_salinity_restoring(self, piston_velocity, target, ocean, out):
+        """SurfaceFluxRestoring as the additional flux of MultipleFluxes (omip_simulation.jl:175-206, 507-523)."""
+        o = self.ocean_struct(ocean)
+        self._check(self.lib.cf_materialize_salinity_restoring(self._h, float(piston_velocity), _ptr(target), C.byref(o), _ptr(out)),
+                    "cf_materialize_salinity_restoring")
+
     def compute_net_ocean_fluxes(self, ocean, atmos, fluxes, net, ice=None, weights=None):
         o, e, f = self.ocean_struct(ocean), self.exchange_struct(atmos), self.fluxes_struct(fluxes)
         i = self.ice_struct(ice)

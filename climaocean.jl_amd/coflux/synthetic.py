@@ -171,6 +171,20 @@ def jra55_snapshots(n_levels=2, nsx=JRA55_NX, nsy=JRA55_NY, seed=SEED, temporal_
     return out
 
 
+def jra55_land_snapshots(n_levels=2, nsx=JRA55_NX, nsy=JRA55_NY, seed=SEED):
+    """Synthetic JRA55PrescribedLand window (jra55_data_staging.jl:8: friver, licalvf), float32 [n, nsy, nsx], kg m⁻² s⁻¹:
+    river discharge concentrated in a few per cent of the source cells, calving only poleward of 60°."""
+    i = np.arange(nsx)[None, :]
+    j = np.arange(nsy)[:, None]
+    phi = JRA55_LAT0 + j * (2 * 89.57 / (nsy - 1)) + 0 * i
+    out = {k: np.zeros((n_levels, nsy, nsx), np.float32) for k in ("friver", "licalvf")}
+    mouth = uniform("land", i, j, 3, seed) < 0.03
+    for n in range(n_levels):
+        out["friver"][n] = np.where(mouth, 2e-4 * (1.0 + 0.3 * normal("rain", i, j, 10 + n, seed)) ** 2, 0.0)
+        out["licalvf"][n] = np.where(np.abs(phi) > 60.0, 2e-5 * uniform("snow", i, j, 10 + n, seed), 0.0)
+    return out
+
+
 def latlon_fractional_indices(nx, ny, hx, hy, *, ny_global=None, j_offset=0, latitude=(-70.0, 70.0),
                               nsx=JRA55_NX, nsy=JRA55_NY):
     """Separable fractional source indices (0-based) of a lat-lon ocean grid into the JRA55 grid,

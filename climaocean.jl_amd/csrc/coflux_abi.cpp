@@ -630,7 +630,7 @@ int cf_compute_net_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean, cons
     CHECK(check_fluxes(ctx, fluxes));
     CHECK(check_net(ctx, out, w));
     CHECK(wait_for_halos(ctx));
-    HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, out));
+    HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, out, ctx->d_land_freshwater));
     return CF_OK;
 }
 
@@ -670,7 +670,7 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     // kernel follows — bitwise the same numbers as the three-launch sequence (shared arithmetic, contraction off).
     const bool fuse = ctx->fused_net && ctx->launch.solver == CF_SOLVER_TABLES && ctx->dev.albedo_kind == CF_ALBEDO_CONSTANT;
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes,
-                                  fuse ? ice : nullptr, fuse ? net : nullptr));
+                                  fuse ? ice : nullptr, fuse ? net : nullptr, ctx->d_land_freshwater));
     // the next step's interpolation goes out behind the solver: its workgroups are dispatched first, the gather kernel
     // takes the registers and issue slots they leave free
     CHECK(cf_flush_deferred_prefetch(ctx));
@@ -678,7 +678,7 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     if (fuse)
         HIP_TRY(ctx, launch_net_stress(ctx->stream, ctx->dev, ctx->grid, ocean, fluxes, ice, net));
     else
-        HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net));
+        HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net, ctx->d_land_freshwater));
     if (rec) {
         HIP_TRY(ctx, hipEventRecord(ev[3], ctx->stream));
         ++ctx->prof_count;
@@ -1043,6 +1043,32 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
     CHECK(cf_update_state(ctx, src, w, ocean, atmos, ao_fluxes, ice_partition, net));
     CHECK(cf_compute_atmosphere_sea_ice_fluxes(ctx, ice_state, ocean, atmos, ai_fluxes));
     return cf_compute_net_sea_ice_fluxes(ctx, ice_state, ocean, atmos, ai_fluxes, frazil_heat, interface_heat, net_ice);
+}
+
+int cf_interpolate_land_freshwater(cf_ctx* ctx, const cf_land_source* src, const cf_interp_weights* w, double* d_out) {
+    if (!ctx || !src || !src->friver || !d_out) return fail(ctx, CF_ERR_INVALID, "cf_interpolate_land_freshwater: NULL argument");
+    CHECK(check_weights(ctx, w));
+    if (src->ns_x <= 0 || src->ns_y <= 0 || src->n_levels <= 0 || src->level1 < 0 || src->level1 >= src->n_levels || src->level2 < 0 ||
+        src->level2 >= src->n_levels)
+        return fail(ctx, CF_ERR_INVALID, "land source: shape %dx%d, levels (%d,%d) of %d", src->ns_x, src->ns_y, src->level1, src->level2, src->n_levels);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_interpolate_land(ctx->stream, ctx->grid, src, w, d_out));
+    return CF_OK;
+}
+
+int cf_set_land_freshwater(cf_ctx* ctx, const double* d_land_freshwater) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    ctx->d_land_freshwater = d_land_freshwater;
+    return CF_OK;
+}
+
+int cf_materialize_salinity_restoring(cf_ctx* ctx, double piston_velocity, const double* d_target, const cf_ocean_surface* ocean,
+                                      double* d_buffer) {
+    if (!ctx || !d_target || !ocean || !ocean->S || !d_buffer) return fail(ctx, CF_ERR_INVALID, "cf_materialize_salinity_restoring: NULL argument");
+    if (ctx->dev.mask_kind != CF_MASK_NONE && !ocean->mask) return fail(ctx, CF_ERR_INVALID, "ocean mask is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_salinity_restoring(ctx->stream, ctx->dev, ctx->grid, ocean->mask, piston_velocity, d_target, ocean->S, d_buffer));
+    return CF_OK;
 }
 
 int cf_normalize_salinity_flux(cf_ctx* ctx, double* d_flux, const double* d_additional, const double* d_area,

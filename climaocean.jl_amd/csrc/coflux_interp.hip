@@ -232,6 +232,42 @@ __global__ __launch_bounds__(256) void interpolate_gather_kernel(SourceDesc S, W
     E.v[k] = va;
 }
 
+// JRA55PrescribedLand: friver + licalvf → one ocean-grid field (same weights and time blend as the atmosphere, gather form)
+__global__ __launch_bounds__(256) void interpolate_land_kernel(const float* __restrict__ friver, const float* __restrict__ licalvf,
+                                                               int ns_x, int ns_y, int level1, int level2, double tf,
+                                                               WeightDesc Wt, GridDesc G, double* __restrict__ out) {
+    const int wx = G.nx + 2 * G.ring, wy = G.ny + 2 * G.ring;
+    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (idx >= wx * wy) return;
+    const int jj = idx / wx;
+    const int i = idx - jj * wx - G.ring, j = jj - G.ring;
+    const size_t k = cell_index(G, i, j);
+    const double fi = Wt.separable ? Wt.fi[i + G.hx] : Wt.fi[k];
+    const double fj = Wt.separable ? Wt.fj[j + G.hy] : Wt.fj[k];
+    const double xi = fi - floor(fi), eta = fj - floor(fj);
+    const int i0 = (int)trunc(fi), ja = (int)trunc(fj);
+    const int is0 = wrap_index(i0, ns_x), is1 = wrap_index(i0 + (fi > 0.0 ? 1 : (fi < 0.0 ? -1 : 0)), ns_x);
+    const int j0 = min(max(ja, 0), ns_y - 1), j1 = min(max(ja + (fj > 0.0 ? 1 : (fj < 0.0 ? -1 : 0)), 0), ns_y - 1);
+    const size_t g00 = (size_t)j0 * ns_x + is0, g10 = (size_t)j0 * ns_x + is1, g01 = (size_t)j1 * ns_x + is0, g11 = (size_t)j1 * ns_x + is1;
+    const size_t plane = (size_t)ns_x * ns_y;
+    const double w00 = (1.0 - xi) * (1.0 - eta), w01 = (1.0 - xi) * eta, w10 = xi * (1.0 - eta), w11 = xi * eta;
+    auto value = [&](const float* d) {
+        const float* a = d + (size_t)level1 * plane;
+        const float* b = d + (size_t)level2 * plane;
+        const double v1 = w00 * (double)a[g00] + w01 * (double)a[g01] + w10 * (double)a[g10] + w11 * (double)a[g11];
+        const double v2 = w00 * (double)b[g00] + w01 * (double)b[g01] + w10 * (double)b[g10] + w11 * (double)b[g11];
+        return v2 * tf + v1 * (1.0 - tf);
+    };
+    out[k] = value(friver) + (licalvf ? value(licalvf) : 0.0);
+}
+
+hipError_t launch_interpolate_land(hipStream_t st, const GridDesc& G, const cf_land_source* s, const cf_interp_weights* w, double* out) {
+    const int n = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
+    hipLaunchKernelGGL(interpolate_land_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->friver, s->licalvf, s->ns_x, s->ns_y,
+                       s->level1, s->level2, s->time_fraction, make_weights(w), G, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_interpolate_background(hipStream_t st, const GridDesc& G, const cf_atmos_source* s,
                                          const cf_interp_weights* w, const cf_exchange_fields* e) {
     const int n = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);

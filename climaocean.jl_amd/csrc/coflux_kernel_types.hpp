@@ -62,6 +62,7 @@ struct IceIn {
     const double* Jsio;
     const double* txio;
     const double* tyio;
+    const double* land;   // JRA55PrescribedLand freshwater (kg m⁻² s⁻¹) or nullptr — rides with the partition's inputs
 };
 
 struct IceStateIn {   // sea_ice.model fields the atmosphere–sea-ice interface reads (atmosphere.jl:34-39)
@@ -177,7 +178,7 @@ struct NetCell {
 
 __device__ __forceinline__ NetCell net_cell_local(const DevParams& P, double alb, double aice, double So, double Ts_kelvin,
                                                   double Mp, double Qs, double Ql, double Qc, double Qv, double Mv,
-                                                  double Qio, double Jsio) {
+                                                  double Qio, double Jsio, double Mland = 0.0) {
 #pragma clang fp contract(off)
     NetCell C;
     const double T2 = Ts_kelvin * Ts_kelvin;
@@ -190,7 +191,9 @@ __device__ __forceinline__ NetCell net_cell_local(const DevParams& P, double alb
     const double SFs = (So < P.S_min && SFao < 0.0) ? 0.0 : SFao;
     const double roc = P.rho_o_inv * P.c_o_inv;
     C.JT = SQao * roc + Qio * roc;
-    C.JS = (1.0 - aice) * (-So * SFs) + Jsio;
+    const double SFl = -Mland * P.rho_f_inv;                       // land freshwater (rivers, calving): not ice-masked
+    const double SFls = (So < P.S_min && SFl < 0.0) ? 0.0 : SFl;
+    C.JS = (1.0 - aice) * (-So * SFs) + Jsio + (-So * SFls);
     C.sw = Qts * roc;
     C.lw_up = Qu;
     C.lw_down = -Qal;

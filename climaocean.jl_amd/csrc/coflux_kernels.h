@@ -29,7 +29,7 @@ hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc
 hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
                             const cf_interface_fluxes* f, const cf_sea_ice_fields* ice = nullptr,
-                            const cf_net_ocean_fluxes* net = nullptr);
+                            const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr);
 hipError_t launch_net_stress(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* n);
 hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks,
@@ -39,7 +39,10 @@ hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridD
                                  const cf_exchange_fields* e, const cf_interface_fluxes* f);
 hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_exchange_fields* e, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
-                             const cf_interp_weights* w, const cf_net_ocean_fluxes* n);
+                             const cf_interp_weights* w, const cf_net_ocean_fluxes* n, const double* land = nullptr);
+hipError_t launch_interpolate_land(hipStream_t st, const GridDesc& G, const cf_land_source* s, const cf_interp_weights* w, double* out);
+hipError_t launch_salinity_restoring(hipStream_t st, const DevParams& P, const GridDesc& G, const void* mask, double vp,
+                                     const double* target, const double* S, double* out);
 hipError_t launch_interpolate_background(hipStream_t st, const GridDesc& G, const cf_atmos_source* s,
                                          const cf_interp_weights* w, const cf_exchange_fields* e);
 hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const IceParams& I,

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(NET_BLOCK) void net_flux_kernel(DevParams P, GridDe
         alb = P.albedo_diffuse - P.albedo_direct * cos(2.0 * phi * (CF_PI / 180.0));
     }
     const NetCell C = net_cell_local(P, alb, aice, O.S[k], F.Ts[k] + P.T_offset, E.Mp[k], E.Qs[k], E.Ql[k], F.Qc[k], F.Qv[k],
-                                     F.Fv[k], I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0);
+                                     F.Fv[k], I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0, I.land ? I.land[k] : 0.0);
     const double tx = net_face_stress(P, F.tx[kw], F.tx[k], aice_w, aice, I.txio ? I.txio[k] : 0.0);
     const double ty = net_face_stress(P, F.ty[ks], F.ty[k], aice_s, aice, I.tyio ? I.tyio[k] : 0.0);
     NetCell Z{};
@@ -64,18 +64,38 @@ __global__ __launch_bounds__(NET_BLOCK) void net_stress_kernel(DevParams P, Grid
 hipError_t launch_net_stress(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* n) {
     IceIn I{};
-    if (ice) I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress};
+    if (ice) I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress, nullptr};
     const int ncells = G.nx * G.ny;
     hipLaunchKernelGGL(net_stress_kernel, dim3((ncells + NET_BLOCK - 1) / NET_BLOCK), dim3(NET_BLOCK), 0, st, P, G, o->mask,
                        f->x_momentum, f->y_momentum, I, n->u, n->v);
     return hipGetLastError();
 }
 
+// SurfaceFluxRestoring materialised: J_add = v_p (Sₒ − S★) on wet interior cells, 0 elsewhere
+__global__ __launch_bounds__(NET_BLOCK) void salinity_restoring_kernel(DevParams P, GridDesc G, const void* mask, double vp,
+                                                                       const double* __restrict__ target, const double* __restrict__ S,
+                                                                       double* __restrict__ out) {
+    const int idx = (int)blockIdx.x * NET_BLOCK + (int)threadIdx.x;
+    if (idx >= G.nx * G.ny) return;
+    const int j = idx / G.nx;
+    const size_t k = cell_index(G, idx - j * G.nx, j);
+    out[k] = cell_is_wet(P, mask, k) ? vp * (S[k] - target[k]) : 0.0;
+}
+
+hipError_t launch_salinity_restoring(hipStream_t st, const DevParams& P, const GridDesc& G, const void* mask, double vp,
+                                     const double* target, const double* S, double* out) {
+    const int ncells = G.nx * G.ny;
+    hipLaunchKernelGGL(salinity_restoring_kernel, dim3((ncells + NET_BLOCK - 1) / NET_BLOCK), dim3(NET_BLOCK), 0, st, P, G, mask, vp,
+                       target, S, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_exchange_fields* e, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
-                             const cf_interp_weights* w, const cf_net_ocean_fluxes* n) {
+                             const cf_interp_weights* w, const cf_net_ocean_fluxes* n, const double* land) {
     IceIn I{};
-    if (ice) I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress};
+    if (ice) I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress, nullptr};
+    I.land = land;
     NetOut N{n->u, n->v, n->T, n->S, n->shortwave_surface_flux, n->upwelling_longwave, n->downwelling_longwave,
              n->downwelling_shortwave};
     const int ncells = G.nx * G.ny;

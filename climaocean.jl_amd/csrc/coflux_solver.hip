@@ -624,7 +624,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                         const NetOut N = kread(&Ke->N);
                         store_net_cell(N, k, net_cell_local(P, P.albedo, I.conc ? I.conc[k] : 0.0, So, R.Ts_ocean + P.T_offset,
                                                             Ke->E.Mp[k], Ke->E.Qs[k], Ke->E.Ql[k], R.Qc, R.Qv, R.Fv,
-                                                            I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0));
+                                                            I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0, I.land ? I.land[k] : 0.0));
                     }
                 }
             }
@@ -691,13 +691,15 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
 // shortwave, diagnostics; constant ocean albedo only), leaving the face stresses to launch_net_stress.
 hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
-                            const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net) {
+                            const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net,
+                            const double* land) {
     if (L.solver == CF_SOLVER_LIBM) return net ? hipErrorInvalidValue : launch_ao_fluxes_libm(st, P, G, o, e, f);
     OceanIn O = make_ocean(o);
     Exchange E = make_exchange(e);
     FluxOut F = make_fluxes(f);
     IceIn I{};
-    if (ice) I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress};
+    if (ice) I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress, nullptr};
+    I.land = land;
     NetOut N{};
     if (net)
         N = NetOut{net->u, net->v, net->T, net->S, net->shortwave_surface_flux, net->upwelling_longwave,

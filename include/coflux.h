@@ -557,6 +557,31 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
                             const cf_interface_fluxes* ai_fluxes, const double* frazil_heat,
                             const double* interface_heat, const cf_net_sea_ice_fluxes* net_ice);
 
+/* ------------------------------------------------------------------------------------------
+ * JRA55PrescribedLand(arch; …) (atmosphere.jl:46): river discharge `friver` and iceberg calving `licalvf`
+ * (jra55_data_staging.jl:8), kg m⁻² s⁻¹ on the JRA55 grid, the last two of the eleven staged variables.  Same window
+ * layout, same bilinear × linear-in-time interpolation as the atmosphere; the two are summed into ONE ocean-grid field.
+ * cf_set_land_freshwater hands that field to compute_net_ocean_fluxes!: the freshwater reaches the ocean as
+ *     JS += −Sₒ · (−M_land / ρ_f)      (not scaled by 1 − ℵ: rivers run under ice; the minimum-salinity guard applies)
+ * [UPSTREAM-RECALL: NumericalEarth adds the land freshwater flux to the ocean's freshwater budget; the line above is
+ * this library's statement of it, both oracles restate the same].  NULL switches it off.                          */
+typedef struct cf_land_source {
+    const float* friver;    /* device, [n_levels][ns_y][ns_x] */
+    const float* licalvf;   /* device, may be NULL */
+    int32_t ns_x, ns_y, n_levels, level1, level2, reserved;
+    double time_fraction;
+} cf_land_source;
+int cf_interpolate_land_freshwater(cf_ctx* ctx, const cf_land_source* src, const cf_interp_weights* w, double* d_out);
+int cf_set_land_freshwater(cf_ctx* ctx, const double* d_land_freshwater /* ocean-grid field, kg m⁻² s⁻¹, or NULL */);
+
+/* SurfaceFluxRestoring(DatasetRestoring(…; rate = piston_velocity / (Δz days))) riding on the salinity top boundary
+ * condition as the `additional_fluxes` of MultipleFluxes{flux_field, additional_fluxes} (omip_simulation.jl:175-206,
+ * 507-523): `_materialize_top_flux!` evaluates it into a 2-D buffer, J_add = v_p (Sₒ − S★) on wet cells (positive = salt
+ * leaves where the surface is saltier than the target).  The buffer is what cf_normalize_salinity_flux takes as
+ * d_additional; the ocean applies flux_field + additional.                                                      */
+int cf_materialize_salinity_restoring(cf_ctx* ctx, double piston_velocity /* m/s */, const double* d_target_salinity,
+                                      const cf_ocean_surface* ocean, double* d_buffer);
+
 /* NormalizeSalinity callback (src/OMIPConfigurations/omip_simulation.jl:182-220, added at :385-388):
  * subtract the global, area-weighted mean over wet cells of (salinity flux [+ additional flux]) from
  * the salinity-flux field — `compute!(mean_total); parent(flux_field) .-= mean_total`, so the constant

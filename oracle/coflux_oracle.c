@@ -572,6 +572,25 @@ int oracle_interpolate_atmosphere_state(const cf_grid* g, const cf_atmos_source*
     return 0;
 }
 
+/* JRA55PrescribedLand freshwater (river discharge + calving, kg m⁻² s⁻¹ on the ocean grid) for the next net-flux
+ * call, or NULL (include/coflux.h: cf_set_land_freshwater; [UPSTREAM-RECALL] for how it enters JS).               */
+static const double* g_land_freshwater = NULL;
+void oracle_set_land_freshwater(const double* land) { g_land_freshwater = land; }
+
+int oracle_interpolate_land_freshwater(const cf_grid* g, const cf_land_source* s, const cf_interp_weights* w, double* out) {
+    int r = g->ring;
+    for (int j = -r; j < g->ny + r; ++j)
+        for (int i = -r; i < g->nx + r; ++i) {
+            size_t k = IDX(g, i, j);
+            double fi = w->separable ? w->fi[i + g->hx] : w->fi[k];
+            double fj = w->separable ? w->fj[j + g->hy] : w->fj[k];
+            double v = interp_one(s->friver, s->ns_x, s->ns_y, s->level1, s->level2, s->time_fraction, fi, fj);
+            if (s->licalvf) v += interp_one(s->licalvf, s->ns_x, s->ns_y, s->level1, s->level2, s->time_fraction, fi, fj);
+            out[k] = v;
+        }
+    return 0;
+}
+
 int oracle_compute_net_ocean_fluxes(const cf_grid* g, const cf_flux_params* P, const cf_ocean_surface* o,
                                     const cf_exchange_fields* a, const cf_interface_fluxes* f,
                                     const cf_sea_ice_fields* ice, const cf_interp_weights* w,
@@ -627,7 +646,9 @@ int oracle_compute_net_ocean_fluxes(const cf_grid* g, const cf_flux_params* P, c
             out->u[k] = wetf * ((1.0 - ax) * txao + ax * txio);
             out->v[k] = wetf * ((1.0 - ay) * tyao + ay * tyio);
             out->T[k] = wetf * (JTao + JTio);
-            out->S[k] = wetf * ((1.0 - aice) * JSao + Jsio);
+            double SFl = g_land_freshwater ? -g_land_freshwater[k] * rho_f_inv : 0.0; /* rivers + calving, not ice-masked */
+            double SFls = (So < P->ocean_minimum_salinity && SFl < 0.0) ? 0.0 : SFl;
+            out->S[k] = wetf * ((1.0 - aice) * JSao + Jsio + (-So * SFls));
             if (out->shortwave_surface_flux) out->shortwave_surface_flux[k] = wetf * Qts * rho_o_inv / c_o;
             if (out->upwelling_longwave) out->upwelling_longwave[k] = wetf * Qu;
             if (out->downwelling_longwave) out->downwelling_longwave[k] = wetf * (-Qal);

@@ -438,7 +438,7 @@ def interpolate_atmosphere_state(src, fi2d, fj2d, level1, level2, tf, cos_rot=No
 
 
 def net_ocean_fluxes(ocean, atmos, fl, *, hx, hy, ocean_properties, albedo, emissivity=1.0,
-                     sigma=5.67e-8, min_salinity=0.0, penetrating=True, ice=None, latitude2d=None):
+                     sigma=5.67e-8, min_salinity=0.0, penetrating=True, ice=None, latitude2d=None, land=None):
     ny, nx = ocean["T"].shape[0] - 2 * hy, ocean["T"].shape[1] - 2 * hx
     C = (slice(hy, hy + ny), slice(hx, hx + nx))
     Wst = (slice(hy, hy + ny), slice(hx - 1, hx + nx - 1))
@@ -465,6 +465,8 @@ def net_ocean_fluxes(ocean, atmos, fl, *, hx, hy, ocean_properties, albedo, emis
     co = ocean_properties.heat_capacity
     SF = -atmos["Mp"][C] * rfi + fl["water_vapor"][C] * rfi
     SFs = np.where((So < min_salinity) & (SF < 0), 0.0, SF)
+    SFl = -(land[C] if land is not None else z) * rfi             # JRA55PrescribedLand: rivers + calving, not ice-masked
+    SFls = np.where((So < min_salinity) & (SFl < 0), 0.0, SFl)
     Qio = ice["interface_heat"][C] if ice else z
     Jsio = ice["salt_flux"][C] if ice else z
     txio = ice["x_stress"][C] if ice else z
@@ -473,7 +475,7 @@ def net_ocean_fluxes(ocean, atmos, fl, *, hx, hy, ocean_properties, albedo, emis
     tyao = 0.5 * (fl["y_momentum"][Sth] + fl["y_momentum"][C]) * roi
     ax, ay = 0.5 * (a_w + a_c), 0.5 * (a_s + a_c)
     res = dict(u=(1 - ax) * txao + ax * txio, v=(1 - ay) * tyao + ay * tyio,
-               T=SQ * roi / co + Qio * roi / co, S=(1 - a_c) * (-So * SFs) + Jsio,
+               T=SQ * roi / co + Qio * roi / co, S=(1 - a_c) * (-So * SFs) + Jsio + (-So * SFls),
                shortwave_surface_flux=Qts * roi / co, upwelling_longwave=Qu,
                downwelling_longwave=-Qal, downwelling_shortwave=-Qts)
     out = {}

@@ -152,8 +152,10 @@ def compute_atmosphere_ocean_fluxes(g, params, ocean, atmos, nthreads=1, scales=
     return out
 
 
-def compute_net_ocean_fluxes(g, params, ocean, atmos, fluxes, ice=None, weights=None, out=None):
+def compute_net_ocean_fluxes(g, params, ocean, atmos, fluxes, ice=None, weights=None, out=None, land=None):
     lib, keep = load(), []
+    land = None if land is None else _f64(land)
+    lib.oracle_set_land_freshwater(_ptr(land))
     names = ["u", "v", "T", "S", "shortwave_surface_flux", "upwelling_longwave",
              "downwelling_longwave", "downwelling_shortwave"]
     if out is None:
@@ -181,7 +183,26 @@ def compute_net_ocean_fluxes(g, params, ocean, atmos, fluxes, ice=None, weights=
     rc = lib.oracle_compute_net_ocean_fluxes(C.byref(g), C.byref(params), C.byref(o), C.byref(e),
                                              C.byref(f), C.byref(ice_s) if ice_s else None,
                                              C.byref(w), C.byref(nf))
+    lib.oracle_set_land_freshwater(None)
     assert rc == 0
+    return out
+
+
+def interpolate_land_freshwater(g, friver, licalvf, weights, level1=0, level2=1, time_fraction=0.0):
+    """JRA55PrescribedLand: friver (+ licalvf) [n_levels, ns_y, ns_x] float32 → one ocean-grid field."""
+    lib, keep = load(), []
+    s = abi.LandSource()
+    fr = np.ascontiguousarray(friver, dtype=np.float32)
+    s.friver = fr.ctypes.data
+    if licalvf is not None:
+        lc = np.ascontiguousarray(licalvf, dtype=np.float32)
+        keep.append(lc)
+        s.licalvf = lc.ctypes.data
+    s.n_levels, s.ns_y, s.ns_x = fr.shape
+    s.level1, s.level2, s.time_fraction = level1, level2, time_fraction
+    w = _weights_struct(weights, keep)
+    out = np.zeros(_shape(g))
+    assert lib.oracle_interpolate_land_freshwater(C.byref(g), C.byref(s), C.byref(w), _ptr(out)) == 0
     return out
 
 
