@@ -159,7 +159,7 @@ normalize_salinity_flux!(b::CoFluxBackend, flux::Ptr{Float64}, additional, area,
 # ---- atmosphere–sea-ice interface: compute_atmosphere_sea_ice_fluxes!(coupled_model) ---------------
 # SkinTemperature(ConductiveFlux) + SurfaceRadiationProperties(sea_ice_albedo, 1.0) (atmosphere.jl:34-44)
 mutable struct CfSeaIceParams
-    struct_size::Int32; reserved::Int32
+    struct_size::Int32; skin_temperature_scheme::Int32       # CF_SKIN_EXPLICIT = 0 / CF_SKIN_SEMI_IMPLICIT = 1
     conductivity::Float64; consolidation_thickness::Float64; maximum_temperature_change::Float64
     ice_salinity::Float64; liquidus_slope::Float64; freshwater_melting_temperature::Float64
     albedo::Float64; emissivity::Float64; temperature_offset::Float64
@@ -167,7 +167,7 @@ mutable struct CfSeaIceParams
 end
 struct CfSeaIceState   # sea_ice.model.{ice_concentration, ice_thickness, top_surface_temperature, velocities}
     concentration::Ptr{Float64}; thickness::Ptr{Float64}; top_temperature::Ptr{Float64}
-    u::Ptr{Float64}; v::Ptr{Float64}; albedo::Ptr{Float64}
+    u::Ptr{Float64}; v::Ptr{Float64}; albedo::Ptr{Float64}; snow_thickness::Ptr{Float64}   # snow: atmosphere.jl:34
 end
 function default_sea_ice_params()
     p = CfSeaIceParams()
@@ -237,8 +237,85 @@ end
 comm_unique_id() = (id = zeros(UInt8, 128); ccall((:cf_comm_unique_id, libcoflux), Cint, (Ptr{UInt8},), id); id)
 comm_init!(b, id::Vector{UInt8}, rank, nranks) =   # `id` is MPI.bcast from rank 0
     check(b.ctx, ccall((:cf_comm_init, libcoflux), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), b.ctx, id, rank, nranks))
-halo_exchange_rows!(b, fields::Vector{Ptr{Float64}}, rows = 1) =
+halo_exchange_rows!(b, fields::Vector{Ptr{Float64}}, rows = 2) =   # rows = ring + 1: the ring row reads v[j+1]
     check(b.ctx, ccall((:cf_halo_exchange_rows, libcoflux), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Cint, Cint),
                        b.ctx, fields, length(fields), rows))
+
+# ---- peer-direct halo rows (HIP IPC mailboxes; handles travel by MPI.Allgather) and the tripolar fold ----------------
+peer_halo_export!(b, max_fields = 4, max_rows = 2) = (h = zeros(UInt8, 64);
+    check(b.ctx, ccall((:cf_peer_halo_export, libcoflux), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), b.ctx, max_fields, max_rows, h)); h)
+peer_halo_connect!(b, south::Union{Nothing, Vector{UInt8}}, north::Union{Nothing, Vector{UInt8}}, rank, nranks) =
+    check(b.ctx, ccall((:cf_peer_halo_connect, libcoflux), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{UInt8}, Cint, Cint), b.ctx,
+                       isnothing(south) ? C_NULL : south, isnothing(north) ? C_NULL : north, rank, nranks))
+halo_exchange_rows_peer!(b, fields::Vector{Ptr{Float64}}, rows = 2) =
+    check(b.ctx, ccall((:cf_halo_exchange_rows_peer, libcoflux), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Cint, Cint),
+                       b.ctx, fields, length(fields), rows))
+# TripolarGrid: the last rank's north halo (T, S centres; u x-faces, v y-faces; vectors change sign) — one_degree_tripolar.jl:48-51
+fold_north_halo!(b, fields::Vector{Ptr{Float64}}, locations::Vector{Cint}, signs::Vector{Float64}, rows = 2) =
+    check(b.ctx, ccall((:cf_fold_north_halo, libcoflux), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Cint}, Ptr{Float64}, Cint, Cint),
+                       b.ctx, fields, locations, signs, length(fields), rows))
+
+# ---- pipelined update_state!: the prescribed atmosphere of the NEXT step on the auxiliary stream ---------------------
+prefetch_atmosphere_state!(b, src_next::CfAtmosSource, w::CfInterpWeights, out::CfExchangeFields) =
+    check(b.ctx, ccall((:cf_prefetch_atmosphere_state, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfAtmosSource}, Ref{CfInterpWeights}, Ref{CfExchangeFields}), b.ctx, src_next, w, out))
+
+# ---- run!(simulation) of a prescribed-ocean model inside the library (bench / offline forcing runs) -------------------
+struct CfRunSchedule
+    struct_size::Int32; n_ocean_states::Int32
+    ocean_states::Ptr{CfOceanSurface}
+    n_atmos_sets::Int32; pipeline::Int32
+    atmos::Ptr{CfExchangeFields}
+    first_level::Int32; halo_backend::Int32; halo_rows::Int32; fold_north::Int32
+    time_fraction::Float64; time_fraction_increment::Float64
+end
+time_steps!(b, first_step, nsteps, sched::CfRunSchedule, src, w, fluxes, ice, net) =
+    check(b.ctx, ccall((:cf_time_steps, libcoflux), Cint,
+                       (Ptr{Cvoid}, Int64, Cint, Ref{CfRunSchedule}, Ref{CfAtmosSource}, Ref{CfInterpWeights}, Ref{CfInterfaceFluxes},
+                        Ptr{CfSeaIceFields}, Ref{CfNetOceanFluxes}), b.ctx, first_step, nsteps, sched, src, w, fluxes, ice, net))
+
+# ---- SeaIceAlbedo(hi, hs, Ts) (atmosphere.jl:30-44) and compute_sea_ice_ocean_fluxes! (omip_simulation.jl:71-77) ------
+mutable struct CfSeaIceAlbedoParams
+    struct_size::Int32; reserved::Int32
+    ice_visible::Float64; ice_near_infrared::Float64; snow_visible::Float64; snow_near_infrared::Float64; ocean_albedo::Float64
+    reference_thickness::Float64; melt_temperature_range::Float64; ice_melt_change::Float64
+    snow_melt_change_visible::Float64; snow_melt_change_near_infrared::Float64; snow_patch_thickness::Float64
+    visible_fraction::Float64; melting_temperature::Float64
+    CfSeaIceAlbedoParams() = new()
+end
+default_sea_ice_albedo_params() = (p = CfSeaIceAlbedoParams();
+    ccall((:cf_default_sea_ice_albedo_params, libcoflux), Cint, (Ref{CfSeaIceAlbedoParams},), p); p)
+set_sea_ice_albedo!(b, p::CfSeaIceAlbedoParams) =
+    check(b.ctx, ccall((:cf_set_sea_ice_albedo, libcoflux), Cint, (Ptr{Cvoid}, Ref{CfSeaIceAlbedoParams}), b.ctx, p))
+compute_sea_ice_albedo!(b, p, hi, hs, Ts, out) =
+    check(b.ctx, ccall((:cf_compute_sea_ice_albedo, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfSeaIceAlbedoParams}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), b.ctx, p, hi, hs, Ts, out))
+mutable struct CfIceOceanParams   # ThreeEquationHeatFlux(; friction_velocity = MomentumBasedFrictionVelocity())
+    struct_size::Int32; reserved::Int32
+    heat_transfer_coefficient::Float64; salt_transfer_coefficient::Float64; minimum_friction_velocity::Float64
+    ice_density::Float64; latent_heat_of_fusion::Float64; ice_salinity::Float64; liquidus_slope::Float64
+    top_cell_thickness::Float64; time_step::Float64
+    CfIceOceanParams() = new()
+end
+struct CfIceOceanFluxes; interface_heat::Ptr{Float64}; salt_flux::Ptr{Float64}; frazil_heat::Ptr{Float64}; friction_velocity::Ptr{Float64}; end
+default_ice_ocean_params() = (p = CfIceOceanParams(); ccall((:cf_default_ice_ocean_params, libcoflux), Cint, (Ref{CfIceOceanParams},), p); p)
+compute_sea_ice_ocean_fluxes!(b, p::CfIceOceanParams, ocean::CfOceanSurface, concentration, x_stress, y_stress, out::CfIceOceanFluxes) =
+    check(b.ctx, ccall((:cf_compute_sea_ice_ocean_fluxes, libcoflux), Cint,
+                       (Ptr{Cvoid}, Ref{CfIceOceanParams}, Ref{CfOceanSurface}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{CfIceOceanFluxes}),
+                       b.ctx, p, ocean, concentration, x_stress, y_stress, out))
+
+# ---- JRA55PrescribedLand (atmosphere.jl:46) and the MultipleFluxes additional flux (omip_simulation.jl:175-206, 507-523) --
+struct CfLandSource
+    friver::Ptr{Float32}; licalvf::Ptr{Float32}
+    ns_x::Int32; ns_y::Int32; n_levels::Int32; level1::Int32; level2::Int32; reserved::Int32
+    time_fraction::Float64
+end
+interpolate_land_freshwater!(b, src::CfLandSource, w::CfInterpWeights, out) =
+    check(b.ctx, ccall((:cf_interpolate_land_freshwater, libcoflux), Cint, (Ptr{Cvoid}, Ref{CfLandSource}, Ref{CfInterpWeights}, Ptr{Float64}),
+                       b.ctx, src, w, out))
+set_land_freshwater!(b, field) = check(b.ctx, ccall((:cf_set_land_freshwater, libcoflux), Cint, (Ptr{Cvoid}, Ptr{Float64}), b.ctx, field))
+materialize_salinity_restoring!(b, piston_velocity, target, ocean::CfOceanSurface, buffer) =
+    check(b.ctx, ccall((:cf_materialize_salinity_restoring, libcoflux), Cint,
+                       (Ptr{Cvoid}, Float64, Ptr{Float64}, Ref{CfOceanSurface}, Ptr{Float64}), b.ctx, piston_velocity, target, ocean, buffer))
 
 end # module

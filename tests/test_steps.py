@@ -237,3 +237,63 @@ def test_fused_net_epilogue_is_bitwise_the_three_launch_sequence():
         for k in NET_NAMES:
             assert torch.equal(outs[0][1][k], outs[1][1][k]), k
     ctx.close()
+
+
+def _two_device_worker(rank, world, port, backend, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from coflux.distributed import SlabHaloExchanger
+        ctx, states, src, w, _np, j0, j1 = _slab(rank, world, device=rank)       # one rank per GPU
+        ny = j1 - j0
+        ex = SlabHaloExchanger(ctx, ny, H, backend=backend)
+        full = syn.ocean_state(NX, NY, H, H)
+        fields = [states[0][k] for k in ("T", "S", "u", "v")]
+        ok = True
+        for step in range(3):
+            _poison_halos(fields, ny, rank, world)
+            torch.cuda.synchronize()
+            ex(fields)
+            ctx.sync()
+            lo = H - 2 if rank > 0 else 0
+            hi = H + ny + 2 if rank < world - 1 else ny + 2 * H
+            for k, f in zip(("T", "S", "u", "v"), fields):
+                ok &= bool(np.array_equal(f.cpu().numpy()[lo:hi], full[k][j0 + lo:j0 + hi]))
+        # the all-reduce of the salinity normaliser over the two ranks (rccl backend only: it owns the communicator)
+        if backend == "rccl":
+            flux = ctx.to_device(np.where(_np[0]["mask"] != 0, 1.0 + rank, 0.0))
+            mean = ctx.zeros()[:1].contiguous()
+            ctx.normalize_salinity_flux(flux, states[0]["mask"], mean_out=mean)
+            ctx.sync()
+            wet = [int((syn.ocean_state(NX, b - a, H, H, ny_global=NY, j_offset=a)["mask"][H:H + b - a, H:H + NX] != 0).sum())
+                   for a, b in (slab_bounds(NY, r, world) for r in range(world))]
+            want = (1.0 * wet[0] + 2.0 * wet[1]) / (wet[0] + wet[1])
+            ok &= abs(float(mean.cpu()) - want) < 1e-12
+        out[rank] = ok
+        dist.barrier()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices (runs on the multi-GPU node, not on the 1-GPU test box)")
+@pytest.mark.parametrize("backend", ["rccl", "peer"])
+def test_halo_rows_between_two_devices(backend):
+    """One rank per GPU: native RCCL grouped send/recv (and its all-reduce in the salinity normaliser), and the peer-direct
+    mailboxes over xGMI, against the globally indexed state."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctxm = mp.get_context("spawn")
+    out = ctxm.Manager().dict()
+    procs = [ctxm.Process(target=_two_device_worker, args=(r, 2, port, backend, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    assert out.get(0) is True and out.get(1) is True, dict(out)
