@@ -180,6 +180,36 @@ __device__ __forceinline__ double2 psi_eval_mh(const double* psi, const PsiArg& 
     return make_double2(psi_eval(psi, 0, a), psi_eval(psi, 1, b));
 }
 
+// ψ_m(a) and ψ_h(b) from the general table with the coefficient reads kept exactly two steps ahead of their FMAs.
+// Written with fences because the scheduler, at the register cap, has been seen to choose either extreme for the
+// plain form: every read sunk next to its use (read, wait, FMA, … twenty LDS latencies in a row) or all twenty
+// reads first (forty registers, spills).  A fence with a "memory" clobber pins the LDS reads between two fences, and
+// passing the accumulators through it pins the FMAs.
+__device__ __forceinline__ double2 psi_eval_two(const double* psi, const PsiArg& a, const PsiArg& b) {
+    constexpr int S = 2 * PSI_SEG;
+    const double* ca = psi + ((size_t)(a.side * (PSI_DEG + 1)) * PSI_SEG + a.k) * 2;
+    const double* cb = psi + ((size_t)(b.side * (PSI_DEG + 1)) * PSI_SEG + b.k) * 2 + 1;
+    double qa[PSI_DEG + 1], qb[PSI_DEG + 1];
+    constexpr int AHEAD = 2;
+#pragma unroll
+    for (int j = PSI_DEG; j > PSI_DEG - AHEAD; --j) {
+        qa[j] = ca[j * S];
+        qb[j] = cb[j * S];
+    }
+    double pa = 0.0, pb = 0.0;
+#pragma unroll
+    for (int j = PSI_DEG; j >= 0; --j) {
+        asm volatile("" : "+v"(pa), "+v"(pb)::"memory");
+        if (j - AHEAD >= 0) {
+            qa[j - AHEAD] = ca[(j - AHEAD) * S];
+            qb[j - AHEAD] = cb[(j - AHEAD) * S];
+        }
+        pa = j == PSI_DEG ? qa[j] : __builtin_fma(pa, a.t, qa[j]);
+        pb = j == PSI_DEG ? qb[j] : __builtin_fma(pb, b.t, qb[j]);
+    }
+    return make_double2(pa, pb);
+}
+
 // ψ_m(zu), ψ_h(zq) for |zu|, |zq| < SMALL_Z0 and a common sign (both are a positive roughness length times 1/L★):
 // degree-SMALL_DEG polynomials in |ζ|, one 16-byte LDS read per coefficient pair (two distinct addresses per wave).
 __device__ __forceinline__ double2 psi_small_mh(const double* tab, bool unstable, double zu, double zq) {
@@ -453,9 +483,8 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
                         pl = psi_small_mh(tab, inv_L < 0.0, zu, zq);
                     } else {
                         asm volatile("" ::: "memory");
-                        // (the first iterates only: two plain 8-byte chains — fewer registers in flight than the paired form)
-                        pl.x = psi_eval(psi, 0, psi_arg(zu));
-                        pl.y = psi_eval(psi, 1, psi_arg(zq));
+                        // (the first iterates only: two 8-byte chains — fewer registers in flight than the paired form)
+                        pl = psi_eval_two(psi, psi_arg(zu), psi_arg(zq));
                     }
                     Du += pl.x;
                     Dq += pl.y;

@@ -271,10 +271,10 @@ size_t wet_list_capacity(int ncells) { return (size_t)chunk_table_capacity(ncell
 
 // zero_interface_state of a land cell: all fluxes 0, T = 0 K (and, in the fused path, zero net fluxes inside the interior)
 template <bool FUSE_NET>
-__device__ __forceinline__ void zero_cell(const LoopParams& L, const DevParams& P, const GridDesc& G, const FluxOut& F,
+__device__ __forceinline__ void zero_cell(const LoopParams& L, double T_offset, const GridDesc& G, const FluxOut& F,
                                           const NetOut& N, size_t k, int i, int j) {
     CellFluxes Z{};
-    Z.Ts_ocean = -P.T_offset;
+    Z.Ts_ocean = -T_offset;
     Z.iterations = L.fixed ? L.maxiter : 0;
     store_fluxes(F, k, Z);
     if constexpr (FUSE_NET) {
@@ -311,6 +311,9 @@ struct SolverArgs {
     NetOut N;
     IceStateIn S;   // SOLVER_SEAICE only
     IceParams Ice;
+    double z_surface;    // with mask_kind: how the start phase reads wetness before the parameter block is in LDS
+    long long mask_kind;
+    double T_offset;     // (zero_interface_state writes −T_offset; same reason)
 };
 typedef const SolverArgs __attribute__((address_space(4)))* SolverArgsPtr;
 
@@ -331,6 +334,19 @@ __device__ __forceinline__ SolverArgsPtr opaque(SolverArgsPtr p) {
     return p;
 }
 
+// two independent 32-bit mixes of a cell's linear index (murmur3's finaliser): XOR-accumulated over a set of cells
+// they make a 64-bit fingerprint of the set
+__device__ __forceinline__ unsigned mix32(unsigned h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ unsigned cell_hash_lo(unsigned idx) { return mix32(idx + 0x9e3779b9u); }
+__device__ __forceinline__ unsigned cell_hash_hi(unsigned idx) { return mix32(idx * 0x01000193u ^ 0x7f4a7c15u); }
+
 template <bool COARE, int SPEC, bool FUSE_NET>
 __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
     SolverArgsPtr K = opaque((SolverArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
@@ -344,10 +360,10 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
     // Land cells (≈30 % of a global grid) must not occupy lanes for 10–20 iterations: a workgroup works on the
     // LIST of its chunk's wet cells, counting-sorted by the trip count of the previous call (longest first), and
     // its waves pull 64 list entries at a time from an LDS cursor, so every lane that enters the solver holds an
-    // ocean cell and the lanes of a batch finish together.  Land gets its zeros in a pass at the END of the
-    // workgroup's life (other workgroups' iterations hide it), which also re-counts the wet cells of the range:
-    // a mask rewritten in place makes the static list stale, the count or a listed cell gives it away, and the
-    // workgroup redoes its range by classifying it — a stale list costs time, never correctness.
+    // ocean cell and the lanes of a batch finish together.  The list is static (built with the chunk table) and
+    // is checked against the mask as it is NOW in the start phase: a mask rewritten in place makes it stale, a
+    // 64-bit fingerprint of the range's wet set gives that away, and the workgroup redoes its range by classifying
+    // it — a stale list costs time, never correctness.  Land gets its zeros right behind the start phase.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tab = reinterpret_cast<double*>(smem);
     int* list = reinterpret_cast<int*>(smem + TABLE_BYTES);
@@ -360,50 +376,142 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
     const int wx = G.nx + 2 * G.ring;
     const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
     bool use_static = W.pos != nullptr;
-    // Order of the start phase: (1) my share of the chunk's static list — entries tid, tid + 256, … of a fixed-stride
-    // array, so nothing has to be looked up first: coalesced 4-byte and 1-byte loads, consumed after the barrier;
-    // (2) the parameters (ordinary loads into LDS); (3) the 45 KB of tables as LDS-DMA (global_load_lds, 1 KB per wave
-    // instruction, no VGPR round trip).  Vector memory returns in issue order, so the list arrives ahead of the table
-    // stream, and the first barrier deliberately does NOT drain the DMA: the tables are first read in the batch phase.
-    constexpr int PER_THREAD = AO_CHUNK / AO_BLOCK;
-    int my_idx[PER_THREAD], my_trip[PER_THREAD];
-    if (use_static) {
-        const size_t base = (size_t)chunk * AO_CHUNK + tid;
-#pragma unroll
-        for (int n = 0; n < PER_THREAD; ++n) {
-            my_idx[n] = (int)W.pos[base + n * AO_BLOCK];
-            my_trip[n] = W.trip ? (int)W.trip[base + n * AO_BLOCK] : AO_BINS - 1;
-        }
-    }
-    const int range_begin = chunk_begins[chunk], range_end = chunk_begins[chunk + 1];
-    for (int n = tid; n < (int)(sizeof(DevParams) / sizeof(double)); n += AO_BLOCK)
-        reinterpret_cast<double*>(lp)[n] = reinterpret_cast<const double*>(g_params)[n];
-    if (tid < 4) counters[tid] = 0;
-    if (tid < AO_BINS) hist[tid] = 0;
+    // Order of the start phase — everything is REQUESTED before anything is looked at, in straight-line code (a
+    // branch around a load makes the compiler wait for all memory at the next join):
+    // (1) the parameter block and the 45 KB of tables as LDS-DMA (global_load_lds, 1 KB per wave instruction, no VGPR
+    //     round trip): the long transfer first — the compiler drains it before the first LDS access behind the barrier
+    //     anyway (it cannot tell the DMA's destination from the lists');
+    // (2) my share of the chunk's static list — entries tid, tid + 256, … of a fixed-stride array, so nothing has to be
+    //     looked up first: coalesced 4-byte and 1-byte loads;
+    // (3) the raw mask words of my share of the chunk's cell range (validation and land, below): they depend on nothing
+    //     but the chunk table.  One aligned 4-byte word per cell of a byte mask, the two halves of the double for a
+    //     bottom-height mask — the same two load instructions either way, so no branch.
+    static_assert(sizeof(DevParams) % 16 == 0 && sizeof(DevParams) <= 1024, "the parameter block is one LDS-DMA piece");
+    static_assert(AO_PARAMS_OFFSET % 16 == 0, "LDS-DMA destination alignment");
+    if (tid < (int)(sizeof(DevParams) / 16))
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g_params) + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(smem + AO_PARAMS_OFFSET), 16, 0, 0);
     static_assert(TABLE_BYTES % 1024 == 0, "the table stage copies whole 1 KB pieces");
     {
         const char* gb = reinterpret_cast<const char*>(g_tab);
-        for (int c = tid >> 6; c < TABLE_BYTES / 1024; c += AO_BLOCK / 64)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + c * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(smem + c * 1024), 16, 0, 0);
+        constexpr int PIECES = TABLE_BYTES / 1024, WAVES = AO_BLOCK / 64;
+#pragma unroll
+        for (int r = 0; r < (PIECES + WAVES - 1) / WAVES; ++r) {
+            const int c = (tid >> 6) + r * WAVES;
+            if (c < PIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(smem + c * 1024), 16, 0, 0);
+        }
     }
+    constexpr int PER_THREAD = AO_CHUNK / AO_BLOCK;
+    constexpr int LAND_UNROLL = 8;  // strips of the range whose mask values are requested up front
+    typedef const __attribute__((address_space(1))) unsigned* GlobalWords;
+    int my_idx[PER_THREAD], my_trip[PER_THREAD];
+    unsigned raw_lo[LAND_UNROLL], raw_hi[LAND_UNROLL], raw_shift = 0;  // raw_shift: 2 bits per strip, the byte within its word
+    const int range_begin = chunk_begins[chunk], range_end = chunk_begins[chunk + 1];
+    const int mask_kind = (mask == nullptr) ? CF_MASK_NONE : (int)K->mask_kind;
+    const double z_surface = K->z_surface;
+    const double T_offset = K->T_offset;
+    if (use_static) {
+        const size_t base = (size_t)chunk * AO_CHUNK + tid;
+        const __attribute__((address_space(1))) uint32_t* gpos = (const __attribute__((address_space(1))) uint32_t*)W.pos;
+        // no hint array: the bytes are read from the list itself and replaced below
+        const __attribute__((address_space(1))) uint8_t* gtrip =
+            (const __attribute__((address_space(1))) uint8_t*)(W.trip ? (const void*)W.trip : (const void*)W.pos);
+#pragma unroll
+        for (int n = 0; n < PER_THREAD; ++n) my_idx[n] = (int)gpos[base + n * AO_BLOCK];
+#pragma unroll
+        for (int n = 0; n < PER_THREAD; ++n) my_trip[n] = (int)gtrip[base + n * AO_BLOCK];
+        // no mask: the words are read from the list and ignored
+        const unsigned long long mbase = mask_kind == CF_MASK_NONE ? (unsigned long long)W.pos : (unsigned long long)mask;
+        const unsigned stride = mask_kind == CF_MASK_NONE ? 0u : (mask_kind == CF_MASK_U8 ? 1u : 8u);
+        const unsigned hi_step = mask_kind == CF_MASK_BOTTOM_HEIGHT ? 4u : 0u;
+#pragma unroll
+        for (int n = 0; n < LAND_UNROLL; ++n) {
+            const int ic = min(range_begin + tid + n * AO_BLOCK, range_end - 1);
+            const int jj = ic / wx;
+            const unsigned long long a = mbase + (unsigned long long)cell_index(G, ic - jj * wx - G.ring, jj - G.ring) * stride;
+            raw_shift |= ((unsigned)a & 3u) << (2 * n);
+            raw_lo[n] = *(GlobalWords)(a & ~3ull);
+            raw_hi[n] = *(GlobalWords)((a & ~3ull) + hi_step);
+        }
+    }
+    if (tid < 4) counters[tid] = 0;
+    if (tid < AO_BINS) hist[tid] = 0;
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only: vmcnt / expcnt fields left at their maxima
     __builtin_amdgcn_s_barrier();
-    const DevParams& P = *lp;  // prologue-only parameters live in LDS, not in SGPRs
+    // (the values requested above are not to be looked at before this point: computing with them earlier would put
+    // a wait for memory in front of the table DMA's issue)
+    if (use_static) {
+#pragma unroll
+        for (int n = 0; n < PER_THREAD; ++n) asm volatile("" : "+v"(my_idx[n]), "+v"(my_trip[n]));
+#pragma unroll
+        for (int n = 0; n < LAND_UNROLL; ++n) asm volatile("" : "+v"(raw_lo[n]), "+v"(raw_hi[n]));
+        if (!W.trip) {
+#pragma unroll
+            for (int n = 0; n < PER_THREAD; ++n) my_trip[n] = AO_BINS - 1;
+        }
+    }
+    const DevParams& P = *lp;  // prologue-only parameters live in LDS, not in SGPRs (valid once the DMA has drained)
     const double* logt = tab + LOG_OFFSET;
 
     int nwet = 0;
     bool have_list = false;
     if (use_static) {
         // ---- counting sort of the static list by trip-count bin (all in LDS), longest first (LPT) ---------
-        bool dry = false;
+        // Alongside, the list is VALIDATED against the mask as it is now: the XOR of a 64-bit hash over the listed
+        // cells must equal the XOR over the wet cells of the chunk's range (a mask rewritten in place makes the static
+        // list stale; the workgroup then redoes its range by classifying it — a stale list costs time, never
+        // correctness).  The mask values were requested before the table DMA, so none of this waits for memory.
+        unsigned hx = 0, hy = 0;
 #pragma unroll
         for (int n = 0; n < PER_THREAD; ++n)
             if (my_idx[n] >= 0) {
                 atomicAdd(&hist[AO_BINS - 1 - min(my_trip[n], AO_BINS - 1)], 1);
-                const int jj = my_idx[n] / wx;  // the mask byte of every listed cell is requested now and looked at below
-                dry |= !cell_is_wet(P, mask, cell_index(G, my_idx[n] - jj * wx - G.ring, jj - G.ring));
+                hx ^= cell_hash_lo((unsigned)my_idx[n]);
+                hy ^= cell_hash_hi((unsigned)my_idx[n]);
             }
+        unsigned land = 0;  // bit n: strip n's cell is inside the range and dry — it gets its zeros after the last barrier
+#pragma unroll
+        for (int n = 0; n < LAND_UNROLL; ++n) {
+            const int idx = range_begin + tid + n * AO_BLOCK;
+            const bool w = mask_kind == CF_MASK_NONE ? true
+                           : mask_kind == CF_MASK_U8 ? ((raw_lo[n] >> (8 * ((raw_shift >> (2 * n)) & 3u))) & 0xffu) != 0
+                                                     : !(z_surface <= __hiloint2double((int)raw_hi[n], (int)raw_lo[n]));
+            if (idx < range_end) {
+                if (w) {
+                    hx ^= cell_hash_lo((unsigned)idx);
+                    hy ^= cell_hash_hi((unsigned)idx);
+                } else {
+                    land |= 1u << n;
+                }
+            }
+        }
+        // a range longer than LAND_UNROLL strips (a chunk that is mostly land): the rest the plain way, zeros at once
+        for (int idx = range_begin + tid + LAND_UNROLL * AO_BLOCK; idx < range_end; idx += AO_BLOCK) {
+            const int jj = idx / wx;
+            const int i = idx - jj * wx - G.ring, j = jj - G.ring;
+            const size_t k = cell_index(G, i, j);
+            const bool w = mask_kind == CF_MASK_NONE ? true
+                           : mask_kind == CF_MASK_U8 ? ((const uint8_t*)mask)[k] != 0 : !(z_surface <= ((const double*)mask)[k]);
+            if (w) {
+                hx ^= cell_hash_lo((unsigned)idx);
+                hy ^= cell_hash_hi((unsigned)idx);
+            } else {
+                SolverArgsPtr Kz = opaque(K);
+                const FluxOut F = kread(&Kz->F);
+                const NetOut N = kread(&Kz->N);
+                zero_cell<FUSE_NET>(L, T_offset, G, F, N, k, i, j);
+            }
+        }
+        for (int d = 32; d; d >>= 1) {
+            hx ^= (unsigned)__shfl_xor((int)hx, d);
+            hy ^= (unsigned)__shfl_xor((int)hy, d);
+        }
+        if (lane == 0) {
+            atomicXor(reinterpret_cast<unsigned*>(&counters[2]), hx);
+            atomicXor(reinterpret_cast<unsigned*>(&counters[3]), hy);
+        }
         __syncthreads();
         if (tid < 64) {  // exclusive scan of the AO_BINS (≤ 64) bin counts by one wave
             const int v = lane < AO_BINS ? hist[lane] : 0;
@@ -424,51 +532,36 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 list[p] = my_idx[n];
                 list_e[p] = (unsigned short)(tid + n * AO_BLOCK);
             }
-        // ---- land of the range gets its zeros; the same pass re-counts the wet cells: a mask rewritten in place
-        // makes the static list stale, the count or a listed cell gives it away (all of this hides under the table DMA)
-        int seen = 0;
-        {
-            SolverArgsPtr Kz = opaque(K);
-            const FluxOut F = kread(&Kz->F);
-            const NetOut N = kread(&Kz->N);
-            constexpr int LAND_UNROLL = 8;  // the mask bytes of eight strips are requested together
-            for (int base = range_begin + tid; base < range_end; base += AO_BLOCK * LAND_UNROLL) {
-                unsigned land = 0;  // bit n: strip n's cell is inside the range and dry
-#pragma unroll
-                for (int n = 0; n < LAND_UNROLL; ++n) {
-                    const int idx = base + n * AO_BLOCK;
-                    const int ic = min(idx, range_end - 1);
-                    const int jj = ic / wx;
-                    const bool w = cell_is_wet(P, mask, cell_index(G, ic - jj * wx - G.ring, jj - G.ring));
-                    if (idx < range_end) {
-                        seen += w ? 1 : 0;
-                        land |= w ? 0u : 1u << n;
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < LAND_UNROLL; ++n) {
-                    if (land & (1u << n)) {
-                        const int idx = base + n * AO_BLOCK;
-                        const int jj = idx / wx;
-                        const int i = idx - jj * wx - G.ring, j = jj - G.ring;
-                        zero_cell<FUSE_NET>(L, P, G, F, N, cell_index(G, i, j), i, j);
-                    }
-                }
-            }
-        }
-        for (int d = 32; d; d >>= 1) seen += __shfl_xor(seen, d);
-        if (lane == 0) atomicAdd(&counters[2], seen);
-        if (__any(dry) && lane == 0) atomicOr(&counters[3], 1);
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the table DMA has landed
         __syncthreads();
         nwet = counters[0];
-        have_list = counters[2] == nwet && counters[3] == 0;  // the list is the range's wet set
-        if (!have_list) {  // stale list: redo the range the slow way
+        have_list = (counters[2] | counters[3]) == 0;  // the list is the range's wet set
+        if (have_list) {
+            // zero_interface_state of the range's land, issued behind the last barrier: nothing waits for these stores
+            // but the first batch's loads, whose latency they share
+            if (land) {
+                SolverArgsPtr Kz = opaque(K);
+                const FluxOut F = kread(&Kz->F);
+                const NetOut N = kread(&Kz->N);
+#pragma unroll
+                for (int n = 0; n < LAND_UNROLL; ++n)
+                    if (land & (1u << n)) {
+                        const int idx = range_begin + tid + n * AO_BLOCK;
+                        const int jj = idx / wx;
+                        const int i = idx - jj * wx - G.ring, j = jj - G.ring;
+                        zero_cell<FUSE_NET>(L, T_offset, G, F, N, cell_index(G, i, j), i, j);
+                    }
+            }
+        } else {  // stale list: redo the range the slow way
             use_static = false;
             __syncthreads();
             if (tid < 4) counters[tid] = 0;
             __syncthreads();
         }
+    }
+    if (!use_static) {  // no list at all: the classification below reads the parameter block, which is still in flight
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
     }
     int begin = range_begin, end = range_end;
     for (;;) {
@@ -486,7 +579,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                         SolverArgsPtr Kz = opaque(K);
                         const FluxOut F = kread(&Kz->F);
                         const NetOut N = kread(&Kz->N);
-                        zero_cell<FUSE_NET>(L, P, G, F, N, k, i, j);
+                        zero_cell<FUSE_NET>(L, T_offset, G, F, N, k, i, j);
                     }
                 }
                 const unsigned long long m = __ballot(wet);
@@ -674,8 +767,10 @@ __global__ void debug_eval_kernel(int fn, int n, const double* __restrict__ x, d
 
 template <bool COARE, bool FUSE>
 static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const LoopParams& C, const GridDesc& G,
-                           const OceanIn& O, const Exchange& E, const FluxOut& F, const IceIn& I, const NetOut& N) {
-    const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip}, L.d_chunk_begins, I, N, IceStateIn{}, IceParams{}};
+                           const OceanIn& O, const Exchange& E, const FluxOut& F, const IceIn& I, const NetOut& N,
+                           double z_surface, long long mask_kind, double T_offset) {
+    const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip}, L.d_chunk_begins, I, N, IceStateIn{}, IceParams{},
+                       z_surface, mask_kind, T_offset};
 #define CF_LAUNCH(COARE_, SPEC_) \
     hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, FUSE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A)
     switch (C.specialization) {
@@ -709,11 +804,11 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     dim3 grid(L.n_chunks);
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
     if (net) {
-        if (coare) launch_ao_spec<true, true>(st, grid, L, C, G, O, E, F, I, N);
-        else launch_ao_spec<false, true>(st, grid, L, C, G, O, E, F, I, N);
+        if (coare) launch_ao_spec<true, true>(st, grid, L, C, G, O, E, F, I, N, P.z_surface, P.mask_kind, P.T_offset);
+        else launch_ao_spec<false, true>(st, grid, L, C, G, O, E, F, I, N, P.z_surface, P.mask_kind, P.T_offset);
     } else {
-        if (coare) launch_ao_spec<true, false>(st, grid, L, C, G, O, E, F, I, N);
-        else launch_ao_spec<false, false>(st, grid, L, C, G, O, E, F, I, N);
+        if (coare) launch_ao_spec<true, false>(st, grid, L, C, G, O, E, F, I, N, P.z_surface, P.mask_kind, P.T_offset);
+        else launch_ao_spec<false, false>(st, grid, L, C, G, O, E, F, I, N, P.z_surface, P.mask_kind, P.T_offset);
     }
     return hipGetLastError();
 }
@@ -737,6 +832,9 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     A.chunk_begins = L.d_chunk_begins;
     A.S = IceStateIn{ice->thickness, ice->top_temperature, ice->u, ice->v, ice->albedo};
     A.Ice = Ice;
+    A.z_surface = P.z_surface;
+    A.mask_kind = P.mask_kind;
+    A.T_offset = P.T_offset;
     dim3 grid(L.n_chunks);
     if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
         hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE, false>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A);
