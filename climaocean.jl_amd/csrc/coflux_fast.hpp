@@ -304,6 +304,31 @@ __device__ __forceinline__ double flog_pos(const double* logt, double x) {
     return __builtin_fma((double)e, 0.6931471805599453094, __builtin_fma(r * r, q, r) + ck.y);
 }
 
+// flog_pos in two halves, so that the table read can be started well ahead of the polynomial (the LDS latency then
+// hides under whatever is computed in between); same operations, same order: bitwise flog_pos.
+struct LogHalf {
+    double2 ck;
+    double m;
+    int e;
+};
+__device__ __forceinline__ LogHalf flog_pos_begin(const double* logt, double x) {
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    LogHalf h;
+    h.e = (hi >> 20) - 1023;
+    const int k = (hi >> 13) & (LOG_SEG - 1);
+    h.m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
+    h.ck = *reinterpret_cast<const double2*>(logt + 2 * k);
+    return h;
+}
+__device__ __forceinline__ double flog_pos_end(const LogHalf& h) {
+    const double r = __builtin_fma(h.m, h.ck.x, -1.0);
+    double q = __builtin_fma(r, -1.0 / 6.0, 1.0 / 5.0);
+    q = __builtin_fma(r, q, -1.0 / 4.0);
+    q = __builtin_fma(r, q, 1.0 / 3.0);
+    q = __builtin_fma(r, q, -1.0 / 2.0);
+    return __builtin_fma((double)h.e, 0.6931471805599453094, __builtin_fma(r * r, q, r) + h.ck.y);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Parameter split.  The iteration touches ~25 uniform scalars; the per-cell prologue touches ~60
 // more.  Passing all of DevParams by value makes the compiler hoist every field into SGPRs and
@@ -422,6 +447,17 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
         if (go) {
             const double bstar = c.gTv * __builtin_fma(ts, c.b_theta, c.b_q * qq);
             const double Jb = -us * bstar;
+            const double inv_us = frcp1(us);
+            double lu = 0.0;
+            LogHalf half_u, half_q;
+            if constexpr (SPEC == SOLVER_OCEAN) {
+                // the two log-table reads are started here and used behind the gustiness block, whose ≈ 40
+                // instructions cover their latency (the fence keeps the reads from being sunk next to their use)
+                lu = fmin(__builtin_fma(c.alpha_g * us, us, c.lam_nu * inv_us), L.lm_m);
+                half_u = flog_pos_begin(logt, lu);
+                half_q = flog_pos_begin(logt, lu * us * c.inv_nu_q);
+                asm volatile("" ::: "memory");
+            }
             // gustiness: U_G = max(β·cbrt(max(Jᵇ,0)·h_bl), U_G,min); the cube root only where Jᵇ > 0
             double U = c.U_calm;
             if (L.beta_gust != 0.0 && __any(Jb > 0.0)) {
@@ -430,12 +466,10 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
                 U = Jb > 0.0 ? Uc : c.U_calm;
             }
 
-            const double inv_us = frcp1(us);
-            double lu, log_lu, log_lq, log_lt;
+            double log_lu, log_lq, log_lt;
             if constexpr (SPEC == SOLVER_OCEAN) {
-                lu = fmin(__builtin_fma(c.alpha_g * us, us, c.lam_nu * inv_us), L.lm_m);
-                log_lu = flog_pos(logt, lu);
-                log_lq = fmin(__builtin_fma(-L.b_q, flog_pos(logt, lu * us * c.inv_nu_q), L.log_A_q), L.log_lm_q);
+                log_lu = flog_pos_end(half_u);
+                log_lq = fmin(__builtin_fma(-L.b_q, flog_pos_end(half_q), L.log_A_q), L.log_lm_q);
                 log_lt = log_lq;
             } else if constexpr (SPEC == SOLVER_ICE) {
                 lu = L.const_m;
