@@ -7,9 +7,8 @@
 // Design.  The gather (4 corners × 18 planes = 72 dwords per cell) is bound by the vector-memory
 // address path, not by HBM: 72 scattered dword loads per lane cost ≈ 16 cycles each in the
 // texture-address unit.  So every WAVE stages the source footprint of its own 64 × ROWS cell tile
-// in LDS (≈ 31 × 4 source nodes per variable at 1/4°, both time levels interleaved as float2) with
-// ≈ 9 coalesced loads per cell, and then reads each variable's four corners with two 16-byte LDS
-// reads.  Tiles belong to waves, not workgroups: there is no __syncthreads() anywhere, so the
+// in LDS (≈ 31 × 4 source nodes per variable at 1/4°, the two time levels already blended, as doubles)
+// with ≈ 9 coalesced loads per cell, and then reads each variable's four corners from there.  Tiles belong to waves, not workgroups: there is no __syncthreads() anywhere, so the
 // waves of a CU hide each other's load latency.
 #include <hip/hip_runtime.h>
 
@@ -25,15 +24,31 @@ __device__ __forceinline__ int wrap_index(int i, int n) {
     return r < 0 ? r + n : r;
 }
 
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
-    return v;
+// Wave-wide min / max as a wave-uniform value.  Four DPP steps (xor 1, xor 2, mirror within 8, mirror within 16)
+// leave every lane with its 16-lane row's result, then one lane per row is read: ≈ 10 short instructions, where the
+// __shfl_xor butterfly is six dependent ds_bpermute round trips through LDS (four such reductions open every tile).
+template <bool MIN>
+__device__ __forceinline__ int wave_reduce(int v) {
+    auto op = [](int a, int b) { return MIN ? min(a, b) : max(a, b); };
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return op(op(a, b), op(c, d));
 }
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
-    return v;
+__device__ __forceinline__ int wave_min(int v) { return wave_reduce<true>(v); }
+__device__ __forceinline__ int wave_max(int v) { return wave_reduce<false>(v); }
+
+// The two halves of a cell's value, shared by every kernel in this file so that they agree bitwise: a source node's
+// two time levels are blended first (once per NODE in the tiled kernel: a tile has half as many nodes as it has cell
+// corners, and the f32→f64 conversions go with them), the four blended corners are interpolated second.  The
+// reference interpolates each level and blends last; the two orders differ by rounding (≈ 1e-16 relative).
+__device__ __forceinline__ double blend_levels(float a, float b, double tf) { return (double)b * tf + (double)a * (1.0 - tf); }
+__device__ __forceinline__ double bilinear(double w00, double w01, double w10, double w11, double c00, double c01, double c10,
+                                           double c11) {
+    return w00 * c00 + w01 * c01 + w10 * c10 + w11 * c11;
 }
 
 // LDS traffic of one wave is ordered by issue; this only stops the compiler from moving accesses.
@@ -47,7 +62,7 @@ __global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S
                                                                      Exchange E, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float2* tile = reinterpret_cast<float2*>(smem) + (size_t)wave * CF_JRA55_NVARS * cap;
+    double* tile = reinterpret_cast<double*>(smem) + (size_t)wave * CF_JRA55_NVARS * cap;
 
     const int wx = G.nx + 2 * G.ring, wy = G.ny + 2 * G.ring;
     const int tiles_x = (wx + 63) / 64, tiles_y = (wy + ROWS - 1) / ROWS;
@@ -98,7 +113,7 @@ __global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S
         const int W = hi - lo + 1, H = jhi - jlo + 1, WH = W * H;
         const bool fits = WH <= cap && W <= S.ns_x;
 
-        // ---- stage the footprint: tile[var][y][x] = (level1, level2) -------------------------------
+        // ---- stage the footprint: tile[var][y][x] = the node's value at the time fraction ---------------
         if (fits) {
             const float inv_W = 1.0f / (float)W;
             for (int rem = lane; rem < WH; rem += 64) {
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S
                 const size_t off = (size_t)(jlo + y) * S.ns_x + wrap_index(ref + lo + x, S.ns_x);
 #pragma unroll
                 for (int v = 0; v < CF_JRA55_NVARS; ++v)
-                    tile[v * cap + rem] = make_float2(S.data[v][off1 + off], S.data[v][off2 + off]);
+                    tile[v * cap + rem] = blend_levels(S.data[v][off1 + off], S.data[v][off2 + off], S.tf);
             }
         }
         wave_lds_sync();
@@ -123,11 +138,8 @@ __global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S
                 const int o00 = (j0[r] - jlo) * W + (d0[r] - lo), o01 = (j1[r] - jlo) * W + (d0[r] - lo);
 #pragma unroll
                 for (int v = 0; v < CF_JRA55_NVARS; ++v) {
-                    const float2* p = tile + v * cap;
-                    const float2 a00 = p[o00], a10 = p[o00 + di[r]], a01 = p[o01], a11 = p[o01 + di[r]];
-                    const double v1 = w00 * (double)a00.x + w01 * (double)a01.x + w10 * (double)a10.x + w11 * (double)a11.x;
-                    const double v2 = w00 * (double)a00.y + w01 * (double)a01.y + w10 * (double)a10.y + w11 * (double)a11.y;
-                    val[v] = v2 * S.tf + v1 * (1.0 - S.tf);
+                    const double* p = tile + v * cap;
+                    val[v] = bilinear(w00, w01, w10, w11, p[o00], p[o01], p[o00 + di[r]], p[o01 + di[r]]);
                 }
             } else {  // footprint too large for the tile (coarse target grid): gather from L2
                 const int is0 = wrap_index(ref + d0[r], S.ns_x), is1 = wrap_index(ref + d0[r] + di[r], S.ns_x);
@@ -137,9 +149,8 @@ __global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S
                 for (int v = 0; v < CF_JRA55_NVARS; ++v) {
                     const float* a = S.data[v] + off1;
                     const float* b = S.data[v] + off2;
-                    const double v1 = w00 * (double)a[g00] + w01 * (double)a[g01] + w10 * (double)a[g10] + w11 * (double)a[g11];
-                    const double v2 = w00 * (double)b[g00] + w01 * (double)b[g01] + w10 * (double)b[g10] + w11 * (double)b[g11];
-                    val[v] = v2 * S.tf + v1 * (1.0 - S.tf);
+                    val[v] = bilinear(w00, w01, w10, w11, blend_levels(a[g00], b[g00], S.tf), blend_levels(a[g01], b[g01], S.tf),
+                                      blend_levels(a[g10], b[g10], S.tf), blend_levels(a[g11], b[g11], S.tf));
                 }
             }
             if (i < G.nx + G.ring && j < G.ny + G.ring) {
@@ -196,13 +207,12 @@ __global__ __launch_bounds__(256) void interpolate_gather_kernel(SourceDesc S, W
     const unsigned plane = (unsigned)(S.ns_x * S.ns_y);
     const unsigned off1 = (unsigned)S.level1 * plane, off2 = (unsigned)S.level2 * plane;
     const double w00 = (1.0 - xi) * (1.0 - eta), w01 = (1.0 - xi) * eta, w10 = xi * (1.0 - eta), w11 = xi * eta;
-    // same operation order as the tiled kernel (bitwise-identical results)
+    // same operations in the same order as the tiled kernel (bitwise-identical results)
     auto value = [&](int v) {
         const float* a = S.data[v] + off1;
         const float* b = S.data[v] + off2;
-        const double v1 = w00 * (double)a[g00] + w01 * (double)a[g01] + w10 * (double)a[g10] + w11 * (double)a[g11];
-        const double v2 = w00 * (double)b[g00] + w01 * (double)b[g01] + w10 * (double)b[g10] + w11 * (double)b[g11];
-        return v2 * S.tf + v1 * (1.0 - S.tf);
+        return bilinear(w00, w01, w10, w11, blend_levels(a[g00], b[g00], S.tf), blend_levels(a[g01], b[g01], S.tf),
+                        blend_levels(a[g10], b[g10], S.tf), blend_levels(a[g11], b[g11], S.tf));
     };
     // One variable at a time in a rolled loop: ≤ 56 VGPRs is what fits beside three resident solver waves per
     // SIMD (3 × 152 of 512 registers).
@@ -254,9 +264,8 @@ __global__ __launch_bounds__(256) void interpolate_land_kernel(const float* __re
     auto value = [&](const float* d) {
         const float* a = d + (size_t)level1 * plane;
         const float* b = d + (size_t)level2 * plane;
-        const double v1 = w00 * (double)a[g00] + w01 * (double)a[g01] + w10 * (double)a[g10] + w11 * (double)a[g11];
-        const double v2 = w00 * (double)b[g00] + w01 * (double)b[g01] + w10 * (double)b[g10] + w11 * (double)b[g11];
-        return v2 * tf + v1 * (1.0 - tf);
+        return bilinear(w00, w01, w10, w11, blend_levels(a[g00], b[g00], tf), blend_levels(a[g01], b[g01], tf),
+                        blend_levels(a[g10], b[g10], tf), blend_levels(a[g11], b[g11], tf));
     };
     out[k] = value(friver) + (licalvf ? value(licalvf) : 0.0);
 }
@@ -279,13 +288,24 @@ hipError_t launch_interpolate_background(hipStream_t st, const GridDesc& G, cons
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
                               const cf_interp_weights* w, const cf_exchange_fields* e) {
     if (L.interp_cap == 0) return launch_interpolate_background(st, G, s, w, e);  // CF_OPT_INTERP_TILE_CAP = 0
-    constexpr int ROWS = 4;
+    // Rows of 64 cells per wave tile.  A tile is one dependent chain (indices → footprint → LDS → 8 stores per row),
+    // and on a surface that does not fill the device's wave slots the kernel's time IS that chain: fewer rows per
+    // tile then mean more waves and a shorter chain (1440×70: 7.8 → 5.4 µs with one row), while on the full surface
+    // four rows amortise the footprint best (measured; thresholds in tiles of four rows, per 256 CUs).
     const int wx = G.nx + 2 * G.ring, wy = G.ny + 2 * G.ring;
-    const int ntiles = ((wx + 63) / 64) * ((wy + ROWS - 1) / ROWS);
+    const int tiles_x = (wx + 63) / 64;
+    const long tiles4 = (long)tiles_x * ((wy + 3) / 4) * 256 / (L.cu_count > 0 ? L.cu_count : 256);
+    const int rows = tiles4 >= 1200 ? 4 : (tiles4 >= 600 ? 2 : 1);
+    const int ntiles = tiles_x * ((wy + rows - 1) / rows);
     const int blocks = (ntiles + IT_WAVES - 1) / IT_WAVES;
-    const size_t lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(float2);
-    hipLaunchKernelGGL(interpolate_kernel<ROWS>, dim3(blocks), dim3(64 * IT_WAVES), lds, st, make_source(s),
-                       make_weights(w), G, make_exchange(e), L.interp_cap);
+    const size_t lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double);
+#define CF_LAUNCH_INTERP(ROWS_)                                                                                        \
+    hipLaunchKernelGGL(interpolate_kernel<ROWS_>, dim3(blocks), dim3(64 * IT_WAVES), lds, st, make_source(s),          \
+                       make_weights(w), G, make_exchange(e), L.interp_cap)
+    if (rows == 4) CF_LAUNCH_INTERP(4);
+    else if (rows == 2) CF_LAUNCH_INTERP(2);
+    else CF_LAUNCH_INTERP(1);
+#undef CF_LAUNCH_INTERP
     return hipGetLastError();
 }
 
