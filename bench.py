@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--pipeline", choices=("auto", "on", "off"), default="auto",
                     help="interpolate the next step's atmosphere on the auxiliary stream during the solver; auto: only on "
                          "slabs too small to fill the device (beside a full-size solver the gather kernel costs more than it hides)")
+    ap.add_argument("--net-diagnostics", action="store_true",
+                    help="also write the three optional radiation diagnostics of cf_net_ocean_fluxes (24 B/cell beyond "
+                         "the 88 + 40 B/cell contract of compute_net_ocean_fluxes!, SURVEY.md §8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample: passes that fit this wall time")
     return ap.parse_args()
@@ -87,8 +90,7 @@ def cpu_baseline(case_np, params, nx, ny, h, seconds):
     shape = (ny + 2 * h, nx + 2 * h)
     atmos = {n: np.zeros(shape) for n in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
     fl = {n: np.zeros(shape) for n in ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum", "temperature")}
-    net = {n: np.zeros(shape) for n in ("u", "v", "T", "S", "shortwave_surface_flux", "upwelling_longwave",
-                                        "downwelling_longwave", "downwelling_shortwave")}
+    net = {n: np.zeros(shape) for n in ("u", "v", "T", "S", "shortwave_surface_flux")}
 
     def one_pass():
         t0 = time.perf_counter()
@@ -185,7 +187,9 @@ def main():
     pipeline = a.pipeline == "on" or (a.pipeline == "auto" and (nx + 2) * (ny + 2) < 300_000)
     atmos_sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2 if pipeline else 1)]
     fl = ctx.field_set(FLUX_NAMES)
-    net = ctx.field_set(NET_NAMES)
+    # compute_net_ocean_fluxes! writes five fields (τx, τy, Jᵀ, Jˢ, penetrating shortwave: the 40 B/cell of the contract);
+    # the ABI's three radiation diagnostics are optional outputs and off unless asked for
+    net = ctx.field_set(NET_NAMES if a.net_diagnostics else NET_NAMES[:5])
 
     ice = ice_state = ai = net_ice = None
     if a.config == "sea_ice":
