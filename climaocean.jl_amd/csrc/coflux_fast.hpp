@@ -133,6 +133,9 @@ __device__ __forceinline__ PsiArg psi_arg(double zeta) {
     const double x = fmin(__builtin_fma(PSI_A, fabs(zeta), 1.0), 0x1.fffffffffffffp33);
     const int hi = __double2hiint(x);
     a.k = (hi >> 18) - (1023 << 2);
+    // (opaque to the compiler: it otherwise folds the exponent bias into every coefficient's address, which makes the
+    // ten LDS offsets negative — not encodable — and costs one v_add per coefficient read)
+    asm("" : "+v"(a.k));
     a.t = x - __hiloint2double(hi & (int)0xfffc0000, 0);
     a.side = zeta < 0.0 ? 0 : 1;
     return a;

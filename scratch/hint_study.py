@@ -1,0 +1,102 @@
+"""CPU study: how much of the trip-count sort survives one step of the bench's input evolution, and what a key refined
+by the last drift's margin below the tolerance would recover.  (oracle only; no GPU)"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "climaocean.jl_amd"))
+import numpy as np
+import oracle as orc
+from coflux import synthetic as syn, interface_computations as ic
+nx, ny, h = 720, 280, 3
+g = orc.make_grid(nx, ny, h, h, 1)
+oc0 = syn.ocean_state(nx, ny, h, h, ny_global=560, j_offset=140)
+oc1 = syn.evolved_ocean_state(oc0, nx, ny, h, h, 1, ny_global=560, j_offset=140)
+src = syn.jra55_snapshots(4, temporal_correlation=0.95)
+fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h, ny_global=560, j_offset=140)
+w = dict(separable=True, fi=fi, fj=fj)
+inc = 20.0 / 180.0
+cfg = sys.argv[1] if len(sys.argv) > 1 else "default"
+mk = {"default": ic.SimilarityTheoryFluxes, "corrected": ic.corrected_atmosphere_ocean_fluxes}[cfg]
+P = ic.flux_params(mk())
+W = (slice(h - 1, h + ny + 1), slice(h - 1, h + nx + 1))
+def run(step, fixed=None):
+    tf = step * inc
+    at = orc.interpolate_atmosphere_state(g, src, w, 0, 1, tf)
+    oc = oc0 if step % 2 == 0 else oc1
+    if fixed is None:
+        return orc.compute_atmosphere_ocean_fluxes(g, P, oc, at, nthreads=8)
+    Pf = ic.flux_params(mk(solver_stop_criteria=ic.FixedIterations(fixed)))
+    return orc.compute_atmosphere_ocean_fluxes(g, Pf, oc, at, nthreads=8)
+a0, a1 = run(4), run(5)
+wet = oc0["mask"][W] != 0
+t0 = a0["iterations"][W][wet].astype(int); t1 = a1["iterations"][W][wet].astype(int)
+d = t1 - t0
+print(cfg, "cells", t0.size, "mean trips", t0.mean(), "P(d):", {k: round(float((d == k).mean()), 3) for k in range(-3, 4)})
+# final drift of step 4 per cell: |x_t - x_{t-1}| from fixed-iteration runs
+tmax = int(t0.max())
+X = {}
+for n in range(max(1, int(t0.min()) - 1), tmax + 1):
+    r = run(4, fixed=n)
+    X[n] = np.stack([r["friction_velocity"][W][wet], r["temperature_scale"][W][wet], r["humidity_scale"][W][wet]])
+drift = np.zeros(t0.size); prev = np.zeros(t0.size)
+for n in range(int(t0.min()), tmax + 1):
+    m = t0 == n
+    if n - 1 in X:
+        drift[m] = np.abs(X[n][:, m] - X[n - 1][:, m]).sum(0)
+    if n - 2 in X:
+        prev[m] = np.abs(X[n - 1][:, m] - X[n - 2][:, m]).sum(0)
+tol = 1e-8
+ok = (drift > 0) & (prev > 0)
+rate = np.where(ok, np.log(prev / np.maximum(drift, 1e-300)), 2.0)   # log contraction per iteration
+margin = np.where(ok, np.log(tol / np.maximum(drift, 1e-300)) / np.maximum(rate, 0.2), 0.5)  # in iterations, 0..1: how far below tol the last drift was
+print("margin quantiles", np.quantile(margin[ok], [0.05, 0.25, 0.5, 0.75, 0.95]), "rate q", np.quantile(rate[ok], [0.05, 0.5, 0.95]))
+for k in (-1, 0, 1):
+    print("  d=%d: mean margin %.3f" % (k, margin[(d == k) & ok].mean()))
+def eff(key, chunk=1024):
+    n = (t1.size // chunk) * chunk
+    K = key[:n].reshape(-1, chunk); T = t1[:n].reshape(-1, chunk)
+    order = np.argsort(-K, axis=1, kind="stable")
+    Ts = np.take_along_axis(T, order, 1)
+    return Ts.reshape(-1, chunk // 64, 64).max(2).mean()
+print("mean t1 %.3f | batches: unsorted %.3f  key=t0 %.3f  key=t1 (perfect) %.3f" % (t1.mean(), eff(np.zeros(t1.size)), eff(t0.astype(float)), eff(t1.astype(float))))
+for q in (2, 4, 8):
+    key = t0 - np.floor(np.clip(margin, 0, 0.999) * q) / q
+    print("  key = t0 - floor(margin*%d)/%d: %.3f" % (q, q, eff(key)))
+key = t0 - np.clip(margin, 0, 0.999)
+print("  key = t0 - margin (continuous): %.3f" % eff(key))
+
+# ---- monotonic evolution (ocean drifting linearly, clock advancing) and extrapolated keys ------------------------
+print("--- monotonic drift: ocean_n = ocean_0 + n*(ocean_1 - ocean_0)")
+def ocean_at(n):
+    o = dict(oc0)
+    for k in ("T", "S", "u", "v"):
+        o[k] = oc0[k] + n * (oc1[k] - oc0[k])
+    return o
+def run2(step, fixed=None):
+    at = orc.interpolate_atmosphere_state(g, src, w, 0, 1, step * inc)
+    Pq = P if fixed is None else ic.flux_params(mk(solver_stop_criteria=ic.FixedIterations(fixed)))
+    return orc.compute_atmosphere_ocean_fluxes(g, Pq, ocean_at(step), at, nthreads=8)
+def trips_and_c(step):
+    a = run2(step)
+    t = a["iterations"][W][wet].astype(int)
+    X = {}
+    for n in range(max(1, int(t.min()) - 2), int(t.max()) + 1):
+        r = run2(step, fixed=n)
+        X[n] = np.stack([r["friction_velocity"][W][wet], r["temperature_scale"][W][wet], r["humidity_scale"][W][wet]])
+    dr = np.full(t.size, np.nan); pv = np.full(t.size, np.nan)
+    for n in range(int(t.min()), int(t.max()) + 1):
+        m = t == n
+        if n - 1 in X: dr[m] = np.abs(X[n][:, m] - X[n - 1][:, m]).sum(0)
+        if n - 2 in X: pv[m] = np.abs(X[n - 1][:, m] - X[n - 2][:, m]).sum(0)
+    good = np.isfinite(dr) & np.isfinite(pv) & (dr > 0) & (pv > dr)
+    rate = np.where(good, np.log(np.where(good, pv, 2.0) / np.where(good, dr, 1.0)), 2.0)
+    mg = np.where(good, np.clip(np.log(tol / np.where(good, dr, tol)) / np.maximum(rate, 0.2), 0, 0.999), 0.5)
+    return t, t - mg
+tA, cA = trips_and_c(3); tB, cB = trips_and_c(4); t1 = run2(5)["iterations"][W][wet].astype(int)
+d = t1 - tB
+print("P(d):", {k: round(float((d == k).mean()), 3) for k in range(-2, 3)})
+print("batches: key=t(n) %.3f   perfect %.3f   mean %.3f" % (eff(tB.astype(float)), eff(t1.astype(float)), t1.mean()))
+print("  key = c(n)                 %.3f" % eff(cB))
+chat = 2 * cB - cA
+print("  key = 2c(n) - c(n-1)       %.3f   ceil of it %.3f" % (eff(chat), eff(np.ceil(chat))))
+print("  key = 2t(n) - t(n-1)       %.3f" % eff(2.0 * tB - tA))
+hit = (np.ceil(chat) == t1).mean(); print("  ceil(extrapolated c) == t(n+1): %.3f   t(n) == t(n+1): %.3f" % (hit, (tB == t1).mean()))
