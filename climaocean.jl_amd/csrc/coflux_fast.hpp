@@ -255,8 +255,27 @@ __device__ __forceinline__ void stage_tables(double* lds_tab, const double* __re
 // ---------------------------------------------------------------------------------------------
 // per-cell constants shared by the iteration
 // ---------------------------------------------------------------------------------------------
+// saturation_vapor_pressure(param_set, T, LH_0, Δcp) = p_tr · exp(a·log(T/T_tr) + b·(1/T_tr − 1/T)): the logarithm and the
+// reciprocal difference depend on T only and are shared by every phase partition evaluated at that temperature
+struct SvpArg {
+    double L, D;
+};
+__device__ __forceinline__ SvpArg svp_arg(const DevParams& P, const double* logt, double T, double inv_T) {
+    return SvpArg{flog(logt, T * P.inv_T_triple), P.inv_T_triple - inv_T};
+}
+__device__ __forceinline__ double svp_liquid_from(const DevParams& P, const SvpArg& s) {
+    return P.p_triple * fexp(__builtin_fma(P.svp_a_liq, s.L, P.svp_b_liq * s.D));
+}
+// PhaseEquil: liquid-fraction weighted L₀ and Δcp.  No shortcut for λ = 1: a batch's cells come from anywhere on the
+// globe, so a wave nearly always holds both kinds and would execute both sides of such a branch.
+__device__ __forceinline__ double svp_equil_from(const DevParams& P, const SvpArg& s, double lam) {
+    const double LH_0 = lam * P.LH_v0 + (1.0 - lam) * P.LH_s0;
+    const double dcp = lam * (P.cp_v - P.cp_l) + (1.0 - lam) * (P.cp_v - P.cp_i);
+    const double a = dcp * P.inv_R_v, b = (LH_0 - dcp * P.T_0) * P.inv_R_v;
+    return P.p_triple * fexp(__builtin_fma(a, s.L, b * s.D));
+}
 __device__ __forceinline__ double svp_liquid_fast(const DevParams& P, const double* logt, double T, double inv_T) {
-    return P.p_triple * fexp(__builtin_fma(P.svp_a_liq, flog(logt, T * P.inv_T_triple), P.svp_b_liq * (P.inv_T_triple - inv_T)));
+    return svp_liquid_from(P, svp_arg(P, logt, T, inv_T));
 }
 
 __device__ __forceinline__ double liquid_fraction_fast(const DevParams& P, const double* logt, double T) {
@@ -267,11 +286,7 @@ __device__ __forceinline__ double liquid_fraction_fast(const DevParams& P, const
 }
 
 __device__ __forceinline__ double svp_equil_fast(const DevParams& P, const double* logt, double T, double inv_T, double lam) {
-    if (lam == 1.0) return svp_liquid_fast(P, logt, T, inv_T);
-    double LH_0 = lam * P.LH_v0 + (1.0 - lam) * P.LH_s0;
-    double dcp = lam * (P.cp_v - P.cp_l) + (1.0 - lam) * (P.cp_v - P.cp_i);
-    double a = dcp * P.inv_R_v, b = (LH_0 - dcp * P.T_0) * P.inv_R_v;
-    return P.p_triple * fexp(__builtin_fma(a, flog(logt, T * P.inv_T_triple), b * (P.inv_T_triple - inv_T)));
+    return svp_equil_from(P, svp_arg(P, logt, T, inv_T), lam);
 }
 
 __device__ __forceinline__ AirState air_state_fast(const DevParams& P, double p, double T, double inv_T, double q_tot,
@@ -377,7 +392,8 @@ __device__ __forceinline__ CellConsts cell_prologue(const DevParams& P, double m
     const double pvs_a = svp_equil_fast(P, logt, Ta, inv_Ta, lam_a);
     const AirState A = air_state_fast(P, pa, Ta, inv_Ta, qa, lam_a, pvs_a);
 
-    const double pstar_s = svp_liquid_fast(P, logt, Ts, inv_Ts);
+    const SvpArg arg_s = svp_arg(P, logt, Ts, inv_Ts);
+    const double pstar_s = svp_liquid_from(P, arg_s);
     const double sal = So * 1e-3;
     const double x_h2o = P.sw_inv_w * frcp(__builtin_fma(sal * frcp(1.0 - sal), P.sw_inv_mu, P.sw_inv_w));
     const double qs = x_h2o * pstar_s * frcp(A.rho * P.R_v * Ts);
@@ -395,7 +411,8 @@ __device__ __forceinline__ CellConsts cell_prologue(const DevParams& P, double m
     c.U_calm = fsqrt1(__builtin_fma(min_gust, min_gust, c.dU2));  // U when the gustiness sits at its floor
 
     const double lam_s = liquid_fraction_fast(P, logt, Ts);
-    const double pvs_s = (lam_s == 1.0) ? pstar_s : svp_equil_fast(P, logt, Ts, inv_Ts, lam_s);
+    double pvs_s = pstar_s;  // (water below 0 °C — polar cells only: worth a wave-level branch, and the logarithm is shared)
+    if (__any(lam_s != 1.0)) pvs_s = (lam_s == 1.0) ? pstar_s : svp_equil_from(P, arg_s, lam_s);
     const AirState Sfc = air_state_fast(P, pa, Ts, inv_Ts, qs, lam_s, pvs_s);
     c.gTv = P.g * frcp(Sfc.T_virtual);
     c.b_theta = 1.0 + P.delta * Sfc.q_vap;
