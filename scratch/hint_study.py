@@ -100,3 +100,6 @@ chat = 2 * cB - cA
 print("  key = 2c(n) - c(n-1)       %.3f   ceil of it %.3f" % (eff(chat), eff(np.ceil(chat))))
 print("  key = 2t(n) - t(n-1)       %.3f" % eff(2.0 * tB - tA))
 hit = (np.ceil(chat) == t1).mean(); print("  ceil(extrapolated c) == t(n+1): %.3f   t(n) == t(n+1): %.3f" % (hit, (tB == t1).mean()))
+print("--- sort-group size (batches of 64 inside groups of N consecutive wet cells), key = previous trips / perfect")
+for ch in (128, 256, 512, 1024, 2048, 4096):
+    print("  N=%4d: stale %.3f   exact %.3f" % (ch, eff(tB.astype(float), ch), eff(t1.astype(float), ch)))
