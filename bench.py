@@ -294,11 +294,20 @@ def main():
         # Clocks first: a cold device needs tens of milliseconds of work before it holds its sustained clock, and a
         # 20-step region is 3 ms.  Untimed steps until ≈ 0.15 s have passed, then the W warm-up steps the caller asked
         # for, then exactly K timed steps — so that --steps 20 and --steps 1000 measure the same machine state.
+        # (every rank must run the SAME number of steps — the halo rows pair up step by step — so the ranks agree on
+        # when to stop: all of them have been busy for 0.15 s)
         done, t_start = 0, time.perf_counter()
-        while time.perf_counter() - t_start < 0.15:
+        while True:
             run_steps(name, sched, done, 50)
             ctx.sync()
             done += 50
+            enough = time.perf_counter() - t_start >= 0.15
+            if world > 1:
+                flag = torch.tensor([1 if enough else 0], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                enough = bool(flag.item())
+            if enough:
+                break
         settle[name] = done
         run_steps(name, sched, done, warmup)
         first, samples = done + warmup, []
