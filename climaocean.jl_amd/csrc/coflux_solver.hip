@@ -17,9 +17,11 @@ namespace coflux {
 constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 
 constexpr int AO_BLOCK = 256;
-constexpr int AO_CHUNK = 1024;  // capacity of a workgroup's wet-cell list = the most wet cells a chunk can hold
+constexpr int AO_CHUNK = 1280;  // capacity of a workgroup's wet-cell list = the most wet cells a chunk can hold
+constexpr int AO_LAYER_1 = 1280, AO_LAYER_2 = 512, AO_LAYER_3 = 512;  // wet cells per chunk of the last three arrival layers (plan_chunk_rounds)
+static_assert(AO_LAYER_1 <= AO_CHUNK && AO_LAYER_1 >= AO_LAYER_2 && AO_LAYER_2 >= AO_LAYER_3, "layer sizes");
 constexpr int AO_BINS = 32;    // trip-count bins of the per-chunk counting sort
-constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + AO_CHUNK * 2 + 16 + 2 * AO_BINS * 4;
+constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + 16 + 2 * AO_BINS * 4;
 constexpr int AO_LDS_BYTES = AO_PARAMS_OFFSET + (int)sizeof(DevParams);
 static_assert(AO_LDS_BYTES <= 53760, "three solver workgroups must fit the CU's 160 KB of LDS");
 
@@ -138,8 +140,10 @@ __global__ __launch_bounds__(256) void chunk_begins_kernel(const DevParams* __re
 // is the (b / CUs)-th arrival on its CU — and the SIMD arbiter serves the OLDEST wave first (s_setprio does not
 // change that: measured).  With three equal workgroups per CU the first finishes at 60 % of the kernel and the
 // third runs the last third alone, too few waves to keep the FP64 pipe busy (lifetimes 58 / 73 / 92 µs at
-// equal work).  So the work is handed out in proportion to the share each arrival gets: 1024, 768 and 512
-// wet cells for the last three layers (all multiples of 256 = whole batches for four waves), 1024 for every
+// equal work).  So the work is handed out in proportion to the share each arrival gets: 1280, 512 and 512
+// wet cells for the last three layers (all multiples of 256 = whole batches for four waves; measured against
+// 1024/768/512 — the first layer then fills the list capacity of last round — 1280/768/256, 1280/640/384 and
+// 1152/…: 0.1161 vs 0.1174 ms per step, sizes that are not whole batches per wave lose 3 µs), 1280 for every
 // layer before them (on larger surfaces a new workgroup starts whenever the oldest one retires and the
 // pipeline staggers itself; only the tail needs shaping).  Pure host arithmetic (tests/test_abi.py checks it
 // without a GPU through cf_debug_chunk_plan); returns the largest chunk size used.
@@ -174,13 +178,14 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
     } else {
         // 1024s for everything before the last two layers (none on a surface that fits three layers), then as
         // many 768s as still needed, then 512s
-        const long body = need - cap(768) - cap(512);
-        const long n1024 = body > 0 ? (body + cap(1024) - 1) / cap(1024) * layer : 0;  // whole layers of 1024s
-        add_round(1024, n1024, false);
-        const long left = need - n1024 * 1024L * AO_WET_COST;
-        const long n768 = left > cap(768) ? layer : chunks(left, 768);                 // a whole layer of 768s if needed
-        add_round(768, n768, false);
-        add_round(512, chunks(left - n768 * 768L * AO_WET_COST, 512), false);          // the youngest layer takes the rest
+        constexpr int W1 = AO_LAYER_1, W2 = AO_LAYER_2, W3 = AO_LAYER_3;
+        const long body = need - cap(W2) - cap(W3);
+        const long n1 = body > 0 ? (body + cap(W1) - 1) / cap(W1) * layer : 0;  // whole layers of the largest size
+        add_round(W1, n1, false);
+        const long left = need - n1 * (long)W1 * AO_WET_COST;
+        const long n2 = left > cap(W2) ? layer : chunks(left, W2);                 // a whole middle layer if needed
+        add_round(W2, n2, false);
+        add_round(W3, chunks(left - n2 * (long)W2 * AO_WET_COST, W3), false);          // the youngest layer takes the rest
         R.base[R.n] = (int)total + AO_WET_COST;  // the last round added absorbs the end
     }
     *out = R;
@@ -283,9 +288,13 @@ __device__ __forceinline__ void zero_cell(const LoopParams& L, double T_offset, 
 }
 
 // ---- production solver: LDS tables, one workgroup per chunk of the table above -----------------
-// LDS: tables | list of cell indices | list of wet positions | counters, histogram, bin cursors | DevParams
-constexpr int AO_LIST_E_OFFSET = TABLE_BYTES + AO_CHUNK * 4;
-constexpr int AO_COUNTERS_OFFSET = AO_LIST_E_OFFSET + AO_CHUNK * 2;
+// LDS: tables | list (cell offset + list entry per sorted position) | counters, histogram, bin cursors | DevParams
+constexpr int AO_COUNTERS_OFFSET = TABLE_BYTES + AO_CHUNK * 4;
+// A list word: the cell's offset from the start of the chunk's range (21 bits: a range costs at most AO_CHUNK wet
+// cells' worth of AO_WET_COST = 81 920 cells if it were all land) and its entry in the static list (11 bits).
+constexpr int AO_LIST_OFFSET_BITS = 21;
+static_assert(AO_CHUNK <= (1 << (32 - AO_LIST_OFFSET_BITS)), "list entry index must fit the upper bits");
+static_assert((long)AO_CHUNK * AO_WET_COST < (1L << AO_LIST_OFFSET_BITS), "a chunk's range must fit the lower bits");
 
 struct WetLists {
     const uint32_t* pos;    // wet cells of chunk c in index order at [c·AO_CHUNK, …), 0xffffffff-padded; nullptr: classify per call
@@ -366,8 +375,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
     // it — a stale list costs time, never correctness.  Land gets its zeros right behind the start phase.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tab = reinterpret_cast<double*>(smem);
-    int* list = reinterpret_cast<int*>(smem + TABLE_BYTES);
-    unsigned short* list_e = reinterpret_cast<unsigned short*>(smem + AO_LIST_E_OFFSET);
+    unsigned* list = reinterpret_cast<unsigned*>(smem + TABLE_BYTES);
     int* counters = reinterpret_cast<int*>(smem + AO_COUNTERS_OFFSET);  // [0] wet count, [1] cursor, [2] wet cells seen, [3] stale
     int* hist = counters + 4;
     int* bin_start = hist + AO_BINS;
@@ -529,8 +537,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
         for (int n = 0; n < PER_THREAD; ++n)
             if (my_idx[n] >= 0) {
                 const int p = atomicAdd(&bin_start[AO_BINS - 1 - min(my_trip[n], AO_BINS - 1)], 1);
-                list[p] = my_idx[n];
-                list_e[p] = (unsigned short)(tid + n * AO_BLOCK);
+                list[p] = ((unsigned)(tid + n * AO_BLOCK) << AO_LIST_OFFSET_BITS) | (unsigned)(my_idx[n] - range_begin);
             }
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the table DMA has landed
         __syncthreads();
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 wave_base = __shfl(wave_base, 0);
                 if (wet) {
                     const int p = wave_base + __popcll(m & ((1ull << lane) - 1ull));
-                    if (p < AO_CHUNK) list[p] = idx;
+                    if (p < AO_CHUNK) list[p] = (unsigned)(idx - range_begin);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the table DMA has landed
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 IceConsts c;
                 double Ts;
                 {
-                    const int idx = list[qc];
+                    const int idx = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
                     const int jj = idx / wx;
                     const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
                     SolverArgsPtr Kb = opaque(K);
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 const Scales s = ice_iterate<COARE>(P, L, Ice, c, tab, in_range, Ts);
                 if (in_range) {
                     SolverArgsPtr Ke = opaque(K);
-                    const int idx2 = list[qc];
+                    const int idx2 = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
                     const int jj2 = idx2 / wx;
                     const size_t k = cell_index(G, idx2 - jj2 * wx - G.ring, jj2 - G.ring);
                     CellFluxes R;
@@ -672,14 +679,14 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                     R.iterations = s.it;
                     const FluxOut F = kread(&Ke->F);
                     store_fluxes(F, k, R);
-                    if (use_static && W.trip) W.trip[(size_t)chunk * AO_CHUNK + list_e[qc]] = (uint8_t)min(s.it, 255);
+                    if (use_static && W.trip) W.trip[(size_t)chunk * AO_CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.it, 255);
                 }
                 continue;
             }
             CellConsts c;
             double So;
             {
-                const int idx = list[qc];
+                const int idx = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
                 const int jj = idx / wx;
                 const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
                 SolverArgsPtr Kb = opaque(K);  // this batch's view of the arguments: pointers are (re)loaded here, scalar loads
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
             if (in_range) {
                 SolverArgsPtr Ke = opaque(K);
                 // (cell coordinates recomputed from the list entry: cheaper than four registers held across the iteration)
-                const int idx2 = list[qc];
+                const int idx2 = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
                 const int jj2 = idx2 / wx;
                 const int ci = idx2 - jj2 * wx - G.ring, cj = jj2 - G.ring;
                 const size_t k = cell_index(G, ci, cj);
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                     const FluxOut F = kread(&Ke->F);
                     store_fluxes(F, k, R);
                 }
-                if (use_static && W.trip) W.trip[(size_t)chunk * AO_CHUNK + list_e[qc]] = (uint8_t)min(s.it, 255);
+                if (use_static && W.trip) W.trip[(size_t)chunk * AO_CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.it, 255);
                 if constexpr (FUSE_NET) {
                     // compute_net_ocean_fluxes!, the part that needs no neighbour: interior cells only
                     if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {

@@ -30,12 +30,16 @@ for label in ("default", "fixed0", "fixed12"):
     st = raw[:, [0, 1, 2, 3, 6]]
     d = np.diff(st, axis=1)
     total = st[:, 4] - st[:, 0]
-    for q, name in enumerate(("entry -> first barrier (params, list loads issued)", "sort + table DMA landed", "batches (load/prologue/iterate/store)", "land pass + validation")):
+    for q, name in enumerate(("entry -> first barrier (everything requested)", "sort + validation + table DMA landed", "batches (load/prologue/iterate/store)", "(unused)")):
         a_ = d[:, q] / tick
         print(f"   {name:52s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
-    for nm, v in (("   entry -> list loads issued", raw[:, 4] - raw[:, 0]), ("   list loads issued -> params + DMA issued", raw[:, 5] - raw[:, 4]), ("   wait lgkm + barrier", raw[:, 1] - raw[:, 5])):
+    for nm, v in (("   entry -> table DMA issued", raw[:, 4] - raw[:, 0]), ("   DMA issued -> list + mask loads issued", raw[:, 5] - raw[:, 4]), ("   wait lgkm + barrier", raw[:, 1] - raw[:, 5])):
         a_ = v / tick
         print(f"   {nm:52s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
+    # the tail: how many waves are still alive in the kernel's last microseconds
+    t_end = st[:, 4].max(); t_first = st[:, 0].min()
+    alive = [(k, float(((st[:, 4] > t_end - k * tick)).mean())) for k in (1, 2, 4, 6, 8, 10, 15, 20)]
+    print("   waves still running k us before the end: " + "  ".join(f"{k}us {f*100:.0f}%" for k, f in alive) + f"   (first entry -> last exit {(t_end - t_first)/tick:.1f} us)")
     a_ = total / tick
     print(f"   {'wave lifetime':40s} min {a_.min():6.1f}  median {np.median(a_):6.1f}  p90 {np.percentile(a_,90):6.1f}  max {a_.max():6.1f} us")
     wg_life = (st[:, 4].reshape(NWG, 4).max(axis=1) - st[:, 0].reshape(NWG, 4).min(axis=1)) / tick

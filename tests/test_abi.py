@@ -83,7 +83,7 @@ def test_missing_library_is_loud(tmp_path):
 def test_solver_chunk_plan_covers_every_surface():
     """The layered chunk plan of the flux solver (host arithmetic, coflux_solver.hip::plan_chunk_rounds): for any
     surface cost and CU count the rounds cover the whole cost range with whole chunks, chunk sizes never grow along
-    the dispatch order, only 256/512/768/1024 wet cells occur, and the 1/4° surface gets 1024 / 768 / 512."""
+    the dispatch order, only 256/512/768/1024/1280 wet cells occur, and the 1/4° surface gets 1280 / 512 / 512."""
     lib = abi.load_library()
     out = (C.c_int * 32)()
 
@@ -93,7 +93,7 @@ def test_solver_chunk_plan_covers_every_surface():
         return [(out[1 + 2 * r], out[2 + 2 * r]) for r in range(out[0])], unit
 
     rounds, unit = plan(577498 * 64 + 232906, 256)           # 1440×560 synthetic surface: wet·64 + land
-    assert [w for w, _ in rounds] == [1024, 768, 512] and all(0 < n <= 256 for _, n in rounds)
+    assert [w for w, _ in rounds] == [1280, 512, 512] and all(0 < n <= 256 for _, n in rounds)
     assert sum(n for _, n in rounds) <= 3 * 256
     import random
     rng = random.Random(5)
@@ -102,12 +102,12 @@ def test_solver_chunk_plan_covers_every_surface():
         total = rng.choice([1, 63, 64, 65, rng.randrange(1, 10 ** 5), rng.randrange(1, 10 ** 7), rng.randrange(1, 2 * 10 ** 9)])
         rounds, unit = plan(total, cus)
         sizes = [w for w, _ in rounds]
-        assert rounds and all(w in (256, 512, 768, 1024) for w in sizes) and sizes == sorted(sizes, reverse=True), (total, cus, rounds)
+        assert rounds and all(w in (256, 512, 768, 1024, 1280) for w in sizes) and sizes == sorted(sizes, reverse=True), (total, cus, rounds)
         assert all(n > 0 for _, n in rounds), (total, cus, rounds)
         covered = sum(w * unit * n for w, n in rounds)
         assert covered > total, (total, cus, rounds)                     # every cost prefix falls into some chunk
         assert covered - total <= max(sizes) * unit + unit, (total, cus, rounds)   # and no empty chunk at the end
         if len(rounds) > 1:
-            assert all(n <= cus or w == 1024 for w, n in rounds[:-1]), (total, cus, rounds)
+            assert all(n <= cus or w == 1280 for w, n in rounds[:-1]), (total, cus, rounds)
     rounds, _ = plan(10 ** 6, 256, forced=512)
     assert len(rounds) == 1 and rounds[0][0] == 512
