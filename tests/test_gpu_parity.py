@@ -259,6 +259,16 @@ def test_bottom_height_mask_encoding():
     compare(case, run_gpu(case, params), run_oracle(case, params), 1)
 
 
+def test_no_mask_means_every_cell_is_ocean():
+    """CF_MASK_NONE: the mask array is ignored (the solver's start phase reads dummy words instead of mask words and
+    the range's wet set is the whole range) — every cell is solved, ring included."""
+    params = ic.flux_params(mask_kind=abi.MASK_NONE)
+    case = util.build_case(90, 40)
+    got, ref = run_gpu(case, params), run_oracle(case, params)
+    compare(case, got, ref, 1)
+    assert np.all(util.window(got["fluxes"]["iterations"], case["hx"], case["hy"], case["nx"], case["ny"], 1) > 0)
+
+
 def test_invalid_arguments_are_reported():
     from coflux.runtime import CofluxError
     params = ic.flux_params()
