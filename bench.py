@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--net-diagnostics", action="store_true",
                     help="also write the three optional radiation diagnostics of cf_net_ocean_fluxes (24 B/cell beyond "
                          "the 88 + 40 B/cell contract of compute_net_ocean_fluxes!, SURVEY.md §8d)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="REHEARSAL of the N-rank code path on a box with fewer devices: every rank uses device 0, the host-side "
+                         "collectives go over gloo, and only the halo backends that can run two ranks on one device are "
+                         "tried (peer-direct through HIP IPC; RCCL refuses duplicate devices).  The line is marked "
+                         "'rehearsal' and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample: passes that fit this wall time")
     return ap.parse_args()
@@ -69,7 +74,7 @@ def launch_ranks(a):
     """`python bench.py --gpus N` outside torchrun: start the N ranks (one per GPU) ourselves."""
     import torch
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if ndev < a.gpus:
+    if ndev < a.gpus and not (a.share_device and ndev >= 1):
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {ndev} HIP device(s) visible on this node; "
                          f"refusing to run (an N-GPU number needs N devices)")
     with socket.socket() as s:
@@ -130,12 +135,18 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the line would misreport n_gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the flux path has no CPU backend")
+    if a.share_device:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
+    coll_dev = "cpu" if a.share_device else "cuda"   # where the tensors of the host-side collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.share_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     default_protocol = a.steps is None
     steps = a.steps if a.steps is not None else 1000
@@ -231,20 +242,22 @@ def main():
         for f, xs in zip(halo_fields, want):      # restore either way
             for r, x in zip(rows, xs):
                 f[r].copy_(x)
-        flag = torch.tensor([1 if good else 0], device="cuda")
+        flag = torch.tensor([1 if good else 0], device=coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
     exchangers = {}
     if world > 1:
         wanted = ("rccl", "peer", "torch") if a.halo_backend == "auto" else (a.halo_backend,)
+        if a.share_device:
+            wanted = tuple(n for n in wanted if n == "peer")
         for name in wanted:
-            ok = torch.tensor([1], device="cuda")
+            ok = torch.tensor([1], device=coll_dev)
             try:
                 ex = SlabHaloExchanger(ctx, ny, h, rows=ring_rows, backend=name)
             except Exception as exc:
                 print(f"[bench] rank {rank}: halo backend {name} unavailable: {exc}", file=sys.stderr)
-                ex, ok = None, torch.tensor([0], device="cuda")
+                ex, ok = None, torch.tensor([0], device=coll_dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if bool(ok.item()) and verify(ex):
                 exchangers[name] = ex
@@ -303,7 +316,7 @@ def main():
             done += 50
             enough = time.perf_counter() - t_start >= 0.15
             if world > 1:
-                flag = torch.tensor([1 if enough else 0], device="cuda")
+                flag = torch.tensor([1 if enough else 0], device=coll_dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 enough = bool(flag.item())
             if enough:
@@ -318,7 +331,7 @@ def main():
             barrier()
             dt = time.perf_counter() - t0
             if world > 1:
-                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             samples.append(dt)
@@ -420,6 +433,8 @@ def main():
                                   net_fluxes_standalone=net_ms_alone),
                    device_copy_GBs=2 * copy_bytes / (copy_ms * 1e-3) / 1e9,
                    parity="vs reference: unpinned (self-consistent restatements only; see DESIGN.md)")
+        if a.share_device:
+            out["rehearsal"] = f"{world} ranks time-sharing ONE device: a test of the N-rank code path, not a scaling number"
         if not a.no_cpu_baseline and world == 1:
             case_np = dict(ocean=ocean_np[0], src=src_np, weights=w_np)
             out["cpu_baseline"] = cpu_baseline(case_np, params, nx, ny, h, a.cpu_seconds)

@@ -103,3 +103,22 @@ hit = (np.ceil(chat) == t1).mean(); print("  ceil(extrapolated c) == t(n+1): %.3
 print("--- sort-group size (batches of 64 inside groups of N consecutive wet cells), key = previous trips / perfect")
 for ch in (128, 256, 512, 1024, 2048, 4096):
     print("  N=%4d: stale %.3f   exact %.3f" % (ch, eff(tB.astype(float), ch), eff(t1.astype(float), ch)))
+print("--- straggler parking model: a batch stops when <= P lanes are still iterating; those lanes are queued and finished")
+print("    in 64-lane drain batches (per 1024-cell chunk) that pay a prologue+epilogue (3.3 iteration-equivalents) again")
+OVER = 3.3
+def park_model(key, P, chunk=1024):
+    n = (t1.size // chunk) * chunk
+    K = key[:n].reshape(-1, chunk); T = t1[:n].reshape(-1, chunk)
+    Ts = np.take_along_axis(T, np.argsort(-K, axis=1, kind="stable"), 1).reshape(-1, chunk // 64, 64)
+    srt = np.sort(Ts, axis=2)                        # ascending per batch
+    stop = srt[:, :, 63 - P] if P > 0 else srt[:, :, 63]   # iterations after which <= P lanes remain
+    main = (stop + OVER).sum()
+    rem = np.maximum(Ts - stop[:, :, None], 0)       # remaining iterations of parked lanes
+    drain = 0.0
+    for c in range(rem.shape[0]):
+        r = np.sort(rem[c][rem[c] > 0])[::-1]
+        for b in range(0, r.size, 64):
+            drain += r[b] + OVER
+    return (main + drain) / (Ts.shape[0] * Ts.shape[1])   # iteration-equivalents per batch, overhead included
+for P in (0, 2, 4, 8, 12, 16):
+    print("  P=%2d: stale key %.3f   exact key %.3f   (per batch, incl. %.1f overhead; P=0 is today's kernel)" % (P, park_model(tB.astype(float), P), park_model(t1.astype(float), P), OVER))

@@ -297,3 +297,21 @@ def test_halo_rows_between_two_devices(backend):
         p.join(300)
         assert p.exitcode == 0, f"worker exit code {p.exitcode}"
     assert out.get(0) is True and out.get(1) is True, dict(out)
+
+
+@pytest.mark.gpu
+def test_bench_n_rank_code_path_rehearsal():
+    """bench.py's N-rank path (rank set-up, halo backend verification, the agreed settle loop, cf_time_steps with
+    peer-direct halo rows, max-over-ranks timing, one JSON line from rank 0) rehearsed with two ranks time-sharing
+    this box's device — the driver's multi-GPU run is the first time it meets N devices."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--steps", "40",
+                        "--warmup", "5", "--nx", "360", "--ny", "120", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 40 and "rehearsal" in line
+    assert line["config"]["halo_verified"] == ["peer"] and line["config"]["rows_per_rank"] == 60
+    assert line["value"] > 0 and line["config"]["step_loop"].startswith("cf_time_steps")
