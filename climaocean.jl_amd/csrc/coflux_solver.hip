@@ -323,6 +323,7 @@ struct SolverArgs {
     double z_surface;    // with mask_kind: how the start phase reads wetness before the parameter block is in LDS
     long long mask_kind;
     double T_offset;     // (zero_interface_state writes −T_offset; same reason)
+    unsigned long long wx_reciprocal;  // floor(2³² / (nx + 2·ring)), see row_of
 };
 typedef const SolverArgs __attribute__((address_space(4)))* SolverArgsPtr;
 
@@ -341,6 +342,14 @@ __device__ __forceinline__ T kread(const __attribute__((address_space(4))) T* p)
 __device__ __forceinline__ SolverArgsPtr opaque(SolverArgsPtr p) {
     asm volatile("" : "+s"(p));
     return p;
+}
+
+// row of a window-linear cell index: idx / wx through the host's floor(2³² / wx) — five instructions where the
+// compiler's 32-bit division is ≈ 20, and the kernel does it for every mask word of the start phase and twice per batch.
+// The product underestimates the quotient by at most one for idx < 2²⁶ (67 M cells).
+__device__ __forceinline__ int row_of(int idx, int wx, unsigned wx_reciprocal) {
+    int q = (int)__umulhi((unsigned)idx, wx_reciprocal);
+    return idx - q * wx >= wx ? q + 1 : q;
 }
 
 // two independent 32-bit mixes of a cell's linear index (murmur3's finaliser): XOR-accumulated over a set of cells
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
     DevParams* lp = reinterpret_cast<DevParams*>(smem + AO_PARAMS_OFFSET);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wx = G.nx + 2 * G.ring;
+    const unsigned wx_rcp = (unsigned)K->wx_reciprocal;
     const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
     bool use_static = W.pos != nullptr;
     // Order of the start phase — everything is REQUESTED before anything is looked at, in straight-line code (a
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
 #pragma unroll
         for (int n = 0; n < LAND_UNROLL; ++n) {
             const int ic = min(range_begin + tid + n * AO_BLOCK, range_end - 1);
-            const int jj = ic / wx;
+            const int jj = row_of(ic, wx, wx_rcp);
             const unsigned long long a = mbase + (unsigned long long)cell_index(G, ic - jj * wx - G.ring, jj - G.ring) * stride;
             raw_shift |= ((unsigned)a & 3u) << (2 * n);
             raw_lo[n] = *(GlobalWords)(a & ~3ull);
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
         }
         // a range longer than LAND_UNROLL strips (a chunk that is mostly land): the rest the plain way, zeros at once
         for (int idx = range_begin + tid + LAND_UNROLL * AO_BLOCK; idx < range_end; idx += AO_BLOCK) {
-            const int jj = idx / wx;
+            const int jj = row_of(idx, wx, wx_rcp);
             const int i = idx - jj * wx - G.ring, j = jj - G.ring;
             const size_t k = cell_index(G, i, j);
             const bool w = mask_kind == CF_MASK_NONE ? true
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 for (int n = 0; n < LAND_UNROLL; ++n)
                     if (land & (1u << n)) {
                         const int idx = range_begin + tid + n * AO_BLOCK;
-                        const int jj = idx / wx;
+                        const int jj = row_of(idx, wx, wx_rcp);
                         const int i = idx - jj * wx - G.ring, j = jj - G.ring;
                         zero_cell<FUSE_NET>(L, T_offset, G, F, N, cell_index(G, i, j), i, j);
                     }
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 const int idx = base + tid;
                 bool wet = false;
                 if (idx < end) {
-                    const int jj = idx / wx;
+                    const int jj = row_of(idx, wx, wx_rcp);
                     const int i = idx - jj * wx - G.ring, j = jj - G.ring;
                     const size_t k = cell_index(G, i, j);
                     wet = cell_is_wet(P, mask, k);
@@ -625,7 +635,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 double Ts;
                 {
                     const int idx = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
-                    const int jj = idx / wx;
+                    const int jj = row_of(idx, wx, wx_rcp);
                     const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
                     SolverArgsPtr Kb = opaque(K);
                     const IceStateIn S = kread(&Kb->S);
@@ -661,7 +671,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 if (in_range) {
                     SolverArgsPtr Ke = opaque(K);
                     const int idx2 = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
-                    const int jj2 = idx2 / wx;
+                    const int jj2 = row_of(idx2, wx, wx_rcp);
                     const size_t k = cell_index(G, idx2 - jj2 * wx - G.ring, jj2 - G.ring);
                     CellFluxes R;
                     const double inv_dU = (c.dU == 0.0) ? 0.0 : frcp(c.dU);
@@ -687,7 +697,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
             double So;
             {
                 const int idx = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
-                const int jj = idx / wx;
+                const int jj = row_of(idx, wx, wx_rcp);
                 const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
                 SolverArgsPtr Kb = opaque(K);  // this batch's view of the arguments: pointers are (re)loaded here, scalar loads
             // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
@@ -708,7 +718,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 SolverArgsPtr Ke = opaque(K);
                 // (cell coordinates recomputed from the list entry: cheaper than four registers held across the iteration)
                 const int idx2 = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
-                const int jj2 = idx2 / wx;
+                const int jj2 = row_of(idx2, wx, wx_rcp);
                 const int ci = idx2 - jj2 * wx - G.ring, cj = jj2 - G.ring;
                 const size_t k = cell_index(G, ci, cj);
                 const CellFluxes R = cell_epilogue(c, P.T_offset, s);
@@ -777,7 +787,7 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
                            const OceanIn& O, const Exchange& E, const FluxOut& F, const IceIn& I, const NetOut& N,
                            double z_surface, long long mask_kind, double T_offset) {
     const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip}, L.d_chunk_begins, I, N, IceStateIn{}, IceParams{},
-                       z_surface, mask_kind, T_offset};
+                       z_surface, mask_kind, T_offset, (0x100000000ull / (unsigned long long)(G.nx + 2 * G.ring))};
 #define CF_LAUNCH(COARE_, SPEC_) \
     hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, FUSE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A)
     switch (C.specialization) {
@@ -842,6 +852,7 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     A.z_surface = P.z_surface;
     A.mask_kind = P.mask_kind;
     A.T_offset = P.T_offset;
+    A.wx_reciprocal = 0x100000000ull / (unsigned long long)(G.nx + 2 * G.ring);
     dim3 grid(L.n_chunks);
     if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
         hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE, false>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A);
