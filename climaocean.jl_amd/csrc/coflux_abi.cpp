@@ -205,13 +205,27 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_sums, sizeof(int) * chunk_sums_capacity(ncells)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_begins, sizeof(int) * chunk_table_capacity(ncells)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_meta, sizeof(int) * 4));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wet_pos, sizeof(uint32_t) * wet_list_capacity(ncells)));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trip, wet_list_capacity(ncells)));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trip_ice, wet_list_capacity(ncells)));
     }
-    int wet = 0, n = 0;
+    int wet = 0, n = 0, wide = 0;
     HIP_TRY(ctx, build_chunk_table(ctx->stream, ctx->d_params, ctx->grid, mask, ctx->launch.cu_count, ctx->launch.ao_chunk,
-                                   ctx->d_chunk_sums, ctx->d_chunk_begins, ctx->d_chunk_meta, &wet, &n));
+                                   ctx->d_chunk_sums, ctx->d_chunk_begins, ctx->d_chunk_meta, &wet, &n, &wide));
+    ctx->launch.ao_wide = wide;
+    {   // the lists' storage: n chunks at the geometry's fixed stride (grown when a rebuild needs more)
+        const size_t want = std::max(wet_list_capacity(ncells), (size_t)(n + 1) * wet_list_stride(wide != 0));
+        if (want > ctx->wet_list_entries) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_wet_pos);
+            (void)hipFree(ctx->d_trip);
+            (void)hipFree(ctx->d_trip_ice);
+            ctx->d_wet_pos = nullptr;
+            ctx->d_trip = ctx->d_trip_ice = nullptr;
+            ctx->wet_list_entries = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wet_pos, sizeof(uint32_t) * want));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trip, want));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trip_ice, want));
+            ctx->wet_list_entries = want;
+        }
+    }
     if (n <= 0 || n + 1 > chunk_table_capacity(ncells)) return fail(ctx, CF_ERR_HIP, "chunk table of %d entries is invalid", n);
     ctx->chunk_mask = key;
     ctx->chunk_mask_kind = d.mask_kind;
@@ -221,13 +235,14 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
     ctx->launch.d_chunk_begins = ctx->d_chunk_begins;
     ctx->launch.n_chunks = n;
     int overflow = 0;
-    HIP_TRY(ctx, build_wet_lists(ctx->stream, ctx->d_params, ctx->grid, mask, n, ctx->d_chunk_begins, ctx->d_wet_pos, ctx->d_trip,
-                                 ctx->d_chunk_meta, &overflow));
+    HIP_TRY(ctx, build_wet_lists(ctx->stream, ctx->d_params, ctx->grid, mask, n, wide != 0, ctx->d_chunk_begins, ctx->d_wet_pos,
+                                 ctx->d_trip, ctx->d_chunk_meta, &overflow));
     ctx->launch.d_wet_pos = overflow ? nullptr : ctx->d_wet_pos;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_trip_ice, 0, (size_t)n * 1024, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_trip_ice, 0, (size_t)n * wet_list_stride(wide != 0), ctx->stream));
     ctx->launch.d_trip = ctx->trip_hints ? ctx->d_trip : nullptr;
     if (std::getenv("COFLUX_DEBUG"))
-        std::fprintf(stderr, "[coflux] chunk table: %d chunks of %d wet cells (%d CUs)\n", n, wet, ctx->launch.cu_count);
+        std::fprintf(stderr, "[coflux] chunk table: %d chunks of %d wet cells (%d CUs, %s workgroups)\n", n, wet, ctx->launch.cu_count,
+                     wide ? "wide" : "narrow");
     return CF_OK;
 }
 
@@ -466,8 +481,9 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->prof_stride = value;
             return CF_OK;
         case CF_OPT_AO_CHUNK:
-            if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024)
-                return fail(ctx, CF_ERR_INVALID, "solver chunk %d: wet cells per workgroup must be 0 (automatic), 256, 512, 768 or 1024", value);
+            if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024 && value != 1280 && value != 3072)
+                return fail(ctx, CF_ERR_INVALID, "solver chunk %d: wet cells per workgroup must be 0 (automatic), 256, 512, 768, 1024, 1280 "
+                            "(narrow workgroups, uniform size) or 3072 (wide workgroups)", value);
             ctx->launch.ao_chunk = value;
             ctx->chunk_valid = false;
             return CF_OK;
@@ -668,7 +684,8 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     // Fused form: the cell-local part of compute_net_ocean_fluxes! (everything but the two face stresses, which
     // need the west / south neighbour's ρτ) is computed in the solver's epilogue from registers, and a thin stress
     // kernel follows — bitwise the same numbers as the three-launch sequence (shared arithmetic, contraction off).
-    const bool fuse = ctx->fused_net && ctx->launch.solver == CF_SOLVER_TABLES && ctx->dev.albedo_kind == CF_ALBEDO_CONSTANT;
+    const bool fuse = ctx->fused_net && ctx->launch.solver == CF_SOLVER_TABLES && ctx->dev.albedo_kind == CF_ALBEDO_CONSTANT &&
+                      !ctx->launch.ao_wide;  // (the fused epilogue exists in the narrow workgroup geometry only)
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes,
                                   fuse ? ice : nullptr, fuse ? net : nullptr, ctx->d_land_freshwater));
     // the next step's interpolation goes out behind the solver: its workgroups are dispatched first, the gather kernel

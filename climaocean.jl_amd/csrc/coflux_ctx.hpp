@@ -46,7 +46,7 @@ struct cf_ctx {
     hipStream_t stream = nullptr;
     LoopParams fast{};
     DevParams* d_params = nullptr;
-    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, 0, 256, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, 0, 256, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0};
     uint8_t* d_trip = nullptr;       // trip count of the previous call per wet-list entry
     uint32_t* d_wet_pos = nullptr;   // static wet lists of the solver's chunks
     bool trip_hints = true;
@@ -73,6 +73,7 @@ struct cf_ctx {
     cf_sea_ice_albedo_params ice_albedo{};
     double* d_ice_albedo = nullptr;  // the albedo field of the current step (computed by the library)
     uint8_t* d_trip_ice = nullptr;   // trip counts of the sea-ice interface solve per wet-list entry
+    size_t wet_list_entries = 0;     // entries allocated in d_wet_pos / d_trip / d_trip_ice
     double* d_ice_tables = nullptr;
     DevParams* d_ice_params = nullptr;
     // halo rows travel on their own stream so that they overlap the interpolation kernel, which

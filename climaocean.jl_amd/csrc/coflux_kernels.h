@@ -22,6 +22,7 @@ struct LaunchCfg {
     const int* d_chunk_begins;  // cost-balanced chunk table of the solver (coflux_solver.hip), n_chunks + 1 entries
     int n_chunks;
     const uint32_t* d_wet_pos;  // static wet lists of the chunks, fixed stride (coflux_solver.hip), or NULL
+    int ao_wide;                // 1: the chunk table was built for the wide geometry (one 768-thread workgroup per CU)
 };
 
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
@@ -32,9 +33,10 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
                             const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr);
 hipError_t launch_net_stress(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* n);
-hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks,
+hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks, bool wide,
                            const int* d_begins, uint32_t* d_wet_pos, uint8_t* d_trip, int* d_scratch, int* overflow_out);
 size_t wet_list_capacity(int ncells);
+int wet_list_stride(bool wide);
 hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                                  const cf_exchange_fields* e, const cf_interface_fluxes* f);
 hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
@@ -51,7 +53,7 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
                             const DevParams* d_params, uint8_t* d_trip);
 hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
                              int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
-                             int* nchunks_out);
+                             int* nchunks_out, int* wide_out);
 int chunk_table_capacity(int ncells);
 int chunk_sums_capacity(int ncells);
 hipError_t launch_net_sea_ice_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const void* mask,

@@ -16,14 +16,28 @@ namespace coflux {
 
 constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 
+// Two workgroup geometries.  NARROW: 256 threads, three workgroups per CU (each with its own copy of the tables),
+// chunks of ≤ 1280 wet cells in arrival layers — the only choice for a surface too small to give every CU a big chunk.
+// WIDE (CF_OPT_AO_CHUNK = 3072; measured 3 % slower, see build_chunk_table): 768 threads, ONE workgroup per CU: twelve
+// waves of the same age pull batches from both ends of one queue, one copy of the tables per CU, ≈ 100 KB of LDS free.
 constexpr int AO_BLOCK = 256;
-constexpr int AO_CHUNK = 1280;  // capacity of a workgroup's wet-cell list = the most wet cells a chunk can hold
+constexpr int AO_CHUNK = 1280;  // capacity of a narrow workgroup's wet-cell list = the most wet cells a chunk can hold
+constexpr int AO_BLOCK_WIDE = 768;
+constexpr int AO_CHUNK_WIDE = 3072;
+int wet_list_stride(bool wide);
+template <int BLOCK>
+struct Geom {
+    static constexpr int CHUNK = BLOCK == AO_BLOCK ? AO_CHUNK : AO_CHUNK_WIDE;
+    static constexpr int COUNTERS_OFFSET = TABLE_DOUBLES * 8 + CHUNK * 4;
+    static constexpr int PARAMS_OFFSET = COUNTERS_OFFSET + 16 + 2 * 32 * 4;
+    static constexpr int LDS_BYTES = PARAMS_OFFSET + (int)sizeof(DevParams);
+};
+static_assert(Geom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
 constexpr int AO_LAYER_1 = 1280, AO_LAYER_2 = 512, AO_LAYER_3 = 512;  // wet cells per chunk of the last three arrival layers (plan_chunk_rounds)
 static_assert(AO_LAYER_1 <= AO_CHUNK && AO_LAYER_1 >= AO_LAYER_2 && AO_LAYER_2 >= AO_LAYER_3, "layer sizes");
 constexpr int AO_BINS = 32;    // trip-count bins of the per-chunk counting sort
-constexpr int AO_PARAMS_OFFSET = TABLE_BYTES + AO_CHUNK * 4 + 16 + 2 * AO_BINS * 4;
-constexpr int AO_LDS_BYTES = AO_PARAMS_OFFSET + (int)sizeof(DevParams);
-static_assert(AO_LDS_BYTES <= 53760, "three solver workgroups must fit the CU's 160 KB of LDS");
+static_assert(AO_BINS == 32, "Geom<>::PARAMS_OFFSET spells the bin count out");
+static_assert(Geom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow solver workgroups must fit the CU's 160 KB of LDS");
 
 // ---------------------------------------------------------------------------------------------
 // Chunk table.  Two quantisation effects cost ≈ 25 % each when every workgroup simply takes 512 surface
@@ -42,6 +56,7 @@ static_assert(AO_LDS_BYTES <= 53760, "three solver workgroups must fit the CU's 
 // ---------------------------------------------------------------------------------------------
 constexpr int AO_WET_COST = 64;
 constexpr int AO_MAX_ROUNDS = 8;
+constexpr int AO_PLAN_WIDE = -1;  // plan_chunk_rounds: the wide geometry's plan
 struct ChunkRounds {  // round r covers cost prefixes [base[r], base[r+1]) in chunks of cost[r], ids from first[r]
     int n;
     int base[AO_MAX_ROUNDS + 1];
@@ -167,7 +182,15 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
         return cost_units <= 0 ? 0L : (cost_units + (long)w * AO_WET_COST - 1) / ((long)w * AO_WET_COST);
     };
     const long need = total > 0 ? total : 1;
-    if (forced_wet_per_chunk > 0) {
+    if (forced_wet_per_chunk == AO_PLAN_WIDE) {
+        // one workgroup per CU and round: chunks of equal cost, whole batches, as few rounds as the list capacity allows
+        const long per_round = cap(AO_CHUNK_WIDE);
+        const long rounds = (need + per_round - 1) / per_round;
+        const long want = (need + layer * rounds - 1) / (layer * rounds);                  // cost per chunk
+        int w = (int)((want + 64L * AO_WET_COST - 1) / (64L * AO_WET_COST)) * 64;          // … in whole batches of wet cells
+        w = w < 256 ? 256 : w;  // (the chunk table's capacity is sized for chunks of at least 256 wet cells)
+        add_round(w, chunks(need, w), true);
+    } else if (forced_wet_per_chunk > 0) {
         add_round(forced_wet_per_chunk, chunks(need, forced_wet_per_chunk), true);  // forced uniform size
     } else if (need <= 3 * cap(256)) {
         // small surface (a slab of a strongly scaled run): every chunk resident at once, one batch per wave — the
@@ -194,7 +217,7 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
 
 hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
                              int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
-                             int* nchunks_out) {
+                             int* nchunks_out, int* wide_out) {
     const int ncells = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
     const int nblocks = (ncells + CT_CELLS - 1) / CT_CELLS;
     hipLaunchKernelGGL(chunk_block_costs_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums);
@@ -204,8 +227,15 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
     ChunkRounds R{};
-    const int largest = plan_chunk_rounds(total, cu_count, wet_per_chunk, &R);
+    // Geometry: narrow workgroups in arrival layers unless CF_OPT_AO_CHUNK = 3072 asks for the wide one (one 768-thread
+    // workgroup per CU).  Measured on the 1/4° surface the wide geometry loses 3 % (0.1232 vs 0.1196 ms per step on the
+    // same box; kernel 77.1 vs 75.4 µs on identical inputs) even with its batch queue served from both ends: three
+    // workgroups of different age on a CU stagger themselves — the oldest iterates while the youngest loads — and
+    // twelve waves of one age do not.  It stays as an option because it leaves ≈ 100 KB of the CU's LDS unused.
+    const bool wide = wet_per_chunk == AO_CHUNK_WIDE;
+    const int largest = plan_chunk_rounds(total, cu_count, wide ? AO_PLAN_WIDE : wet_per_chunk, &R);
     wet_per_chunk = largest;
+    *wide_out = wide ? 1 : 0;
     hipLaunchKernelGGL(chunk_begins_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums, R, d_begins,
                        d_meta);
     int n = 0;
@@ -228,12 +258,13 @@ int chunk_sums_capacity(int ncells) { return (ncells + CT_CELLS - 1) / CT_CELLS 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void chunk_wet_fill_kernel(const DevParams* __restrict__ g_params, GridDesc G,
                                                              const void* mask, const int* __restrict__ begins,
-                                                             uint32_t* __restrict__ wet_pos, int* __restrict__ overflow) {
+                                                             uint32_t* __restrict__ wet_pos, int* __restrict__ overflow,
+                                                             int stride) {
     __shared__ int wave_count[4];
     const DevParams& P = *g_params;
     const int wx = G.nx + 2 * G.ring, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int begin = begins[blockIdx.x], end = begins[blockIdx.x + 1];
-    uint32_t* out = wet_pos + (size_t)blockIdx.x * AO_CHUNK;
+    uint32_t* out = wet_pos + (size_t)blockIdx.x * stride;
     int base = 0;
     for (int strip = begin; strip < end; strip += 256) {  // index order: strips in order, waves in order, lanes in order
         const int idx = strip + (int)threadIdx.x;
@@ -248,23 +279,24 @@ __global__ __launch_bounds__(256) void chunk_wet_fill_kernel(const DevParams* __
         int off = base;
         for (int w = 0; w < wave; ++w) off += wave_count[w];
         const int p = off + __popcll(m & ((1ull << lane) - 1ull));
-        if (wet && p < AO_CHUNK) out[p] = (uint32_t)idx;
+        if (wet && p < stride) out[p] = (uint32_t)idx;
         base += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
         __syncthreads();
     }
-    for (int p = base + (int)threadIdx.x; p < AO_CHUNK; p += 256) out[p] = 0xffffffffu;  // sentinel: no cell
-    if (threadIdx.x == 0 && base > AO_CHUNK) atomicAdd(overflow, 1);
+    for (int p = base + (int)threadIdx.x; p < stride; p += 256) out[p] = 0xffffffffu;  // sentinel: no cell
+    if (threadIdx.x == 0 && base > stride) atomicAdd(overflow, 1);
 }
 
 // Chunk c's list occupies entries [c·AO_CHUNK, (c+1)·AO_CHUNK) of wet_pos / trip — a fixed stride, so the solver
 // needs no lookup before it can request its list.  *overflow_out != 0: some chunk holds more wet cells than a list
 // (cannot happen with the cost-balanced table; the solver then classifies per call).
-hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks,
+hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks, bool wide,
                            const int* d_begins, uint32_t* d_wet_pos, uint8_t* d_trip, int* d_scratch, int* overflow_out) {
+    const int stride = wet_list_stride(wide);
     hipError_t e = hipMemsetAsync(d_scratch, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chunk_wet_fill_kernel, dim3(nchunks), dim3(256), 0, st, d_params, G, mask, d_begins, d_wet_pos, d_scratch);
-    if ((e = hipMemsetAsync(d_trip, 0, (size_t)nchunks * AO_CHUNK, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(chunk_wet_fill_kernel, dim3(nchunks), dim3(256), 0, st, d_params, G, mask, d_begins, d_wet_pos, d_scratch, stride);
+    if ((e = hipMemsetAsync(d_trip, 0, (size_t)nchunks * stride, st)) != hipSuccess) return e;
     int overflow = 0;
     if ((e = hipMemcpyAsync(&overflow, d_scratch, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -272,7 +304,8 @@ hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const Grid
     return hipGetLastError();
 }
 
-size_t wet_list_capacity(int ncells) { return (size_t)chunk_table_capacity(ncells) * AO_CHUNK; }
+int wet_list_stride(bool wide) { return wide ? AO_CHUNK_WIDE : AO_CHUNK; }
+size_t wet_list_capacity(int ncells) { return (size_t)chunk_table_capacity(ncells) * AO_CHUNK; }  // (≥ any wide table's need: fewer, 2.4× longer lists)
 
 // zero_interface_state of a land cell: all fluxes 0, T = 0 K (and, in the fused path, zero net fluxes inside the interior)
 template <bool FUSE_NET>
@@ -289,12 +322,11 @@ __device__ __forceinline__ void zero_cell(const LoopParams& L, double T_offset, 
 
 // ---- production solver: LDS tables, one workgroup per chunk of the table above -----------------
 // LDS: tables | list (cell offset + list entry per sorted position) | counters, histogram, bin cursors | DevParams
-constexpr int AO_COUNTERS_OFFSET = TABLE_BYTES + AO_CHUNK * 4;
-// A list word: the cell's offset from the start of the chunk's range (21 bits: a range costs at most AO_CHUNK wet
-// cells' worth of AO_WET_COST = 81 920 cells if it were all land) and its entry in the static list (11 bits).
-constexpr int AO_LIST_OFFSET_BITS = 21;
-static_assert(AO_CHUNK <= (1 << (32 - AO_LIST_OFFSET_BITS)), "list entry index must fit the upper bits");
-static_assert((long)AO_CHUNK * AO_WET_COST < (1L << AO_LIST_OFFSET_BITS), "a chunk's range must fit the lower bits");
+// A list word: the cell's offset from the start of the chunk's range (20 bits: a range costs at most AO_CHUNK_WIDE wet
+// cells' worth of AO_WET_COST = 196 608 cells if it were all land) and its entry in the static list (12 bits).
+constexpr int AO_LIST_OFFSET_BITS = 20;
+static_assert(AO_CHUNK_WIDE <= (1 << (32 - AO_LIST_OFFSET_BITS)), "list entry index must fit the upper bits");
+static_assert((long)AO_CHUNK_WIDE * AO_WET_COST < (1L << AO_LIST_OFFSET_BITS), "a chunk's range must fit the lower bits");
 
 struct WetLists {
     const uint32_t* pos;    // wet cells of chunk c in index order at [c·AO_CHUNK, …), 0xffffffff-padded; nullptr: classify per call
@@ -365,8 +397,9 @@ __device__ __forceinline__ unsigned mix32(unsigned h) {
 __device__ __forceinline__ unsigned cell_hash_lo(unsigned idx) { return mix32(idx + 0x9e3779b9u); }
 __device__ __forceinline__ unsigned cell_hash_hi(unsigned idx) { return mix32(idx * 0x01000193u ^ 0x7f4a7c15u); }
 
-template <bool COARE, int SPEC, bool FUSE_NET>
-__global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
+template <bool COARE, int SPEC, bool FUSE_NET, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
+    constexpr int CHUNK = Geom<BLOCK>::CHUNK;
     SolverArgsPtr K = opaque((SolverArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
     const LoopParams L = kread(&K->L);
     const GridDesc G = kread(&K->G);
@@ -385,10 +418,10 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tab = reinterpret_cast<double*>(smem);
     unsigned* list = reinterpret_cast<unsigned*>(smem + TABLE_BYTES);
-    int* counters = reinterpret_cast<int*>(smem + AO_COUNTERS_OFFSET);  // [0] wet count, [1] cursor, [2] wet cells seen, [3] stale
+    int* counters = reinterpret_cast<int*>(smem + Geom<BLOCK>::COUNTERS_OFFSET);  // [0] wet count, [1] cursor, [2] wet cells seen, [3] stale
     int* hist = counters + 4;
     int* bin_start = hist + AO_BINS;
-    DevParams* lp = reinterpret_cast<DevParams*>(smem + AO_PARAMS_OFFSET);
+    DevParams* lp = reinterpret_cast<DevParams*>(smem + Geom<BLOCK>::PARAMS_OFFSET);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wx = G.nx + 2 * G.ring;
     const unsigned wx_rcp = (unsigned)K->wx_reciprocal;
@@ -405,14 +438,14 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
     //     but the chunk table.  One aligned 4-byte word per cell of a byte mask, the two halves of the double for a
     //     bottom-height mask — the same two load instructions either way, so no branch.
     static_assert(sizeof(DevParams) % 16 == 0 && sizeof(DevParams) <= 1024, "the parameter block is one LDS-DMA piece");
-    static_assert(AO_PARAMS_OFFSET % 16 == 0, "LDS-DMA destination alignment");
+    static_assert(Geom<BLOCK>::PARAMS_OFFSET % 16 == 0, "LDS-DMA destination alignment");
     if (tid < (int)(sizeof(DevParams) / 16))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g_params) + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(smem + AO_PARAMS_OFFSET), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(smem + Geom<BLOCK>::PARAMS_OFFSET), 16, 0, 0);
     static_assert(TABLE_BYTES % 1024 == 0, "the table stage copies whole 1 KB pieces");
     {
         const char* gb = reinterpret_cast<const char*>(g_tab);
-        constexpr int PIECES = TABLE_BYTES / 1024, WAVES = AO_BLOCK / 64;
+        constexpr int PIECES = TABLE_BYTES / 1024, WAVES = BLOCK / 64;
 #pragma unroll
         for (int r = 0; r < (PIECES + WAVES - 1) / WAVES; ++r) {
             const int c = (tid >> 6) + r * WAVES;
@@ -421,7 +454,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                                                  (__attribute__((address_space(3))) void*)(smem + c * 1024), 16, 0, 0);
         }
     }
-    constexpr int PER_THREAD = AO_CHUNK / AO_BLOCK;
+    constexpr int PER_THREAD = CHUNK / BLOCK;
     constexpr int LAND_UNROLL = 8;  // strips of the range whose mask values are requested up front
     typedef const __attribute__((address_space(1))) unsigned* GlobalWords;
     int my_idx[PER_THREAD], my_trip[PER_THREAD];
@@ -431,22 +464,22 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
     const double z_surface = K->z_surface;
     const double T_offset = K->T_offset;
     if (use_static) {
-        const size_t base = (size_t)chunk * AO_CHUNK + tid;
+        const size_t base = (size_t)chunk * CHUNK + tid;
         const __attribute__((address_space(1))) uint32_t* gpos = (const __attribute__((address_space(1))) uint32_t*)W.pos;
         // no hint array: the bytes are read from the list itself and replaced below
         const __attribute__((address_space(1))) uint8_t* gtrip =
             (const __attribute__((address_space(1))) uint8_t*)(W.trip ? (const void*)W.trip : (const void*)W.pos);
 #pragma unroll
-        for (int n = 0; n < PER_THREAD; ++n) my_idx[n] = (int)gpos[base + n * AO_BLOCK];
+        for (int n = 0; n < PER_THREAD; ++n) my_idx[n] = (int)gpos[base + n * BLOCK];
 #pragma unroll
-        for (int n = 0; n < PER_THREAD; ++n) my_trip[n] = (int)gtrip[base + n * AO_BLOCK];
+        for (int n = 0; n < PER_THREAD; ++n) my_trip[n] = (int)gtrip[base + n * BLOCK];
         // no mask: the words are read from the list and ignored
         const unsigned long long mbase = mask_kind == CF_MASK_NONE ? (unsigned long long)W.pos : (unsigned long long)mask;
         const unsigned stride = mask_kind == CF_MASK_NONE ? 0u : (mask_kind == CF_MASK_U8 ? 1u : 8u);
         const unsigned hi_step = mask_kind == CF_MASK_BOTTOM_HEIGHT ? 4u : 0u;
 #pragma unroll
         for (int n = 0; n < LAND_UNROLL; ++n) {
-            const int ic = min(range_begin + tid + n * AO_BLOCK, range_end - 1);
+            const int ic = min(range_begin + tid + n * BLOCK, range_end - 1);
             const int jj = row_of(ic, wx, wx_rcp);
             const unsigned long long a = mbase + (unsigned long long)cell_index(G, ic - jj * wx - G.ring, jj - G.ring) * stride;
             raw_shift |= ((unsigned)a & 3u) << (2 * n);
@@ -492,7 +525,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
         unsigned land = 0;  // bit n: strip n's cell is inside the range and dry — it gets its zeros after the last barrier
 #pragma unroll
         for (int n = 0; n < LAND_UNROLL; ++n) {
-            const int idx = range_begin + tid + n * AO_BLOCK;
+            const int idx = range_begin + tid + n * BLOCK;
             const bool w = mask_kind == CF_MASK_NONE ? true
                            : mask_kind == CF_MASK_U8 ? ((raw_lo[n] >> (8 * ((raw_shift >> (2 * n)) & 3u))) & 0xffu) != 0
                                                      : !(z_surface <= __hiloint2double((int)raw_hi[n], (int)raw_lo[n]));
@@ -506,7 +539,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
             }
         }
         // a range longer than LAND_UNROLL strips (a chunk that is mostly land): the rest the plain way, zeros at once
-        for (int idx = range_begin + tid + LAND_UNROLL * AO_BLOCK; idx < range_end; idx += AO_BLOCK) {
+        for (int idx = range_begin + tid + LAND_UNROLL * BLOCK; idx < range_end; idx += BLOCK) {
             const int jj = row_of(idx, wx, wx_rcp);
             const int i = idx - jj * wx - G.ring, j = jj - G.ring;
             const size_t k = cell_index(G, i, j);
@@ -547,7 +580,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
         for (int n = 0; n < PER_THREAD; ++n)
             if (my_idx[n] >= 0) {
                 const int p = atomicAdd(&bin_start[AO_BINS - 1 - min(my_trip[n], AO_BINS - 1)], 1);
-                list[p] = ((unsigned)(tid + n * AO_BLOCK) << AO_LIST_OFFSET_BITS) | (unsigned)(my_idx[n] - range_begin);
+                list[p] = ((unsigned)(tid + n * BLOCK) << AO_LIST_OFFSET_BITS) | (unsigned)(my_idx[n] - range_begin);
             }
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the table DMA has landed
         __syncthreads();
@@ -563,7 +596,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
 #pragma unroll
                 for (int n = 0; n < LAND_UNROLL; ++n)
                     if (land & (1u << n)) {
-                        const int idx = range_begin + tid + n * AO_BLOCK;
+                        const int idx = range_begin + tid + n * BLOCK;
                         const int jj = row_of(idx, wx, wx_rcp);
                         const int i = idx - jj * wx - G.ring, j = jj - G.ring;
                         zero_cell<FUSE_NET>(L, T_offset, G, F, N, cell_index(G, i, j), i, j);
@@ -584,7 +617,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
     for (;;) {
         if (!have_list) {
             // ---- no (valid) static list: classify the piece [begin, end), zero its land ------------------
-            for (int base = begin; base < end; base += AO_BLOCK) {
+            for (int base = begin; base < end; base += BLOCK) {
                 const int idx = base + tid;
                 bool wet = false;
                 if (idx < end) {
@@ -605,14 +638,14 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                 wave_base = __shfl(wave_base, 0);
                 if (wet) {
                     const int p = wave_base + __popcll(m & ((1ull << lane) - 1ull));
-                    if (p < AO_CHUNK) list[p] = (unsigned)(idx - range_begin);
+                    if (p < CHUNK) list[p] = (unsigned)(idx - range_begin);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the table DMA has landed
             __syncthreads();
             nwet = counters[0];
-            if (nwet > AO_CHUNK) {  // more wet cells than the list holds: retry on a piece that cannot overflow it
-                end = begin + AO_CHUNK;
+            if (nwet > CHUNK) {  // more wet cells than the list holds: retry on a piece that cannot overflow it
+                end = begin + CHUNK;
                 __syncthreads();
                 if (tid < 2) counters[tid] = 0;
                 __syncthreads();
@@ -622,9 +655,26 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
         // ---- waves pull 64 wet cells at a time ---------------------------------------------------------
         for (;;) {
             int start = 0;
-            if (lane == 0) start = atomicAdd(&counters[1], 64);
-            start = __shfl(start, 0);
-            if (start >= nwet) break;
+            if constexpr (BLOCK == AO_BLOCK) {
+                if (lane == 0) start = atomicAdd(&counters[1], 64);
+                start = __shfl(start, 0);
+                if (start >= nwet) break;
+            } else {
+                // Twelve waves of one age: taken from one end of the (longest-first) queue they would run in lockstep —
+                // every wave loading, then every wave iterating — so of the three waves that share a SIMD (w, w+4, w+8) the
+                // middle one takes its batches from the short end.
+                // counters[1] counts claims; [2] / [3] (zero again once the list is validated) count each end's.
+                int claim = 0, mine = 0;
+                if (lane == 0) {
+                    claim = atomicAdd(&counters[1], 64);
+                    if (claim < nwet) mine = atomicAdd(&counters[2 + ((tid >> 8) & 1)], 1);
+                }
+                claim = __shfl(claim, 0);
+                mine = __shfl(mine, 0);
+                if (claim >= nwet) break;
+                const int nb = (nwet + 63) >> 6;
+                start = (((tid >> 8) & 1) ? nb - 1 - mine : mine) * 64;
+            }
             const int q = start + lane;
             const bool in_range = q < nwet;
             const int qc = in_range ? q : nwet - 1;
@@ -689,7 +739,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                     R.iterations = s.it;
                     const FluxOut F = kread(&Ke->F);
                     store_fluxes(F, k, R);
-                    if (use_static && W.trip) W.trip[(size_t)chunk * AO_CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.it, 255);
+                    if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.it, 255);
                 }
                 continue;
             }
@@ -726,7 +776,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ao_flux_fast_kernel(SolverArgs un
                     const FluxOut F = kread(&Ke->F);
                     store_fluxes(F, k, R);
                 }
-                if (use_static && W.trip) W.trip[(size_t)chunk * AO_CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.it, 255);
+                if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.it, 255);
                 if constexpr (FUSE_NET) {
                     // compute_net_ocean_fluxes!, the part that needs no neighbour: interior cells only
                     if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {
@@ -788,8 +838,17 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
                            double z_surface, long long mask_kind, double T_offset) {
     const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip}, L.d_chunk_begins, I, N, IceStateIn{}, IceParams{},
                        z_surface, mask_kind, T_offset, (0x100000000ull / (unsigned long long)(G.nx + 2 * G.ring))};
-#define CF_LAUNCH(COARE_, SPEC_) \
-    hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, FUSE>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A)
+#define CF_LAUNCH(COARE_, SPEC_)                                                                                                   \
+    do {                                                                                                                          \
+        if (L.ao_wide) { /* (the fused epilogue exists in the narrow geometry only: launch_ao_fluxes refuses the combination) */ \
+            if constexpr (!FUSE)                                                                                                  \
+                hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, false, AO_BLOCK_WIDE>), grid, dim3(AO_BLOCK_WIDE),       \
+                                   Geom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);                                                        \
+        } else {                                                                                                                  \
+            hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, FUSE, AO_BLOCK>), grid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, \
+                               st, A);                                                                                            \
+        }                                                                                                                         \
+    } while (0)
     switch (C.specialization) {
         case SOLVER_OCEAN: CF_LAUNCH(COARE, SOLVER_OCEAN); break;
         case SOLVER_ICE: CF_LAUNCH(COARE, SOLVER_ICE); break;
@@ -818,6 +877,7 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
                    net->downwelling_longwave, net->downwelling_shortwave};
     // one workgroup per chunk of the cost-balanced table: the hardware dispatcher is the dynamic load balancer
     if (!L.d_chunk_begins || L.n_chunks <= 0) return hipErrorInvalidValue;
+    if (net && L.ao_wide) return hipErrorInvalidValue;  // the caller keeps the three-launch sequence on wide tables
     dim3 grid(L.n_chunks);
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
     if (net) {
@@ -854,10 +914,17 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     A.T_offset = P.T_offset;
     A.wx_reciprocal = 0x100000000ull / (unsigned long long)(G.nx + 2 * G.ring);
     dim3 grid(L.n_chunks);
-    if (P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC)
-        hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE, false>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A);
-    else
-        hipLaunchKernelGGL((ao_flux_fast_kernel<false, SOLVER_SEAICE, false>), grid, dim3(AO_BLOCK), AO_LDS_BYTES, st, A);
+    const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
+    if (L.ao_wide) {
+        if (coare)
+            hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE, false, AO_BLOCK_WIDE>), grid, dim3(AO_BLOCK_WIDE), Geom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);
+        else
+            hipLaunchKernelGGL((ao_flux_fast_kernel<false, SOLVER_SEAICE, false, AO_BLOCK_WIDE>), grid, dim3(AO_BLOCK_WIDE), Geom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);
+    } else if (coare) {
+        hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE, false, AO_BLOCK>), grid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, st, A);
+    } else {
+        hipLaunchKernelGGL((ao_flux_fast_kernel<false, SOLVER_SEAICE, false, AO_BLOCK>), grid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, st, A);
+    }
     return hipGetLastError();
 }
 

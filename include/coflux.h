@@ -327,7 +327,10 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 #define CF_OPT_MAX_BLOCKS 2       /* reserved for persistent-grid experiments (multiple of 8)        */
 #define CF_OPT_TRIP_HINTS 3       /* 1 (default): order each chunk's cells by their iteration count in the
                                      previous call so that the lanes of a wave finish together; scheduling only */
-#define CF_OPT_AO_CHUNK 4         /* wet cells per workgroup of the flux solver: 256, 512, 768 or 0 = automatic */
+#define CF_OPT_AO_CHUNK 4         /* wet cells per workgroup of the flux solver: 0 = automatic (arrival layers of 1280 / 512 / 512
+                                     on a surface that fills the device, 256 on a slab that does not), 256 … 1280 = that size for
+                                     every 256-thread workgroup, 3072 = the wide geometry (one 768-thread workgroup per CU;
+                                     measured 3 % slower on the 1/4° surface) */
 #define CF_OPT_PROFILE_STRIDE 5   /* cf_profile_enable: bracket only every n-th cf_update_state with events (1); the event
                                      records between the kernels cost ≈ 4 µs of stream time each               */
 #define CF_OPT_FUSED_NET 6        /* 1: cf_update_state computes the cell-local net ocean fluxes in the solver's epilogue and

@@ -177,14 +177,14 @@ def test_tripolar_like_general_weights_and_rotation(fused):
 
 
 def test_launch_geometry_does_not_change_results():
-    """Persistent-grid size and the LDS tile capacity (incl. the global-gather fallback) are pure
-    speed knobs."""
+    """Persistent-grid size, the LDS tile capacity (incl. the global-gather fallback), the solver's chunk size and its
+    workgroup geometry (3072 = one 768-thread workgroup per CU) are pure speed knobs."""
     params = ic.flux_params()
     case = util.build_case(200, 37, 4, 4)
     ref = run_gpu(case, params, fused=True)
     for options in (((abi.OPT_MAX_BLOCKS, 8),), ((abi.OPT_MAX_BLOCKS, 24), (abi.OPT_INTERP_TILE_CAP, 16)),
                     ((abi.OPT_INTERP_TILE_CAP, 224),), ((abi.OPT_INTERP_TILE_CAP, 0),), ((abi.OPT_AO_CHUNK, 256),), ((abi.OPT_AO_CHUNK, 512),),
-                    ((abi.OPT_AO_CHUNK, 768),)):
+                    ((abi.OPT_AO_CHUNK, 768),), ((abi.OPT_AO_CHUNK, 1280),), ((abi.OPT_AO_CHUNK, 3072),)):
         for fused in (False, True):
             got = run_gpu(case, params, fused=fused, options=options)
             for grp in ("atmos", "fluxes", "net"):
