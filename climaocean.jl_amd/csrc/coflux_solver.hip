@@ -46,13 +46,13 @@ static_assert(Geom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow solver workgroup
 // wave→SIMD placement in every workgroup, two SIMDs of the CU — idle for the second half); (ii) the device
 // holds 3 workgroups per CU, and a dispatch "round" that is only half full runs at half throughput.
 // The wet mask is static, so the surface is cut ONCE per mask into chunks of prescribed cost with
-// wet = AO_WET_COST, land = 1.  The host picks a descending sequence of rounds — each a full set of
-// 3·CU chunks of 768, 512 or 256 wet cells, the remainder as a last partial round of the smallest size —
+// wet = AO_WET_COST, land = 1.  The host picks a descending sequence of rounds (plan_chunk_rounds below: arrival
+// layers of 1280 / 512 / 512 wet cells on a surface that fills the device, 256-cell chunks on one that does not)
 // so that the long workgroups start first and whatever tail is left is short.  An open-ocean chunk holds
 // exactly its nominal wet count, a coastal one slightly fewer, a land chunk at most 64× as many cells (it
-// only writes zeros).  The table only steers scheduling: the solver re-classifies every cell of its range
-// on every call and falls back to smaller pieces if a range holds more wet cells than the list (a mask
-// changed in place), so a stale table can cost time, never correctness.
+// only writes zeros).  The table and the static wet lists built with it only steer scheduling: the solver checks
+// the list against the mask as it is on every call and falls back to classifying its range (in pieces, if a range
+// holds more wet cells than the list) when a mask changed in place — a stale table can cost time, never correctness.
 // ---------------------------------------------------------------------------------------------
 constexpr int AO_WET_COST = 64;
 constexpr int AO_MAX_ROUNDS = 8;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void chunk_wet_fill_kernel(const DevParams* __
     if (threadIdx.x == 0 && base > stride) atomicAdd(overflow, 1);
 }
 
-// Chunk c's list occupies entries [c·AO_CHUNK, (c+1)·AO_CHUNK) of wet_pos / trip — a fixed stride, so the solver
+// Chunk c's list occupies entries [c·stride, (c+1)·stride) of wet_pos / trip — a fixed stride per geometry, so the solver
 // needs no lookup before it can request its list.  *overflow_out != 0: some chunk holds more wet cells than a list
 // (cannot happen with the cost-balanced table; the solver then classifies per call).
 hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks, bool wide,

@@ -122,3 +122,9 @@ def park_model(key, P, chunk=1024):
     return (main + drain) / (Ts.shape[0] * Ts.shape[1])   # iteration-equivalents per batch, overhead included
 for P in (0, 2, 4, 8, 12, 16):
     print("  P=%2d: stale key %.3f   exact key %.3f   (per batch, incl. %.1f overhead; P=0 is today's kernel)" % (P, park_model(tB.astype(float), P), park_model(t1.astype(float), P), OVER))
+print("--- upward-biased keys (an under-predicted lane costs its whole batch an iteration, an over-predicted one idles)")
+mgB = tB - cB
+print("  key = max(t(n), t(n-1))                 %.3f" % eff(np.maximum(tA, tB).astype(float)))
+for thr in (0.1, 0.2, 0.3, 0.5):
+    print("  key = t(n) + [margin < %.1f]             %.3f   (cells bumped: %.1f %%)" % (thr, eff(tB + (mgB < thr)), 100 * float((mgB < thr).mean())))
+print("  key = t(n) + 1 for every cell            %.3f" % eff(tB + 1.0))
