@@ -459,7 +459,10 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unuse
     typedef const __attribute__((address_space(1))) unsigned* GlobalWords;
     int my_idx[PER_THREAD], my_trip[PER_THREAD];
     unsigned raw_lo[LAND_UNROLL], raw_hi[LAND_UNROLL], raw_shift = 0;  // raw_shift: 2 bits per strip, the byte within its word
-    const int range_begin = chunk_begins[chunk], range_end = chunk_begins[chunk + 1];
+    // (scalar loads through the constant address space: a vector load here would sit behind the table DMA issued above
+    // in the in-order vector-memory queue, and its wait would hold back the list and mask requests until the DMA landed)
+    const __attribute__((address_space(4))) int* cb = (const __attribute__((address_space(4))) int*)chunk_begins;
+    const int range_begin = cb[chunk], range_end = cb[chunk + 1];
     const int mask_kind = (mask == nullptr) ? CF_MASK_NONE : (int)K->mask_kind;
     const double z_surface = K->z_surface;
     const double T_offset = K->T_offset;
