@@ -377,8 +377,8 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
     if (grid->hx < grid->ring + 1 || grid->hy < grid->ring + 1)
         return fail(nullptr, CF_ERR_INVALID, "halo (%d,%d) too small: need >= ring+1 = %d for the face stencils",
                     grid->hx, grid->hy, grid->ring + 1);
-    if ((long long)(grid->nx + 2 * grid->ring) * (grid->ny + 2 * grid->ring) >= (1LL << 26))
-        return fail(nullptr, CF_ERR_INVALID, "surface of %d x %d cells: the kernels index a surface with fewer than 2^26 cells "
+    if ((long long)(grid->nx + 2 * grid->ring) * (grid->ny + 2 * grid->ring) >= (1LL << 24))
+        return fail(nullptr, CF_ERR_INVALID, "surface of %d x %d cells: the kernels index a surface with fewer than 2^24 cells per context "
                     "(shard it by latitude slabs)", grid->nx, grid->ny);
     cf_ctx* ctx = new cf_ctx();
     ctx->device = device;
