@@ -479,6 +479,10 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
         case CF_OPT_FUSED_NET:
             ctx->fused_net = value != 0;
             return CF_OK;
+        case CF_OPT_ICE_ORBIT_SHORTCUT:
+            ctx->ice_orbit_shortcut = value != 0;
+            ctx->ice_kernel.orbit_shortcut = value != 0 ? 1.0 : 0.0;
+            return CF_OK;
         case CF_OPT_PROFILE_STRIDE:
             if (value < 1) return fail(ctx, CF_ERR_INVALID, "profile stride %d must be >= 1", value);
             ctx->prof_stride = value;
@@ -904,6 +908,7 @@ int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, co
     K.albedo = ice->albedo;
     K.T_offset = ice->temperature_offset;
     K.semi_implicit = ice->skin_temperature_scheme == CF_SKIN_SEMI_IMPLICIT ? 1.0 : 0.0;
+    K.orbit_shortcut = ctx->ice_orbit_shortcut ? 1.0 : 0.0;
     ctx->ice_kernel = K;
     ctx->ice_ready = true;
     return CF_OK;

@@ -384,6 +384,10 @@ __device__ __forceinline__ int row_of(int idx, int wx, unsigned wx_reciprocal) {
     return idx - q * wx >= wx ? q + 1 : q;
 }
 
+// Sort bin of a trip count: one bin per count below 24 (the ocean's range), eight-count bins above (the sea-ice
+// iteration's orbit cells stop anywhere between 14 and maxiter = 100), everything from 80 up in the last bin.
+__device__ __forceinline__ int trip_bin(int t) { return t < 24 ? t : min(24 + ((t - 24) >> 3), AO_BINS - 1); }
+
 // two independent 32-bit mixes of a cell's linear index (murmur3's finaliser): XOR-accumulated over a set of cells
 // they make a 64-bit fingerprint of the set
 __device__ __forceinline__ unsigned mix32(unsigned h) {
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unuse
 #pragma unroll
         for (int n = 0; n < PER_THREAD; ++n)
             if (my_idx[n] >= 0) {
-                atomicAdd(&hist[AO_BINS - 1 - min(my_trip[n], AO_BINS - 1)], 1);
+                atomicAdd(&hist[AO_BINS - 1 - trip_bin(my_trip[n])], 1);
                 hx ^= cell_hash_lo((unsigned)my_idx[n]);
                 hy ^= cell_hash_hi((unsigned)my_idx[n]);
             }
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unuse
 #pragma unroll
         for (int n = 0; n < PER_THREAD; ++n)
             if (my_idx[n] >= 0) {
-                const int p = atomicAdd(&bin_start[AO_BINS - 1 - min(my_trip[n], AO_BINS - 1)], 1);
+                const int p = atomicAdd(&bin_start[AO_BINS - 1 - trip_bin(my_trip[n])], 1);
                 list[p] = ((unsigned)(tid + n * BLOCK) << AO_LIST_OFFSET_BITS) | (unsigned)(my_idx[n] - range_begin);
             }
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the table DMA has landed
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unuse
                     R.iterations = s.it;
                     const FluxOut F = kread(&Ke->F);
                     store_fluxes(F, k, R);
-                    if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.it, 255);
+                    if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.work, 255);
                 }
                 continue;
             }
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unuse
                     const FluxOut F = kread(&Ke->F);
                     store_fluxes(F, k, R);
                 }
-                if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.it, 255);
+                if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.work, 255);
                 if constexpr (FUSE_NET) {
                     // compute_net_ocean_fluxes!, the part that needs no neighbour: interior cells only
                     if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {

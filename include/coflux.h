@@ -337,6 +337,10 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                      follows with a face-stress kernel; 0 (default): the three-launch sequence.  Bitwise the
                                      same results; measured SLOWER on MI355X (the epilogue's nine extra scattered 8-byte
                                      accesses per cell cost the solver 18 µs and save 14 µs of net-flux kernel). */
+#define CF_OPT_ICE_ORBIT_SHORTCUT 7 /* 1 (default): the atmosphere–sea-ice iteration stops as soon as its state repeats the state of two
+                                     iterations ago bit for bit — an exact period-2 orbit, where the skin-temperature balance does not
+                                     contract — and returns the iterate the remaining steps up to maxiter would end on (the same
+                                     bits, tested); 0: iterate to maxiter */
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path, LDS-tabulated ψ/log, ≤1e-12 of libm */
 #define CF_SOLVER_LIBM 1    /* same iteration on ocml's libm (slow; cross-check)                     */
 int cf_set_option(cf_ctx* ctx, int option, int value);

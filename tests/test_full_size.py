@@ -122,3 +122,18 @@ def test_config3_sea_ice_interface_full_surface_against_the_oracle(scheme):
     worst = util.compare_ice_fluxes(got, ref, 1e-9, tol_unconverged=None)
     wet = ref["iterations"] > 0
     print(f"scheme {scheme}: {100 * (ref['iterations'][wet] >= 100).mean():.1f} % of the wet cells at maxiter; worst errors {worst}")
+
+
+@pytest.mark.parametrize("config,scheme", [("sea_ice_corrected", 0), ("sea_ice_corrected", 1), ("sea_ice_ncar", 0)])
+def test_sea_ice_orbit_shortcut_returns_the_bits_of_the_full_iteration(config, scheme):
+    """Where the skin-temperature balance does not contract the iteration falls into a period-2 orbit that becomes exact
+    in floating point; the kernel then stops and returns the state the remaining iterations up to maxiter would end on
+    (CF_OPT_ICE_ORBIT_SHORTCUT).  Same bits as iterating to maxiter — every field, every cell of the 1/4° surface —
+    and it must actually fire (most abandoned cells are on such an orbit)."""
+    from coflux import abi
+    from test_gpu_parity import run_ice
+    case = util.build_case(1440, 560, 7, 7)
+    fast, ref = run_ice(case, config, scheme=scheme)
+    slow, _ = run_ice(case, config, scheme=scheme, options=((abi.OPT_ICE_ORBIT_SHORTCUT, 0),))
+    for k in fast:
+        np.testing.assert_array_equal(fast[k], slow[k], err_msg=k)

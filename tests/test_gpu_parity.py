@@ -454,7 +454,7 @@ def test_c_driver_through_the_abi(tmp_path):
 TOL_ICE = 1e-9  # cells converging within 40 iterations; slower ones 1e-6 (util.compare_ice_fluxes)
 
 
-def run_ice(case, config, *, ring=1, albedo=True, drift=True, atmos_override=None, scheme=abi.SKIN_EXPLICIT):
+def run_ice(case, config, *, ring=1, albedo=True, drift=True, atmos_override=None, scheme=abi.SKIN_EXPLICIT, options=()):
     nx, ny, hx, hy = case["nx"], case["ny"], case["hx"], case["hy"]
     fluxes_f, vd = util.ICE_CONFIGS[config]()
     ice_params = ic.flux_params(fluxes_f, velocity_difference=vd)
@@ -472,6 +472,8 @@ def run_ice(case, config, *, ring=1, albedo=True, drift=True, atmos_override=Non
 
     ctx = FluxContext(nx, ny, hx, hy, ic.flux_params(), ring=ring)   # the ocean formulation is independent
     ctx.set_sea_ice_formulation(ice_params, props.to_params())
+    for opt, val in options:
+        ctx.set_option(opt, val)
     dev = ctx.to_device
     ocean = {k: dev(case["ocean"][k]) for k in ("T", "S", "u", "v", "mask")}
     atmos = {k: dev(at[k]) for k in EXCHANGE_NAMES}
