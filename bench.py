@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--net-diagnostics", action="store_true",
                     help="also write the three optional radiation diagnostics of cf_net_ocean_fluxes (24 B/cell beyond "
                          "the 88 + 40 B/cell contract of compute_net_ocean_fluxes!, SURVEY.md §8d)")
+    ap.add_argument("--ice-orbit-shortcut", type=int, choices=(0, 1), default=1,
+                    help="--config sea_ice: CF_OPT_ICE_ORBIT_SHORTCUT (0 = iterate every abandoned cell to maxiter)")
     ap.add_argument("--share-device", action="store_true",
                     help="REHEARSAL of the N-rank code path on a box with fewer devices: every rank uses device 0, the host-side "
                          "collectives go over gloo, and only the halo backends that can run two ranks on one device are "
@@ -209,6 +211,7 @@ def main():
     if a.config == "sea_ice":
         ice_cfg = ic.corrected_atmosphere_sea_ice_fluxes() if a.flux_configuration != "ncar" else ic.ncar_atmosphere_sea_ice_fluxes()
         ctx.set_sea_ice_formulation(ic.flux_params(ice_cfg))
+        ctx.set_option(abi.OPT_ICE_ORBIT_SHORTCUT, a.ice_orbit_shortcut)
         si_np = syn.sea_ice_state(nx, ny, h, h, ny_global=ny_global, j_offset=j0)
         ice = {k: ctx.to_device(ocean_np[0]["ice_" + k]) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")}
         ice_state = dict(concentration=ice["concentration"], **{k: ctx.to_device(si_np[k]) for k in ("thickness", "top_temperature", "u", "v", "albedo")})
