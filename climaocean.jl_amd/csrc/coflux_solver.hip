@@ -388,6 +388,9 @@ __device__ __forceinline__ int row_of(int idx, int wx, unsigned wx_reciprocal) {
 // iteration's orbit cells stop anywhere between 14 and maxiter = 100), everything from 80 up in the last bin.
 __device__ __forceinline__ int trip_bin(int t) { return t < 24 ? t : min(24 + ((t - 24) >> 3), AO_BINS - 1); }
 
+// (a one-cell-wide window: 2³² does not fit the 32-bit operand; 2³² − 1 gives q = idx − 1 and the correction step adds the one)
+static unsigned long long row_reciprocal(int wx) { return wx <= 1 ? 0xffffffffull : 0x100000000ull / (unsigned long long)wx; }
+
 // two independent 32-bit mixes of a cell's linear index (murmur3's finaliser): XOR-accumulated over a set of cells
 // they make a 64-bit fingerprint of the set
 __device__ __forceinline__ unsigned mix32(unsigned h) {
@@ -844,7 +847,7 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
                            const OceanIn& O, const Exchange& E, const FluxOut& F, const IceIn& I, const NetOut& N,
                            double z_surface, long long mask_kind, double T_offset) {
     const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip}, L.d_chunk_begins, I, N, IceStateIn{}, IceParams{},
-                       z_surface, mask_kind, T_offset, (0x100000000ull / (unsigned long long)(G.nx + 2 * G.ring))};
+                       z_surface, mask_kind, T_offset, row_reciprocal(G.nx + 2 * G.ring)};
 #define CF_LAUNCH(COARE_, SPEC_)                                                                                                   \
     do {                                                                                                                          \
         if (L.ao_wide) { /* (the fused epilogue exists in the narrow geometry only: launch_ao_fluxes refuses the combination) */ \
@@ -919,7 +922,7 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     A.z_surface = P.z_surface;
     A.mask_kind = P.mask_kind;
     A.T_offset = P.T_offset;
-    A.wx_reciprocal = 0x100000000ull / (unsigned long long)(G.nx + 2 * G.ring);
+    A.wx_reciprocal = row_reciprocal(G.nx + 2 * G.ring);
     dim3 grid(L.n_chunks);
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
     if (L.ao_wide) {

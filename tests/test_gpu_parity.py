@@ -195,7 +195,7 @@ def test_launch_geometry_does_not_change_results():
 def test_ring0_and_ragged_sizes():
     """Sizes that are not multiples of the 64×4 tile / 256-thread block; ring = 0."""
     params = ic.flux_params()
-    for (nx, ny) in [(1, 1), (7, 3), (65, 5), (130, 9)]:
+    for (nx, ny) in [(1, 1), (1, 40), (2, 33), (7, 3), (65, 5), (130, 9)]:   # (1, 40): a one-cell-wide window (row arithmetic)
         case = util.build_case(nx, ny, 2, 2)
         for fused in (False, True):
             got = run_gpu(case, params, ring=0, fused=fused)
