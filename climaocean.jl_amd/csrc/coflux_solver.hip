@@ -657,7 +657,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unuse
             if (nwet > CHUNK) {  // more wet cells than the list holds: retry on a piece that cannot overflow it
                 end = begin + CHUNK;
                 __syncthreads();
-                if (tid < 2) counters[tid] = 0;
+                if (tid < 4) counters[tid] = 0;  // ([2], [3]: the wide geometry's two queue ends)
                 __syncthreads();
                 continue;
             }
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unuse
         begin = end;  // classification path: the rest of the range
         end = range_end;
         __syncthreads();  // list and counters are reused
-        if (tid < 2) counters[tid] = 0;
+        if (tid < 4) counters[tid] = 0;  // ([2], [3]: the wide geometry's two queue ends)
         __syncthreads();
     }
 }

@@ -334,7 +334,8 @@ def test_trip_count_hints_only_reorder_work():
     ctx.close()
 
 
-def test_stale_chunk_table_costs_time_not_correctness():
+@pytest.mark.parametrize("plan", [0, 3072])
+def test_stale_chunk_table_costs_time_not_correctness(plan):
     """The solver's chunk table is built from the wet mask on the first call.  Rewriting the mask IN PLACE (same
     pointer) afterwards — here: almost-all-land becomes all-ocean, so ranges sized for 16× as many land cells now
     overflow the workgroup's wet-cell list — must still give the oracle's answer (the kernel re-classifies every
@@ -342,6 +343,7 @@ def test_stale_chunk_table_costs_time_not_correctness():
     params = ic.flux_params()
     case = util.build_case(300, 64, 4, 4)
     ctx = FluxContext(300, 64, 4, 4, params)
+    ctx.set_option(abi.OPT_AO_CHUNK, plan)   # 3072: the wide workgroup geometry (its two-ended batch queue restarts per piece)
     dev = ctx.to_device
     src = {k: dev(v) for k, v in case["src"].items()}
     w = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in case["weights"].items()}
@@ -365,10 +367,13 @@ def test_stale_chunk_table_costs_time_not_correctness():
         np.testing.assert_array_equal(util.window(fluxes["iterations"].cpu().numpy(), 4, 4, 300, 64, 1),
                                       util.window(ref["iterations"], 4, 4, 300, 64, 1))
 
+    all_land = np.zeros_like(case["ocean"]["mask"])
+    ocean["mask"].copy_(torch.from_numpy(all_land))
+    check(all_land)                                      # table built for a surface without a single wet cell
     mostly_land = np.zeros_like(case["ocean"]["mask"])
     mostly_land[::7, ::5] = 1
     ocean["mask"].copy_(torch.from_numpy(mostly_land))
-    check(mostly_land)                                   # table built for a land-dominated surface
+    check(mostly_land)                                   # same pointer: stale already
     all_ocean = np.ones_like(mostly_land)
     ocean["mask"].copy_(torch.from_numpy(all_ocean))     # same pointer, new contents: the table is stale
     check(all_ocean)
