@@ -29,14 +29,14 @@ template <int BLOCK>
 struct Geom {
     static constexpr int CHUNK = BLOCK == AO_BLOCK ? AO_CHUNK : AO_CHUNK_WIDE;
     static constexpr int COUNTERS_OFFSET = TABLE_DOUBLES * 8 + CHUNK * 4;
-    static constexpr int PARAMS_OFFSET = COUNTERS_OFFSET + 16 + 2 * 32 * 4;
+    static constexpr int PARAMS_OFFSET = COUNTERS_OFFSET + 16 + 2 * 64 * 4;
     static constexpr int LDS_BYTES = PARAMS_OFFSET + (int)sizeof(DevParams);
 };
 static_assert(Geom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
 constexpr int AO_LAYER_1 = 1280, AO_LAYER_2 = 512, AO_LAYER_3 = 512;  // wet cells per chunk of the last three arrival layers (plan_chunk_rounds)
 static_assert(AO_LAYER_1 <= AO_CHUNK && AO_LAYER_1 >= AO_LAYER_2 && AO_LAYER_2 >= AO_LAYER_3, "layer sizes");
-constexpr int AO_BINS = 32;    // trip-count bins of the per-chunk counting sort
-static_assert(AO_BINS == 32, "Geom<>::PARAMS_OFFSET spells the bin count out");
+constexpr int AO_BINS = 64;    // trip-count bins of the per-chunk counting sort (one wave scans them)
+static_assert(AO_BINS == 64, "Geom<>::PARAMS_OFFSET spells the bin count out");
 static_assert(Geom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow solver workgroups must fit the CU's 160 KB of LDS");
 
 // ---------------------------------------------------------------------------------------------
@@ -384,9 +384,9 @@ __device__ __forceinline__ int row_of(int idx, int wx, unsigned wx_reciprocal) {
     return idx - q * wx >= wx ? q + 1 : q;
 }
 
-// Sort bin of a trip count: one bin per count below 24 (the ocean's range), eight-count bins above (the sea-ice
-// iteration's orbit cells stop anywhere between 14 and maxiter = 100), everything from 80 up in the last bin.
-__device__ __forceinline__ int trip_bin(int t) { return t < 24 ? t : min(24 + ((t - 24) >> 3), AO_BINS - 1); }
+// Sort bin of a trip count: one bin per count below 56 (the ocean needs 8–20 iterations, most sea-ice cells 10–40),
+// eight-count bins above (the sea-ice iteration's orbit cells stop anywhere up to maxiter = 100).
+__device__ __forceinline__ int trip_bin(int t) { return t < 56 ? t : min(56 + ((t - 56) >> 3), AO_BINS - 1); }
 
 // (a one-cell-wide window: 2³² does not fit the 32-bit operand; 2³² − 1 gives q = idx − 1 and the correction step adds the one)
 static unsigned long long row_reciprocal(int wx) { return wx <= 1 ? 0xffffffffull : 0x100000000ull / (unsigned long long)wx; }
