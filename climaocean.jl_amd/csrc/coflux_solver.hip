@@ -384,6 +384,17 @@ __device__ __forceinline__ int row_of(int idx, int wx, unsigned wx_reciprocal) {
     return idx - q * wx >= wx ? q + 1 : q;
 }
 
+// The scheduling hint of a cell: its work in this call, or the previous hint minus one if that is larger.  A cell
+// that ran long once keeps a long hint for a while (it decays by one per call) and is scheduled among the first batches
+// of its workgroup; hinted short and running long it would sit in a LATE batch and hold the workgroup — and with it the
+// kernel — for its whole iteration alone (the sea-ice solve with its hints a step old: 386 → 300 µs; a cell that flips
+// between 35 and 100 iterations from one step to the next is all it takes).  An over-hinted lane merely idles.
+// Sea ice only: the ocean's counts move by ±1, there the read-modify-write costs more than the bias saves (+0.5 %).
+__device__ __forceinline__ void store_hint(uint8_t* hint, int work) {
+    const int old = *hint;
+    *hint = (uint8_t)min(max(work, old - 1), 255);
+}
+
 // Sort bin of a trip count: one bin per count below 56 (the ocean needs 8–20 iterations, most sea-ice cells 10–40),
 // eight-count bins above (the sea-ice iteration's orbit cells stop anywhere up to maxiter = 100).
 __device__ __forceinline__ int trip_bin(int t) { return t < 56 ? t : min(56 + ((t - 56) >> 3), AO_BINS - 1); }
@@ -749,7 +760,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unuse
                     R.iterations = s.it;
                     const FluxOut F = kread(&Ke->F);
                     store_fluxes(F, k, R);
-                    if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.work, 255);
+                    if (use_static && W.trip) store_hint(&W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)], s.work);
                 }
                 continue;
             }
