@@ -626,10 +626,13 @@ struct IceConsts {
     double rho, cp, qav, Ls, Ti, hk, Qd, theta_a, pa, du, dv, dU2, dU, alpha_g;
 };
 
-__device__ __forceinline__ double svp_ice_fast(const DevParams& P, const double* logt, double T, double inv_T) {
+__device__ __forceinline__ double svp_ice_from(const DevParams& P, const SvpArg& s) {
     const double dcp = P.cp_v - P.cp_i;
     const double a = dcp * P.inv_R_v, b = (P.LH_s0 - dcp * P.T_0) * P.inv_R_v;
-    return P.p_triple * fexp(__builtin_fma(a, flog(logt, T * P.inv_T_triple), b * (P.inv_T_triple - inv_T)));
+    return P.p_triple * fexp(__builtin_fma(a, s.L, b * s.D));
+}
+__device__ __forceinline__ double svp_ice_fast(const DevParams& P, const double* logt, double T, double inv_T) {
+    return svp_ice_from(P, svp_arg(P, logt, T, inv_T));
 }
 
 template <bool COARE>
@@ -670,10 +673,11 @@ __device__ __forceinline__ Scales ice_iterate(const DevParams& P, const LoopPara
             const double dT = fmin(fmax(Tstar - Ts, -I.dT_max), I.dT_max);
             Ts = fmin(Ts + dT, I.T_melt);
             const double inv_Ts = frcp(Ts);
-            const double qs = svp_ice_fast(P, logt, Ts, inv_Ts) * frcp(c.rho * P.R_v * Ts);
+            const SvpArg arg_s = svp_arg(P, logt, Ts, inv_Ts);  // one logarithm for both saturation pressures at Ts
+            const double qs = svp_ice_from(P, arg_s) * frcp(c.rho * P.R_v * Ts);
             const double dq = c.qav - qs, dtheta = c.theta_a - Ts;
             const double lam_s = liquid_fraction_fast(P, logt, Ts);
-            const double pvs_s = svp_equil_fast(P, logt, Ts, inv_Ts, lam_s);
+            const double pvs_s = svp_equil_from(P, arg_s, lam_s);
             const AirState Sfc = air_state_fast(P, c.pa, Ts, inv_Ts, qs, lam_s, pvs_s);
             const double gTv = P.g * frcp(Sfc.T_virtual);
 
