@@ -16,7 +16,8 @@ for n in range(ncases):
     nx = int(rng.choice([1, 2, 5, 63, 64, 65, 127, 200, 333, 777, int(rng.integers(1, 1500))]))
     ny = int(rng.choice([1, 2, 3, 7, 40, 97, int(rng.integers(1, 300))]))
     ring = int(rng.integers(0, 2)); h = int(rng.integers(ring + 1, 6))
-    case = util.build_case(nx, ny, h, h)
+    wkind = str(rng.choice(["latlon", "tripolar"])); with_ice = bool(rng.integers(0, 2)); fused = bool(rng.integers(0, 2))
+    case = util.build_case(nx, ny, h, h, weights=wkind)
     m = case["ocean"]["mask"]
     pat = rng.choice(["as_is", "speckle", "stripes", "all_land", "all_ocean", "single", "half"])
     if pat == "speckle": m[...] = (rng.random(m.shape) < rng.choice([0.05, 0.5, 0.95])).astype(m.dtype)
@@ -30,12 +31,12 @@ for n in range(ncases):
     if kind == "bottom": case["ocean"]["mask"] = np.where(m != 0, -3000.0, 10.0)
     opts = [(), ((abi.OPT_AO_CHUNK, 256),), ((abi.OPT_AO_CHUNK, 1280),), ((abi.OPT_AO_CHUNK, 3072),), ((abi.OPT_TRIP_HINTS, 0),)][int(rng.integers(0, 5))]
     try:
-        got = run_gpu(case, params, ring=ring, options=opts)
-        ref = run_oracle(case, params, ring=ring)
+        got = run_gpu(case, params, ring=ring, options=opts, ice=with_ice, fused=fused)
+        ref = run_oracle(case, params, ring=ring, ice=with_ice)
         compare(case, got, ref, ring)
         W = lambda a: util.window(a, h, h, nx, ny, ring)
         np.testing.assert_array_equal(W(got["fluxes"]["iterations"]), W(ref["fluxes"]["iterations"]))
     except Exception as exc:
         bad += 1
-        print("FAIL", n, dict(nx=nx, ny=ny, h=h, ring=ring, pat=pat, kind=kind, opts=opts), repr(exc)[:300], flush=True)
+        print("FAIL", n, dict(nx=nx, ny=ny, h=h, ring=ring, pat=str(pat), kind=str(kind), opts=opts, w=wkind, ice=with_ice, fused=fused), repr(exc)[:300], flush=True)
 print(f"{ncases - bad} of {ncases} cases passed", flush=True)
