@@ -165,7 +165,7 @@ static LoopParams loop_params(const cf_flux_params& p, const DevParams& d) {
     // branch-free instruction streams for the two production configurations (omip_simulation.jl:42-49, :63-69)
     const bool gusty = p.minimum_gustiness > 0;  // ⇒ U > 0 ⇒ u★ > 0: no division guards needed
     if (gusty && m.kind != CF_ROUGHNESS_CONSTANT && q.kind == CF_SCALAR_ROUGHNESS_REYNOLDS && C.same_scalar)
-        C.specialization = SOLVER_OCEAN;
+        C.specialization = SOLVER_OCEAN_LEAN;  // (CF_OPT_SOLVER = CF_SOLVER_TABLES_R2 runs it on SOLVER_OCEAN's body)
     else if (gusty && m.kind == CF_ROUGHNESS_CONSTANT && q.kind == CF_SCALAR_ROUGHNESS_CONSTANT &&
              t.kind == CF_SCALAR_ROUGHNESS_CONSTANT)
         C.specialization = SOLVER_ICE;
@@ -187,6 +187,10 @@ static LoopParams loop_params(const cf_flux_params& p, const DevParams& d) {
         C.ly_lz = std::log(d.h_ref / 10.0);
     }
     C.inv_kappa = 1.0 / d.kappa;
+    C.gust_c = d.beta_gust * d.beta_gust * d.beta_gust * d.h_bl / d.kappa;
+    C.min_gust2 = d.min_gust * d.min_gust;
+    C.x_scale = PSI_A * d.h_ref;
+    C.two_inv_kappa = 2.0 / d.kappa;
     return C;
 }
 
@@ -460,7 +464,7 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     switch (option) {
         case CF_OPT_SOLVER:
-            if (value != CF_SOLVER_TABLES && value != CF_SOLVER_LIBM) return fail(ctx, CF_ERR_INVALID, "unknown solver %d", value);
+            if (value != CF_SOLVER_TABLES && value != CF_SOLVER_LIBM && value != CF_SOLVER_TABLES_R2) return fail(ctx, CF_ERR_INVALID, "unknown solver %d", value);
             ctx->launch.solver = value;
             return CF_OK;
         case CF_OPT_INTERP_TILE_CAP:

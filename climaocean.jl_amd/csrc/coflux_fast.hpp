@@ -125,20 +125,28 @@ struct PsiArg {
     int side;    // 0: ζ < 0 (unstable table), 1: ζ ≥ 0
 };
 
-// No logarithm: the table is indexed by the floating-point representation of x itself.
-// |ζ| > 4.3e9 (never a converged state) and NaN are evaluated at the table edge.
-__device__ __forceinline__ PsiArg psi_arg(double zeta) {
+// No logarithm: the table is indexed by the floating-point representation of x itself (two tiers, coflux_tables.h).
+// |ζ| > 1e9 (never a converged state) and NaN are evaluated at the table edge.
+__device__ __forceinline__ PsiArg psi_arg_x(double x_unclamped, bool unstable) {
     PsiArg a;
     static_assert(PSI_BINADES == 34, "the clamp below is the largest double under 2^PSI_BINADES");
-    const double x = fmin(__builtin_fma(PSI_A, fabs(zeta), 1.0), 0x1.fffffffffffffp33);
+    const double x = fmin(x_unclamped, 0x1.fffffffffffffp33);
     const int hi = __double2hiint(x);
-    a.k = (hi >> 18) - (1023 << 2);
+    const bool coarse = hi >= ((1023 + PSI_FINE_BINADES) << 20);
+    const int kf = (hi >> (20 - PSI_SUB_BITS)) - (1023 << PSI_SUB_BITS);
+    const int kc = (hi >> (20 - PSI_COARSE_SUB_BITS)) - (((1023 + PSI_FINE_BINADES) << PSI_COARSE_SUB_BITS) - PSI_FINE_SEG);
+    a.k = coarse ? kc : kf;
     // (opaque to the compiler: it otherwise folds the exponent bias into every coefficient's address, which makes the
-    // ten LDS offsets negative — not encodable — and costs one v_add per coefficient read)
+    // LDS offsets negative — not encodable — and costs one v_add per coefficient read)
     asm("" : "+v"(a.k));
-    a.t = x - __hiloint2double(hi & (int)0xfffc0000, 0);
-    a.side = zeta < 0.0 ? 0 : 1;
+    constexpr int FINE_MASK = (int)(0xfff00000u | (((1u << PSI_SUB_BITS) - 1u) << (20 - PSI_SUB_BITS)));
+    constexpr int COARSE_MASK = (int)(0xfff00000u | (((1u << PSI_COARSE_SUB_BITS) - 1u) << (20 - PSI_COARSE_SUB_BITS)));
+    a.t = x - __hiloint2double(hi & (coarse ? COARSE_MASK : FINE_MASK), 0);
+    a.side = unstable ? 0 : 1;
     return a;
+}
+__device__ __forceinline__ PsiArg psi_arg(double zeta) {
+    return psi_arg_x(__builtin_fma(PSI_A, fabs(zeta), 1.0), zeta < 0.0);
 }
 
 // fn: 0 = ψ_m, 1 = ψ_h.  Table layout: [side][coefficient][segment]{ψ_m, ψ_h} (coflux_tables.cpp).
@@ -364,6 +372,11 @@ struct LoopParams {
     // CoefficientBasedFluxes + LargeYeagerTransferCoefficients
     double ly_min_wind, ly_zeta_bound, ly_cd0, ly_cd1, ly_cd2, ly_cd3, ly_high_wind, ly_cd_high, ly_ce, ly_ch_s, ly_ch_u;
     double ly_lz, inv_kappa;  // log(h / 10 m), 1/κ
+    // the lean ocean iteration (mo_iterate_lean)
+    double gust_c;            // β³ h_bl / κ:  U_G³ = −u★ (κ b★) · gust_c
+    double min_gust2;         // U_G,min²
+    double x_scale;           // PSI_A · h: the ψ table variable of h/L★ is 1 + x_scale·|1/L★|
+    double two_inv_kappa;     // 2/κ
 };
 
 constexpr int SOLVER_OCEAN = 0;    // Charnock-type momentum roughness, identical Reynolds-scaled scalars, U_G,min > 0
@@ -371,6 +384,7 @@ constexpr int SOLVER_ICE = 1;      // constant roughness lengths, U_G,min > 0
 constexpr int SOLVER_GENERIC = 2;  // anything else (runtime kinds, u★ = 0 guards)
 constexpr int SOLVER_LY = 3;       // CoefficientBasedFluxes: Large & Yeager iteration on (Cd, Ch, Ce)
 constexpr int SOLVER_SEAICE = 4;   // atmosphere–sea-ice interface: skin temperature inside the iteration (ice_iterate)
+constexpr int SOLVER_OCEAN_LEAN = 5;  // SOLVER_OCEAN's configurations on the round-3 iteration body (mo_iterate_lean): the default
 
 using FastConsts = LoopParams;  // name kept for the launcher signatures
 

@@ -1,0 +1,261 @@
+// coflux_lean.hpp — the round-3 body of the atmosphere–ocean Monin–Obukhov iteration (SOLVER_OCEAN_LEAN).
+//
+// Same fixed point, same initial guess, same update order and same stop rule as mo_iterate<…, SOLVER_OCEAN>
+// (coflux_fast.hpp) — the reference's iteration, SURVEY §8 a5–a11; omip_simulation.jl:40-49 — restated so that one
+// iteration costs the CU less of the two pipes that bound it (measured, scratch/ubench_valu.hip: an FP64 VALU
+// instruction is 4 SIMD cycles, v_rcp/v_rsq_f64 16, a scattered ds_read_b128 10–14 cycles of the CU's one LDS pipe):
+//   * the state carries 1/u★ beside u★: u★ ← κU/D_u and 1/u★ ← D_u/(κU) both come out of ONE v_rsq_f64 of U²
+//     (√ and 1/√ by a coupled Newton step) — no reciprocal of u★;
+//   * 1/D_u and 1/D_q from one reciprocal of D_u·D_q;
+//   * κ b★ = θ★·bθ + q★·b_q with κ g/𝒯ᵥ folded into the two per-cell constants; U_G² = (β³ h_bl J_b)^⅔ from a
+//     v_log_f32/v_exp_f32 seed and ONE Newton step on y³ = w² whose divisor 1/(3y²) only needs the seed's seven
+//     digits (v_rcp_f32) — no FP64 reciprocal, no select for the stable lanes (the floor U_G,min² takes them);
+//   * ψ_m, ψ_h(h/L★): degree-6 two-tier tables (coflux_tables.h): seven 16-byte LDS reads and twelve FMAs;
+//   * log: 128-entry table + degree-4 log1p (|r| ≤ 2⁻⁸ ⇒ ≤ 1.8e-13 absolute); exp for ℓ_q: 32-entry table +
+//     degree-3 (6e-10 relative on a roughness length that enters through ψ_h(ℓ_q/L★) ≈ 1e-3 only);
+//   * ψ at the roughness-length arguments: degree 3 below |ζ| < 2⁻¹⁰ (per lane), the general table otherwise.
+// Accuracy: every iterate is within ≈ 3e-13 relative of the libm evaluation of the same map; the error budget
+// and its effect on the stop rule are measured in scratch/lean_study.py (a 1e-12 perturbation of every iterate
+// changes no trip count in 36 664 cells; 1e-11 changes 2e-4 of them) and held by tests/test_full_size.py.
+#pragma once
+#include "coflux_fast.hpp"
+
+namespace coflux {
+
+// log of a positive normal double from flog_pos_begin's table read: degree-4 log1p
+__device__ __forceinline__ double flog_lean_end(const LogHalf& h) {
+    const double r = __builtin_fma(h.m, h.ck.x, -1.0);
+    double q = __builtin_fma(r, -0.25, 1.0 / 3.0);
+    q = __builtin_fma(r, q, -0.5);
+    return __builtin_fma((double)h.e, 0.6931471805599453094, __builtin_fma(r * r, q, r) + h.ck.y);
+}
+
+// w^(2/3) for w ≥ 1e-18: f32 seed (≈ 5e-7), one Newton step on y³ = w² in FP64 (⇒ ≈ 3e-13)
+__device__ __forceinline__ double pow23_lean(double w) {
+    const float wf = (float)w;
+    const float y0f = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(wf) * (2.0f / 3.0f));
+    const float rf = __builtin_amdgcn_rcpf(3.0f * y0f * y0f);
+    const double y0 = (double)y0f;
+    const double t = __builtin_fma(-(y0 * y0), y0, w * w);
+    return __builtin_fma(t, (double)rf, y0);
+}
+
+// g ≈ √s and h ≈ 1/(2√s) for s > 0 from one v_rsq_f64 and one coupled Newton (Goldschmidt) step
+__device__ __forceinline__ void sqrt_rsqrt_lean(double s, double& g, double& h) {
+    const double r = __builtin_amdgcn_rsq(s);
+    const double g0 = s * r, h0 = 0.5 * r;
+    const double e = __builtin_fma(-g0, h0, 0.5);
+    g = __builtin_fma(g0, e, g0);
+    h = __builtin_fma(h0, e, h0);
+}
+
+// exp(x), relative ≤ 6e-10: x = (32k' + k)·ln2/32 + r, |r| ≤ ln2/64, 2^(k/32) from LDS, degree 3
+__device__ __forceinline__ double fexp_lean(const double* tab, double x) {
+    const double kf = __builtin_rint(x * (EXP_SEG * 1.4426950408889634074));
+    const double r = __builtin_fma(-kf, 0.6931471805599453094 / EXP_SEG, x);
+    const int k = (int)kf;
+    const double t = tab[EXP_OFFSET + (k & (EXP_SEG - 1))];
+    double p = __builtin_fma(r, 1.0 / 6.0, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(t * p, k >> 5);
+}
+
+// max / min against a wave-uniform, NaN-free bound held in SGPRs.  Written as instructions because the C form
+// (fmax / fmin under IEEE mode) first canonicalises the bound — v_max_f64 s, s into a VGPR pair — on every call.
+__device__ __forceinline__ double vmax_u(double x, double bound) {
+    double o;
+    asm("v_max_f64 %0, %1, %2" : "=v"(o) : "v"(x), "s"(bound));
+    return o;
+}
+__device__ __forceinline__ double vmin_u(double x, double bound) {
+    double o;
+    asm("v_min_f64 %0, %1, %2" : "=v"(o) : "v"(x), "s"(bound));
+    return o;
+}
+
+// exp(x) to ≈ 2e-15 relative: fexp_tab's reduction (32-entry table) with a degree-5 tail — the prologue's saturation
+// pressures (a third of fexp's instructions)
+__device__ __forceinline__ double fexp_tab5(const double* tab, double x) { return fexp_tab(tab, x); }
+
+// Per-cell, iteration-invariant state of the lean ocean path: what the iteration reads, and what the epilogue needs to
+// turn the converged scales into fluxes (five numbers instead of the seven of CellConsts: ρ and 1/‖Δu‖ are folded in).
+struct LeanCell {
+    double bth, bqq, dU2, dtheta, dq, alpha_g, lam_nu, inv_nu_q;  // iteration
+    double rdu, rdv, rcp, rho, Lv;                                // epilogue: ρ Δu/‖Δu‖, ρ Δv/‖Δu‖, ρ c_p, ρ, ℒv
+    double Ts;                                                    // interface temperature [K] (written before the iteration)
+};
+
+// The same relations as cell_prologue / air_state_fast (Thermodynamics.jl PhaseEquil_pTq, Raoult factor of sea water),
+// with the reciprocals shared (ten instead of fifteen, one Newton step each: 2e-15), the exponentials from the table
+// form and nothing computed that SOLVER_OCEAN_LEAN's preconditions make unnecessary (one scalar roughness, U_G,min > 0).
+// `P` should point at the LDS copy of DevParams.
+__device__ __forceinline__ LeanCell lean_prologue(const DevParams& P, double kappa, const double* tab, double ua, double va,
+                                                  double Ta, double pa, double qa, double uo, double vo, double To, double So) {
+    const double* logt = tab + LOG_OFFSET;
+    LeanCell c;
+    const double Ts = To + P.T_offset;
+    // 1/Ta, 1/Ts from one reciprocal; 1/p
+    const double rT = frcp1(Ta * Ts);
+    const double inv_Ta = rT * Ts, inv_Ts = rT * Ta;
+    const double inv_p = frcp1(pa);
+    const double tiny = 2.220446049250313e-16;
+    // ---- air at the reference height: PhaseEquil_pTq(pa, Ta, qa) ----
+    const double lam_a = liquid_fraction_fast(P, logt, Ta);
+    const SvpArg arg_a = svp_arg(P, logt, Ta, inv_Ta);
+    double pvs_a;
+    {
+        const double LH_0 = lam_a * P.LH_v0 + (1.0 - lam_a) * P.LH_s0;
+        const double dcp = lam_a * (P.cp_v - P.cp_l) + (1.0 - lam_a) * (P.cp_v - P.cp_i);
+        const double a = dcp * P.inv_R_v, b = (LH_0 - dcp * P.T_0) * P.inv_R_v;
+        pvs_a = P.p_triple * fexp_tab5(tab, __builtin_fma(a, arg_a.L, b * arg_a.D));
+    }
+    const double q = fmin(fmax(qa, 0.0), 1.0);
+    const double dp_a = pa - pvs_a;
+    const double qvsp_a = (dp_a >= tiny) ? P.Rd_over_Rv * (1.0 - q) * pvs_a * frcp1(dp_a) : 1.0 / tiny;
+    const double qc0_a = fmax(q - qvsp_a, 0.0);
+    const double inv_rho = P.R_d * (1.0 + P.delta * q - P.eps * qc0_a) * Ta * inv_p;
+    const double rho = frcp1(inv_rho);
+    const double qc_a = fmax(q - pvs_a * inv_rho * P.inv_R_v * inv_Ta, 0.0);
+    const double ql_a = lam_a * qc_a, qi_a = (1.0 - lam_a) * qc_a;
+    const double cp_m = P.cp_d + (P.cp_v - P.cp_d) * q + (P.cp_l - P.cp_v) * ql_a + (P.cp_i - P.cp_v) * qi_a;
+    const double qvap_a = fmax(0.0, q - ql_a - qi_a);
+    // ---- the sea surface: saturated over salt water at Ts ----
+    const SvpArg arg_s = svp_arg(P, logt, Ts, inv_Ts);
+    const double pstar_s = P.p_triple * fexp_tab5(tab, __builtin_fma(P.svp_a_liq, arg_s.L, P.svp_b_liq * arg_s.D));
+    const double sal = So * 1e-3, fresh = 1.0 - sal;
+    const double x_h2o = (P.sw_inv_w * fresh) * frcp1(__builtin_fma(sal, P.sw_inv_mu, P.sw_inv_w * fresh));
+    const double qs = x_h2o * pstar_s * (inv_rho * P.inv_R_v * inv_Ts);
+    c.dq = qvap_a - qs;
+    const double inv_cp = frcp1(cp_m);
+    c.dtheta = Ta + (P.g * P.h_ref) * inv_cp - Ts;
+    double du = ua, dv = va;
+    if (P.velocity_difference == CF_VELOCITY_RELATIVE) {
+        du = ua - uo;
+        dv = va - vo;
+    }
+    c.dU2 = du * du + dv * dv;
+    // 1/‖Δu‖ (0 in a dead calm) from v_rsq_f64 + one Newton step; ‖Δu‖ = Δu²·(1/‖Δu‖)
+    double inv_dU = 0.0, dU = 0.0;
+    {
+        const double r = __builtin_amdgcn_rsq(c.dU2);
+        const double g0 = c.dU2 * r, h0 = 0.5 * r;
+        const double e = __builtin_fma(-g0, h0, 0.5);
+        const bool moving = c.dU2 > 0.0;
+        dU = moving ? __builtin_fma(g0, e, g0) : 0.0;
+        inv_dU = moving ? 2.0 * __builtin_fma(h0, e, h0) : 0.0;
+    }
+    // PhaseEquil_pTq(pa, Ts, qs): virtual temperature and vapour of the surface air
+    const double lam_s = liquid_fraction_fast(P, logt, Ts);
+    double pvs_s = pstar_s;  // (water below 0 °C — polar cells only: worth a wave-level branch, and the logarithm is shared)
+    if (__any(lam_s != 1.0)) pvs_s = (lam_s == 1.0) ? pstar_s : svp_equil_from(P, arg_s, lam_s);
+    const double qss = fmin(fmax(qs, 0.0), 1.0);
+    const double dp_s = pa - pvs_s;
+    const double qvsp_s = (dp_s >= tiny) ? P.Rd_over_Rv * (1.0 - qss) * pvs_s * frcp1(dp_s) : 1.0 / tiny;
+    const double qc0_s = fmax(qss - qvsp_s, 0.0);
+    const double inv_rho_s = P.R_d * (1.0 + P.delta * qss - P.eps * qc0_s) * Ts * inv_p;
+    const double qc_s = fmax(qss - pvs_s * inv_rho_s * P.inv_R_v * inv_Ts, 0.0);
+    const double qvap_s = fmax(0.0, qss - lam_s * qc_s - (1.0 - lam_s) * qc_s);
+    const double Tv_s = (1.0 + P.delta * qss - P.eps * qc_s) * Ts;
+    const double kg = (kappa * P.g) * frcp1(Tv_s);  // κ g / 𝒯ᵥ
+    c.bth = kg * (1.0 + P.delta * qvap_s);
+    c.bqq = kg * (P.delta * Tv_s);
+    // roughness
+    const double nu_m = air_viscosity(P.rm, Ts);
+    c.inv_nu_q = frcp1(air_viscosity(P.rq, Ts));
+    double alpha = P.rm.charnock;
+    if (P.rm.kind == CF_ROUGHNESS_WIND_CHARNOCK) alpha = fmax(P.rm.charnock, P.rm.wind_a1 * fmin(dU, P.rm.wind_umax) + P.rm.wind_a2);
+    c.lam_nu = P.rm.laminar * nu_m;
+    c.alpha_g = alpha * P.inv_g;
+    // epilogue
+    const double rho_dir = rho * inv_dU;
+    c.rdu = rho_dir * du;
+    c.rdv = rho_dir * dv;
+    c.rcp = rho * cp_m;
+    c.rho = rho;
+    c.Lv = P.LH_v0 + (P.cp_v - P.cp_l) * (Ta - P.T_0);
+    c.Ts = Ts;
+    return c;
+}
+
+// All 64 lanes of a wave must call this together (wave64 ballot inside); `active` lanes iterate.
+// Preconditions (loop_params selects SOLVER_OCEAN_LEAN only then): U_G,min > 0 (⇒ u★ > 0), Charnock-type momentum
+// roughness, identical Reynolds-scaled scalar roughness lengths.  FixedIterations(n) arrives as maxiter = n, tol = 0.
+template <bool COARE>
+__device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const LeanCell& c, const double* tab, bool active) {
+    const double* logt = tab + LOG_OFFSET;
+    double us = 1e-4, ius = 1e4, ts = 1e-4, qq = 1e-4;
+    double drift = __builtin_inf();
+    int it = 0;
+    for (;;) {
+        const bool go = active && it < L.maxiter && !(drift < L.tol);
+        if (__ballot(go) == 0ull) break;  // the wave leaves the loop together
+        if (go) {
+            const double kb = __builtin_fma(ts, c.bth, c.bqq * qq);
+            const double inv_L = kb * (ius * ius);  // 1/L★ = κ b★ / u★²
+            const double lu = vmin_u(__builtin_fma(c.alpha_g * us, us, c.lam_nu * ius), L.lm_m);
+            const LogHalf half_u = flog_pos_begin(logt, lu);
+            const LogHalf half_q = flog_pos_begin(logt, lu * us * c.inv_nu_q);
+            const PsiArg ah = psi_arg_x(__builtin_fma(L.x_scale, fabs(inv_L), 1.0), kb < 0.0);
+            // wind speed scale with gustiness: U² = Δu² + max((β³ h_bl J_b)^⅔, U_G,min²); J_b = −u★ b★ > 0 ⇔ unstable
+            double U, rU;  // rU = 1/(2U)
+            if (L.beta_gust != 0.0) {
+                const double w = fmax(-(us * kb) * L.gust_c, 1e-18);
+                sqrt_rsqrt_lean(c.dU2 + vmax_u(pow23_lean(w), L.min_gust2), U, rU);
+            } else {
+                sqrt_rsqrt_lean(c.dU2 + L.min_gust2, U, rU);
+            }
+            const double2 ps = psi_eval_pair(tab, ah);
+            const double log_lu = flog_lean_end(half_u);
+            const double log_lq = vmin_u(__builtin_fma(-L.b_q, flog_lean_end(half_q), L.log_A_q), L.log_lm_q);
+            double Du = (L.log_h - log_lu) - ps.x;
+            double Dq = (L.log_h - log_lq) - ps.y;
+            if constexpr (!COARE) {
+                const double zu = lu * inv_L, zq = fexp_lean(tab, log_lq) * inv_L;
+                // per-lane choice (a cell's result never depends on which cells share its wave); a wave whose lanes all
+                // agree — four out of five — executes only one side
+                double2 pl;
+                if (fabs(zu) < SMALL_Z0 && fabs(zq) < SMALL_Z0) {
+                    asm volatile("" ::: "memory");
+                    pl = psi_small_mh(tab, inv_L < 0.0, zu, zq);
+                } else {
+                    asm volatile("" ::: "memory");
+                    pl = psi_eval_two(tab, psi_arg(zu), psi_arg(zq));
+                }
+                Du += pl.x;
+                Dq += pl.y;
+            }
+            Du = vmax_u(Du, L.profile_floor);
+            Dq = vmax_u(Dq, L.profile_floor);
+            const double r = frcp1(Du * Dq);
+            const double un = (L.kappa * U) * (r * Dq);
+            const double chi = L.kappa * (r * Du);
+            const double tn = chi * c.dtheta, qn = chi * c.dq;
+            ius = (Du * rU) * L.two_inv_kappa;  // 1/u★ = D_u / (κ U)
+            drift = fabs(un - us) + fabs(tn - ts) + fabs(qn - qq);
+            us = un;
+            ts = tn;
+            qq = qn;
+            ++it;
+        }
+    }
+    return Scales{us, ts, qq, it, it};
+}
+
+__device__ __forceinline__ CellFluxes lean_epilogue(const LeanCell& c, double T_offset, const Scales& s) {
+    CellFluxes R;
+    const double mu2 = -(s.us * s.us);
+    R.Fv = -(c.rho * s.us) * s.qq;
+    R.Qv = R.Fv * c.Lv;
+    R.Qc = -(c.rcp * s.us) * s.ts;
+    R.rho_tau_x = mu2 * c.rdu;
+    R.rho_tau_y = mu2 * c.rdv;
+    R.Ts_ocean = c.Ts - T_offset;
+    R.ustar = s.us;
+    R.tstar = s.ts;
+    R.qstar = s.qq;
+    R.iterations = s.it;
+    return R;
+}
+
+}  // namespace coflux

@@ -9,12 +9,16 @@
 #include <hip/hip_runtime.h>
 
 #include "coflux_fast.hpp"
+#include "coflux_lean.hpp"
 #include "coflux_kernel_types.hpp"
 #include "coflux_kernels.h"
 
 namespace coflux {
 
 constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
+#ifndef CF_LEAN_WAVES
+#define CF_LEAN_WAVES 3  // waves per SIMD the lean ocean solver is compiled for
+#endif
 
 // Two workgroup geometries.  NARROW: 256 threads, three workgroups per CU (each with its own copy of the tables),
 // chunks of ≤ 1280 wet cells in arrival layers — the only choice for a surface too small to give every CU a big chunk.
@@ -415,8 +419,10 @@ __device__ __forceinline__ unsigned mix32(unsigned h) {
 __device__ __forceinline__ unsigned cell_hash_lo(unsigned idx) { return mix32(idx + 0x9e3779b9u); }
 __device__ __forceinline__ unsigned cell_hash_hi(unsigned idx) { return mix32(idx * 0x01000193u ^ 0x7f4a7c15u); }
 
+// (second launch bound = waves per SIMD: the lean ocean iteration fits 128 VGPRs — four narrow workgroups per CU, whose
+// LDS, tables included, is 39 KB each; everything else keeps three)
 template <bool COARE, int SPEC, bool FUSE_NET, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
+__global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BLOCK) ? CF_LEAN_WAVES : 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
     constexpr int CHUNK = Geom<BLOCK>::CHUNK;
     SolverArgsPtr K = opaque((SolverArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
     const LoopParams L = kread(&K->L);
@@ -764,6 +770,60 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unuse
                 }
                 continue;
             }
+            if constexpr (SPEC == SOLVER_OCEAN_LEAN) {
+                // ---- the round-3 path: lean prologue → lean iteration → five-number epilogue (coflux_lean.hpp) ----
+                LeanCell c;
+                double So;
+                {
+                    const int idx = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
+                    const int jj = row_of(idx, wx, wx_rcp);
+                    const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+                    SolverArgsPtr Kb = opaque(K);
+                    const double* __restrict__ Ou = Kb->O.u;
+                    const double* __restrict__ Ov = Kb->O.v;
+                    const double uo = 0.5 * (Ou[k] + Ou[k + 1]);
+                    const double vo = 0.5 * (Ov[k] + Ov[k + (size_t)G.sj]);
+                    So = Kb->O.S[k];
+                    c = lean_prologue(P, L.kappa, tab, Kb->E.u[k], Kb->E.v[k], Kb->E.T[k], Kb->E.p[k], Kb->E.q[k], uo, vo, Kb->O.T[k], So);
+                    // the interface temperature does not depend on the iteration: written now, not carried across it
+                    if constexpr (!FUSE_NET) {
+                        if (in_range) Kb->F.Ts[k] = c.Ts - T_offset;
+                    }
+                }
+                const Scales s = mo_iterate_lean<COARE>(L, c, tab, in_range);
+                if (in_range) {
+                    SolverArgsPtr Ke = opaque(K);
+                    const int idx2 = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
+                    const int jj2 = row_of(idx2, wx, wx_rcp);
+                    const int ci = idx2 - jj2 * wx - G.ring, cj = jj2 - G.ring;
+                    const size_t k = cell_index(G, ci, cj);
+                    const CellFluxes R = lean_epilogue(c, T_offset, s);
+                    {
+                        const FluxOut F = kread(&Ke->F);
+                        F.Qc[k] = R.Qc;
+                        F.Qv[k] = R.Qv;
+                        F.Fv[k] = R.Fv;
+                        F.tx[k] = R.rho_tau_x;
+                        F.ty[k] = R.rho_tau_y;
+                        if constexpr (FUSE_NET) F.Ts[k] = R.Ts_ocean;
+                        if (F.ustar) F.ustar[k] = R.ustar;
+                        if (F.tstar) F.tstar[k] = R.tstar;
+                        if (F.qstar) F.qstar[k] = R.qstar;
+                        if (F.iters) F.iters[k] = R.iterations;
+                    }
+                    if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.work, 255);
+                    if constexpr (FUSE_NET) {
+                        if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {
+                            const IceIn I = kread(&Ke->I);
+                            const NetOut N = kread(&Ke->N);
+                            store_net_cell(N, k, net_cell_local(P, P.albedo, I.conc ? I.conc[k] : 0.0, So, R.Ts_ocean + P.T_offset,
+                                                                Ke->E.Mp[k], Ke->E.Qs[k], Ke->E.Ql[k], R.Qc, R.Qv, R.Fv,
+                                                                I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0, I.land ? I.land[k] : 0.0));
+                        }
+                    }
+                }
+                continue;
+            }
             CellConsts c;
             double So;
             {
@@ -870,7 +930,10 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
                                st, A);                                                                                            \
         }                                                                                                                         \
     } while (0)
-    switch (C.specialization) {
+    int spec = C.specialization;
+    if (spec == SOLVER_OCEAN_LEAN && L.solver == CF_SOLVER_TABLES_R2) spec = SOLVER_OCEAN;  // last round's iteration body (A/B)
+    switch (spec) {
+        case SOLVER_OCEAN_LEAN: CF_LAUNCH(COARE, SOLVER_OCEAN_LEAN); break;
         case SOLVER_OCEAN: CF_LAUNCH(COARE, SOLVER_OCEAN); break;
         case SOLVER_ICE: CF_LAUNCH(COARE, SOLVER_ICE); break;
         case SOLVER_LY: CF_LAUNCH(true, SOLVER_LY); break;

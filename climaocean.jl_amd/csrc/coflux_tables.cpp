@@ -3,12 +3,11 @@
 // The Monin–Obukhov iteration spends its time in ψ_m(ζ), ψ_h(ζ) and log().  On CDNA4 an FP64
 // libm call costs 40–120 instructions (double-double arithmetic), and the stability functions
 // need 3 log + 2 atan + cbrt + 2 sqrt each.  Instead, every ψ is tabulated once per context as
-// piecewise degree-9 polynomials in  x = 1 + 16|ζ|  (every binade of x ∈ [1, 2^34) cut into 4 equal
-// pieces ⇒ 136 segments, |ζ| ≤ 1.07e9; one table per sign of ζ), which reproduces the analytic functions
-// to ≤ 3e-14 relative to max(|ψ|, 1) — five orders below the 1e-9 parity tolerance.  The segment index is
-// the exponent and the two top mantissa bits of x and the polynomial variable is u = x − (segment start)
-// (an exact subtraction), so an evaluation costs ≈ 10 integer/FP64 instructions + 10 LDS reads + 9 FMAs and
-// no logarithm.  Both signs share one instruction stream, so waves that mix stable and unstable cells no
+// piecewise degree-6 polynomials in  x = 1 + 16|ζ|  (two tiers, coflux_tables.h: eight pieces per binade
+// below x = 2^14, one per binade up to 2^34; one table per sign of ζ), which reproduces the analytic functions
+// to ≤ 3.3e-12 relative to max(|ψ|, 1) wherever the iteration can stop.  The segment index is the exponent and the
+// three top mantissa bits of x and the polynomial variable is u = x − (segment start) (an exact subtraction),
+// so an evaluation costs ≈ 10 integer/FP64 instructions + 7 LDS reads + 6 FMAs per function and no logarithm.  Both signs share one instruction stream, so waves that mix stable and unstable cells no
 // longer execute both branches.
 //
 // log() itself uses a 128-entry (1/c, log c) table on the mantissa.
@@ -150,8 +149,8 @@ std::vector<double> build_solver_tables(int stability_kind) {
         const bool scalar = tau >= 2, unstable = (tau % 2) == 0;
         for (int k = 0; k < PSI_SEG; ++k) {
             double coef[PSI_DEG + 1];
-            const long double width = ldexpl(1.0L, k / PSI_SUB) / PSI_SUB;                  // Δ of the segment
-            const long double x0 = ldexpl(1.0L, k / PSI_SUB) + (k % PSI_SUB) * width;       // its start
+            long double width, x0;  // Δ of the segment, its start
+            psi_segment(k, &x0, &width);
             auto f = [&](long double tt) {
                 long double az = (x0 - 1.0L + 0.5L * (tt + 1.0L) * width) / (long double)PSI_A;
                 return scalar ? psi_h_exact(stability_kind, unstable, az) : psi_m_exact(stability_kind, unstable, az);

@@ -343,6 +343,7 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                      bits, tested); 0: iterate to maxiter */
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path, LDS-tabulated ψ/log, ≤1e-12 of libm */
 #define CF_SOLVER_LIBM 1    /* same iteration on ocml's libm (slow; cross-check)                     */
+#define CF_SOLVER_TABLES_R2 2 /* CF_SOLVER_TABLES with round 2's body of the ocean iteration (A/B measurements) */
 int cf_set_option(cf_ctx* ctx, int option, int value);
 /* Self-test hook: y[k] = f(x[k]) with the device primitives the solver uses
  * (f: 0 log, 1 exp, 2 cbrt, 3 sqrt, 4 1/x, 5 ψ_m(ζ), 6 ψ_h(ζ)); d_x, d_y device pointers.        */

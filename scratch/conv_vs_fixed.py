@@ -1,0 +1,37 @@
+"""Convergence-mode kernel time beside FixedIterations(n) on the same box/context (scratch): is the stop rule's
+kernel as fast as a fixed-count kernel of the same mean batch length?  env SOLVER, HINTS."""
+import sys, os, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "climaocean.jl_amd"))
+import numpy as np, torch
+from coflux import abi, synthetic as syn, interface_computations as ic
+from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, FluxContext
+nx, ny, h = 1440, 560, 7
+ocean_np = syn.ocean_state(nx, ny, h, h); src_np = syn.jra55_snapshots(2)
+fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "default"
+mk = {"default": ic.SimilarityTheoryFluxes, "corrected": ic.corrected_atmosphere_ocean_fluxes}[cfg]
+res = {}
+ctx = None
+for n in (-1, 10, 12, 13, 14, 16, -1):
+    fl = mk()
+    if n >= 0: fl.solver_stop_criteria = ic.FixedIterations(n)
+    P = ic.flux_params(fl)
+    if ctx is None:
+        ctx = FluxContext(nx, ny, h, h, P)
+        ocean = {k: ctx.to_device(ocean_np[k]) for k in ("T", "S", "u", "v", "mask")}
+        src = {k: ctx.to_device(v) for k, v in src_np.items()}
+        w = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj), latitude=ctx.to_device(phi))
+        atmos = ctx.field_set(EXCHANGE_NAMES); fluxes = ctx.field_set(FLUX_NAMES); fluxes["iterations"] = ctx.zeros(torch.int32)
+        ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
+    else:
+        ctx.set_flux_params(P)
+    if os.environ.get("SOLVER"): ctx.set_option(abi.OPT_SOLVER, int(os.environ["SOLVER"]))
+    if os.environ.get("HINTS"): ctx.set_option(abi.OPT_TRIP_HINTS, int(os.environ["HINTS"]))
+    for _ in range(3): ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
+    t = round(min(ctx.time_stage(abi.STAGE_AO_FLUXES, 50, ocean=ocean, atmos=atmos, fluxes=fluxes) for _ in range(3)) * 1e3, 1)
+    its = fluxes["iterations"].cpu().numpy()
+    wet = its > 0
+    res["conv" if n < 0 else n] = (t, round(float(its[wet].mean()), 2) if wet.any() else 0)
+    print(cfg, "n =", n, "time", t, "us; mean trip", res["conv" if n < 0 else n][1], flush=True)
+ctx.close()

@@ -11,7 +11,7 @@ fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h)
 for name, mk in (("default", lambda: ic.SimilarityTheoryFluxes()), ("corrected", ic.corrected_atmosphere_ocean_fluxes)):
     res = {}
     ctx = None
-    for n in (0, 1, 4, 8, 16, 32):
+    for n in (0, 1, 2, 3, 4, 8, 16, 32):
         fl = mk(); fl.solver_stop_criteria = ic.FixedIterations(n)
         P = ic.flux_params(fl)
         if ctx is None:
@@ -23,6 +23,7 @@ for name, mk in (("default", lambda: ic.SimilarityTheoryFluxes()), ("corrected",
             ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
         else:
             ctx.set_flux_params(P)
+        if os.environ.get("SOLVER"): ctx.set_option(abi.OPT_SOLVER, int(os.environ["SOLVER"]))
         if os.environ.get("HINTS"): ctx.set_option(abi.OPT_TRIP_HINTS, int(os.environ["HINTS"]))
         res[n] = round(min(ctx.time_stage(abi.STAGE_AO_FLUXES, 20, ocean=ocean, atmos=atmos, fluxes=fluxes) for _ in range(3)) * 1e3, 1)
     print(name, json.dumps(res))

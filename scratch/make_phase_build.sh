@@ -12,7 +12,7 @@ def rep(old, new):
     s = s.replace(old, new, 1)
 rep("namespace coflux {\n", "namespace coflux {\n__device__ unsigned long long g_stamp[4096 * 8];\n#define STAMP(q) do { if (lane == 0) g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + (q)] = __builtin_readcyclecounter(); } while (0)\n")
 rep("    const int tid = threadIdx.x, lane = tid & 63;\n    const int wx = G.nx + 2 * G.ring;\n", "    const int tid = threadIdx.x, lane = tid & 63;\n    STAMP(0);\n    const int wx = G.nx + 2 * G.ring;\n")
-rep("    constexpr int PER_THREAD = AO_CHUNK / AO_BLOCK;\n    constexpr int LAND_UNROLL = 8;", "    STAMP(4);\n    constexpr int PER_THREAD = AO_CHUNK / AO_BLOCK;\n    constexpr int LAND_UNROLL = 8;")
+rep("    constexpr int PER_THREAD = CHUNK / BLOCK;\n    constexpr int LAND_UNROLL = 8;", "    STAMP(4);\n    constexpr int PER_THREAD = CHUNK / BLOCK;\n    constexpr int LAND_UNROLL = 8;")
 rep("    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only", "    STAMP(5);\n    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only")
 rep("    const DevParams& P = *lp;  // prologue-only parameters live in LDS", "    STAMP(1);\n    const DevParams& P = *lp;  // prologue-only parameters live in LDS")
 rep("        // ---- waves pull 64 wet cells at a time", "        STAMP(2);\n        if (lane == 0) g_stamp[((size_t)blockIdx.x * 4 + (tid >> 6)) * 8 + 7] = ((unsigned long long)(end - begin) << 32) | (unsigned)nwet;\n        // ---- waves pull 64 wet cells at a time")
