@@ -354,7 +354,7 @@ def main():
     # ---- per-kernel times: a SEPARATE, event-bracketed pass over the same schedule (the event records between
     # dependent kernels cost stream time, so they stay out of the region `value` is measured on) ------------------
     def instrumented(n, hints):
-        ctx.set_option(abi.OPT_TRIP_HINTS, 1 if hints else 0)
+        ctx.set_option(abi.OPT_TRIP_HINTS, hints)
         run_steps(best, sched, next_step, 4)                      # settle (and rebuild hints) after the switch
         ctx.set_option(abi.OPT_PROFILE_STRIDE, 1)
         ctx.profile_enable(n)
@@ -364,9 +364,11 @@ def main():
         return out
 
     n_prof = min(max(steps, 20), 200)
-    prof = instrumented(n_prof, True) if a.config == "ocean" and best != "torch" else None
-    prof_nohint = instrumented(n_prof, False) if prof else None
-    ctx.set_option(abi.OPT_TRIP_HINTS, 1)
+    # CF_OPT_TRIP_HINTS: 2 = the library's default (what the timed region ran), 1 = every solver orders its batches by
+    # the previous call's trip counts (round 2's default; reported beside it)
+    prof = instrumented(n_prof, 2) if a.config == "ocean" and best != "torch" else None
+    prof_sorted = instrumented(n_prof, 1) if prof else None
+    ctx.set_option(abi.OPT_TRIP_HINTS, 2)
 
     if rank == 0:
         kw = dict(src=src, weights=w, ocean=states[0], atmos=atmos_sets[0], fluxes=fl, net=net, time_fraction=0.37)
@@ -426,7 +428,7 @@ def main():
                    roofline=roof("ao_flux_fast_kernel (compute_atmosphere_ocean_fluxes!)", BYTES_AO, cells_rank, ao_ms,
                                  launches_timed=nrec,
                                  measured="HIP events around the kernel inside a separate event-bracketed pass over the timed schedule",
-                                 avg_launch_ms_without_hints=prof_nohint[1][0] if prof_nohint else None,
+                                 avg_launch_ms_batches_sorted_by_trip_hints=prof_sorted[1][0] if prof_sorted else None,
                                  avg_launch_ms_back_to_back_same_inputs=ao_ms_alone),
                    roofline_interpolate=roof("interpolate_kernel (interpolate_atmosphere_state!)", BYTES_INTERP, cells_rank, interp_ms),
                    roofline_net_fluxes=roof("net_flux_kernel (compute_net_ocean_fluxes!)", BYTES_NET, nx * ny, net_ms),

@@ -221,10 +221,15 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
             (void)hipFree(ctx->d_wet_pos);
             (void)hipFree(ctx->d_trip);
             (void)hipFree(ctx->d_trip_ice);
-            ctx->d_wet_pos = nullptr;
+            (void)hipFree(ctx->d_lean_sorted);
+            (void)hipFree(ctx->d_lean_info);
+            ctx->d_wet_pos = ctx->d_lean_sorted = nullptr;
+            ctx->d_lean_info = nullptr;
             ctx->d_trip = ctx->d_trip_ice = nullptr;
             ctx->wet_list_entries = 0;
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wet_pos, sizeof(uint32_t) * want));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lean_sorted, sizeof(uint32_t) * want));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lean_info, sizeof(int) * 4 * (size_t)chunk_table_capacity(ncells)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trip, want));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trip_ice, want));
             ctx->wet_list_entries = want;
@@ -242,6 +247,12 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
     HIP_TRY(ctx, build_wet_lists(ctx->stream, ctx->d_params, ctx->grid, mask, n, wide != 0, ctx->d_chunk_begins, ctx->d_wet_pos,
                                  ctx->d_trip, ctx->d_chunk_meta, &overflow));
     ctx->launch.d_wet_pos = overflow ? nullptr : ctx->d_wet_pos;
+    // the lean ocean kernel's lists: the static lists in index order until the first call has run
+    ctx->launch.d_lean_sorted = nullptr;
+    ctx->launch.d_lean_info = nullptr;
+    if (!overflow) HIP_TRY(ctx, build_lean_lists(ctx->stream, n, wide != 0, ctx->d_wet_pos, ctx->d_chunk_begins, ctx->d_lean_sorted, ctx->d_lean_info));
+    ctx->launch.d_lean_sorted = ctx->d_lean_sorted;
+    ctx->launch.d_lean_info = ctx->d_lean_info;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_trip_ice, 0, (size_t)n * wet_list_stride(wide != 0), ctx->stream));
     ctx->launch.d_trip = ctx->trip_hints ? ctx->d_trip : nullptr;
     if (std::getenv("COFLUX_DEBUG"))
@@ -437,6 +448,8 @@ int cf_destroy(cf_ctx* ctx) {
     if (ctx->d_trip) (void)hipFree(ctx->d_trip);
     if (ctx->d_trip_ice) (void)hipFree(ctx->d_trip_ice);
     if (ctx->d_wet_pos) (void)hipFree(ctx->d_wet_pos);
+    if (ctx->d_lean_sorted) (void)hipFree(ctx->d_lean_sorted);
+    if (ctx->d_lean_info) (void)hipFree(ctx->d_lean_info);
     if (ctx->d_chunk_sums) (void)hipFree(ctx->d_chunk_sums);
     if (ctx->d_chunk_begins) (void)hipFree(ctx->d_chunk_begins);
     if (ctx->d_chunk_meta) (void)hipFree(ctx->d_chunk_meta);
@@ -464,7 +477,7 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     switch (option) {
         case CF_OPT_SOLVER:
-            if (value != CF_SOLVER_TABLES && value != CF_SOLVER_LIBM && value != CF_SOLVER_TABLES_R2) return fail(ctx, CF_ERR_INVALID, "unknown solver %d", value);
+            if (value != CF_SOLVER_TABLES && value != CF_SOLVER_LIBM && value != CF_SOLVER_TABLES_R2 && value != CF_SOLVER_TABLES_R2_OUTER) return fail(ctx, CF_ERR_INVALID, "unknown solver %d", value);
             ctx->launch.solver = value;
             return CF_OK;
         case CF_OPT_INTERP_TILE_CAP:
@@ -477,8 +490,12 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->launch.max_blocks = value;
             return CF_OK;
         case CF_OPT_TRIP_HINTS:
+            if (value < 0 || value > 2) return fail(ctx, CF_ERR_INVALID, "trip hints %d: 0 (off), 1 (on), 2 (automatic)", value);
+            if (ctx->lean_hints && value != 1) ctx->chunk_valid = false;  // the lean kernel's lists go back to index order
             ctx->trip_hints = value != 0;
+            ctx->lean_hints = value == 1;
             ctx->launch.d_trip = ctx->trip_hints ? ctx->d_trip : nullptr;
+            ctx->launch.lean_hints = ctx->lean_hints ? 1 : 0;
             return CF_OK;
         case CF_OPT_FUSED_NET:
             ctx->fused_net = value != 0;

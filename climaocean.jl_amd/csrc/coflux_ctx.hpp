@@ -49,7 +49,10 @@ struct cf_ctx {
     LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, 0, 256, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0};
     uint8_t* d_trip = nullptr;       // trip count of the previous call per wet-list entry
     uint32_t* d_wet_pos = nullptr;   // static wet lists of the solver's chunks
+    uint32_t* d_lean_sorted = nullptr;  // the lean ocean kernel's sorted lists (same capacity as d_wet_pos)
+    int* d_lean_info = nullptr;         // per chunk: listed wet cells + fingerprint (4 ints)
     bool trip_hints = true;
+    bool lean_hints = false;         // the lean ocean kernel sorts its lists by trip count only when CF_OPT_TRIP_HINTS = 1
     bool fused_net = false;          // cf_update_state: net fluxes in the solver's epilogue + a stress kernel (measured slower: off)
     // cost-balanced chunk table of the solver, rebuilt when the wet mask (pointer / kind / surface z) changes
     int* d_chunk_sums = nullptr;

@@ -23,6 +23,9 @@ struct LaunchCfg {
     int n_chunks;
     const uint32_t* d_wet_pos;  // static wet lists of the chunks, fixed stride (coflux_solver.hip), or NULL
     int ao_wide;                // 1: the chunk table was built for the wide geometry (one 768-thread workgroup per CU)
+    uint32_t* d_lean_sorted;    // the lean ocean kernel's lists: every chunk's wet cells ordered by last call's trip counts (coflux_solver_lean.hip)
+    const int* d_lean_info;     // per chunk: wet cells listed, fingerprint of the wet set (x, y), 0
+    int lean_hints;             // 1: the lean ocean kernel re-orders its lists by trip count at the end of every call
 };
 
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
@@ -35,6 +38,9 @@ hipError_t launch_net_stress(hipStream_t st, const DevParams& P, const GridDesc&
                              const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* n);
 hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks, bool wide,
                            const int* d_begins, uint32_t* d_wet_pos, uint8_t* d_trip, int* d_scratch, int* overflow_out);
+hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32_t* d_wet_pos, const int* d_begins, uint32_t* d_sorted, int* d_info);
+hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
+                                 const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f);
 size_t wet_list_capacity(int ncells);
 int wet_list_stride(bool wide);
 hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,

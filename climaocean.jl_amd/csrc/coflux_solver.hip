@@ -8,14 +8,11 @@
 // device's resident-workgroup slots in whole rounds.
 #include <hip/hip_runtime.h>
 
-#include "coflux_fast.hpp"
+#include "coflux_solver_shared.hpp"
 #include "coflux_lean.hpp"
-#include "coflux_kernel_types.hpp"
-#include "coflux_kernels.h"
 
 namespace coflux {
 
-constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 #ifndef CF_LEAN_WAVES
 #define CF_LEAN_WAVES 3  // waves per SIMD the lean ocean solver is compiled for
 #endif
@@ -24,10 +21,6 @@ constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 // chunks of ≤ 1280 wet cells in arrival layers — the only choice for a surface too small to give every CU a big chunk.
 // WIDE (CF_OPT_AO_CHUNK = 3072; measured 3 % slower, see build_chunk_table): 768 threads, ONE workgroup per CU: twelve
 // waves of the same age pull batches from both ends of one queue, one copy of the tables per CU, ≈ 100 KB of LDS free.
-constexpr int AO_BLOCK = 256;
-constexpr int AO_CHUNK = 1280;  // capacity of a narrow workgroup's wet-cell list = the most wet cells a chunk can hold
-constexpr int AO_BLOCK_WIDE = 768;
-constexpr int AO_CHUNK_WIDE = 3072;
 int wet_list_stride(bool wide);
 template <int BLOCK>
 struct Geom {
@@ -39,7 +32,6 @@ struct Geom {
 static_assert(Geom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
 constexpr int AO_LAYER_1 = 1280, AO_LAYER_2 = 512, AO_LAYER_3 = 512;  // wet cells per chunk of the last three arrival layers (plan_chunk_rounds)
 static_assert(AO_LAYER_1 <= AO_CHUNK && AO_LAYER_1 >= AO_LAYER_2 && AO_LAYER_2 >= AO_LAYER_3, "layer sizes");
-constexpr int AO_BINS = 64;    // trip-count bins of the per-chunk counting sort (one wave scans them)
 static_assert(AO_BINS == 64, "Geom<>::PARAMS_OFFSET spells the bin count out");
 static_assert(Geom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow solver workgroups must fit the CU's 160 KB of LDS");
 
@@ -58,7 +50,6 @@ static_assert(Geom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow solver workgroup
 // the list against the mask as it is on every call and falls back to classifying its range (in pieces, if a range
 // holds more wet cells than the list) when a mask changed in place — a stale table can cost time, never correctness.
 // ---------------------------------------------------------------------------------------------
-constexpr int AO_WET_COST = 64;
 constexpr int AO_MAX_ROUNDS = 8;
 constexpr int AO_PLAN_WIDE = -1;  // plan_chunk_rounds: the wide geometry's plan
 struct ChunkRounds {  // round r covers cost prefixes [base[r], base[r+1]) in chunks of cost[r], ids from first[r]
@@ -311,113 +302,6 @@ hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const Grid
 int wet_list_stride(bool wide) { return wide ? AO_CHUNK_WIDE : AO_CHUNK; }
 size_t wet_list_capacity(int ncells) { return (size_t)chunk_table_capacity(ncells) * AO_CHUNK; }  // (≥ any wide table's need: fewer, 2.4× longer lists)
 
-// zero_interface_state of a land cell: all fluxes 0, T = 0 K (and, in the fused path, zero net fluxes inside the interior)
-template <bool FUSE_NET>
-__device__ __forceinline__ void zero_cell(const LoopParams& L, double T_offset, const GridDesc& G, const FluxOut& F,
-                                          const NetOut& N, size_t k, int i, int j) {
-    CellFluxes Z{};
-    Z.Ts_ocean = -T_offset;
-    Z.iterations = L.fixed ? L.maxiter : 0;
-    store_fluxes(F, k, Z);
-    if constexpr (FUSE_NET) {
-        if (i >= 0 && i < G.nx && j >= 0 && j < G.ny) store_net_cell(N, k, NetCell{});
-    }
-}
-
-// ---- production solver: LDS tables, one workgroup per chunk of the table above -----------------
-// LDS: tables | list (cell offset + list entry per sorted position) | counters, histogram, bin cursors | DevParams
-// A list word: the cell's offset from the start of the chunk's range (20 bits: a range costs at most AO_CHUNK_WIDE wet
-// cells' worth of AO_WET_COST = 196 608 cells if it were all land) and its entry in the static list (12 bits).
-constexpr int AO_LIST_OFFSET_BITS = 20;
-static_assert(AO_CHUNK_WIDE <= (1 << (32 - AO_LIST_OFFSET_BITS)), "list entry index must fit the upper bits");
-static_assert((long)AO_CHUNK_WIDE * AO_WET_COST < (1L << AO_LIST_OFFSET_BITS), "a chunk's range must fit the lower bits");
-
-struct WetLists {
-    const uint32_t* pos;    // wet cells of chunk c in index order at [c·AO_CHUNK, …), 0xffffffff-padded; nullptr: classify per call
-    uint8_t* trip;          // iteration count of the previous call per list entry (scheduling hint), or nullptr
-};
-
-// Everything the kernel is handed, as ONE by-value argument: the kernarg segment then IS this struct, and the
-// kernel reads its ≈ 40 pointers from there with scalar loads where it uses them (through a pointer the compiler
-// cannot see through, so that it reloads them per batch instead of hoisting 80 SGPRs' worth out of the loops and
-// spilling them into VGPR lanes — 185 SGPR spills and ≈ 300 v_readlane per batch were measured that way).  Only
-// the iteration's scalars (LoopParams) are copied into registers for the kernel's lifetime.
-struct SolverArgs {
-    LoopParams L;
-    GridDesc G;
-    OceanIn O;
-    Exchange E;
-    FluxOut F;
-    const double* g_tab;
-    const DevParams* g_params;
-    WetLists W;
-    const int* chunk_begins;
-    IceIn I;
-    NetOut N;
-    IceStateIn S;   // SOLVER_SEAICE only
-    IceParams Ice;
-    double z_surface;    // with mask_kind: how the start phase reads wetness before the parameter block is in LDS
-    long long mask_kind;
-    double T_offset;     // (zero_interface_state writes −T_offset; same reason)
-    unsigned long long wx_reciprocal;  // floor(2³² / (nx + 2·ring)), see row_of
-};
-typedef const SolverArgs __attribute__((address_space(4)))* SolverArgsPtr;
-
-// by-value copy of a member of the kernarg struct: scalar loads of its 8-byte words
-template <class T>
-__device__ __forceinline__ T kread(const __attribute__((address_space(4))) T* p) {
-    static_assert(sizeof(T) % 8 == 0, "argument bundles are made of 8-byte words");
-    T v;
-    const __attribute__((address_space(4))) unsigned long long* src = (const __attribute__((address_space(4))) unsigned long long*)p;
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&v);
-#pragma unroll
-    for (size_t n = 0; n < sizeof(T) / 8; ++n) dst[n] = src[n];
-    return v;
-}
-
-__device__ __forceinline__ SolverArgsPtr opaque(SolverArgsPtr p) {
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-// row of a window-linear cell index: idx / wx through the host's floor(2³² / wx) — five instructions where the
-// compiler's 32-bit division is ≈ 20, and the kernel does it for every mask word of the start phase and twice per batch.
-// The product underestimates the quotient by at most one for idx < 2²⁶ (67 M cells).
-__device__ __forceinline__ int row_of(int idx, int wx, unsigned wx_reciprocal) {
-    int q = (int)__umulhi((unsigned)idx, wx_reciprocal);
-    return idx - q * wx >= wx ? q + 1 : q;
-}
-
-// The scheduling hint of a cell: its work in this call, or the previous hint minus one if that is larger.  A cell
-// that ran long once keeps a long hint for a while (it decays by one per call) and is scheduled among the first batches
-// of its workgroup; hinted short and running long it would sit in a LATE batch and hold the workgroup — and with it the
-// kernel — for its whole iteration alone (the sea-ice solve with its hints a step old: 386 → 300 µs; a cell that flips
-// between 35 and 100 iterations from one step to the next is all it takes).  An over-hinted lane merely idles.
-// Sea ice only: the ocean's counts move by ±1, there the read-modify-write costs more than the bias saves (+0.5 %).
-__device__ __forceinline__ void store_hint(uint8_t* hint, int work) {
-    const int old = *hint;
-    *hint = (uint8_t)min(max(work, old - 1), 255);
-}
-
-// Sort bin of a trip count: one bin per count below 56 (the ocean needs 8–20 iterations, most sea-ice cells 10–40),
-// eight-count bins above (the sea-ice iteration's orbit cells stop anywhere up to maxiter = 100).
-__device__ __forceinline__ int trip_bin(int t) { return t < 56 ? t : min(56 + ((t - 56) >> 3), AO_BINS - 1); }
-
-// (a one-cell-wide window: 2³² does not fit the 32-bit operand; 2³² − 1 gives q = idx − 1 and the correction step adds the one)
-static unsigned long long row_reciprocal(int wx) { return wx <= 1 ? 0xffffffffull : 0x100000000ull / (unsigned long long)wx; }
-
-// two independent 32-bit mixes of a cell's linear index (murmur3's finaliser): XOR-accumulated over a set of cells
-// they make a 64-bit fingerprint of the set
-__device__ __forceinline__ unsigned mix32(unsigned h) {
-    h ^= h >> 16;
-    h *= 0x85ebca6bu;
-    h ^= h >> 13;
-    h *= 0xc2b2ae35u;
-    h ^= h >> 16;
-    return h;
-}
-__device__ __forceinline__ unsigned cell_hash_lo(unsigned idx) { return mix32(idx + 0x9e3779b9u); }
-__device__ __forceinline__ unsigned cell_hash_hi(unsigned idx) { return mix32(idx * 0x01000193u ^ 0x7f4a7c15u); }
 
 // (second launch bound = waves per SIMD: the lean ocean iteration fits 128 VGPRs — four narrow workgroups per CU, whose
 // LDS, tables included, is 39 KB each; everything else keeps three)
@@ -949,6 +833,9 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
                             const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net,
                             const double* land) {
     if (L.solver == CF_SOLVER_LIBM) return net ? hipErrorInvalidValue : launch_ao_fluxes_libm(st, P, G, o, e, f);
+    // the production ocean configurations on narrow workgroups, net fluxes as their own launch: the round-3 kernel
+    if (C.specialization == SOLVER_OCEAN_LEAN && L.solver == CF_SOLVER_TABLES && !net && L.d_lean_info)
+        return launch_ao_fluxes_lean(st, L, P, C, G, o, e, f);
     OceanIn O = make_ocean(o);
     Exchange E = make_exchange(e);
     FluxOut F = make_fluxes(f);

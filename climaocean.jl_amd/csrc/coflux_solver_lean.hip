@@ -1,0 +1,479 @@
+// coflux_solver_lean.hip — compute_atmosphere_ocean_fluxes! for the production ocean configurations
+// (SOLVER_OCEAN_LEAN: SimilarityTheoryFluxes with Charnock-type momentum roughness and Reynolds-scaled scalars,
+// omip_simulation.jl:40-49 and the defaults of README.md:75), round-3 kernel.
+//
+// What it keeps from coflux_solver.hip: one 256-thread workgroup per chunk of the cost-balanced chunk table, the ψ /
+// log tables and the parameter block staged in LDS by LDS-DMA, land compacted away, batches of 64 wet cells whose
+// trip counts were equal last call, waves leaving the iteration together on a wave64 ballot, a mask rewritten in place
+// detected by a fingerprint of the chunk's wet set (a stale list costs time, never correctness).
+//
+// What is new (profiles/r03_experiments.md):
+//   * the iteration, its prologue and its epilogue are coflux_lean.hpp's (−17 % VALU instructions per launch);
+//   * the start phase no longer sorts.  Round 2 loaded every chunk's static list and hint bytes, counting-sorted them
+//     in LDS (two atomic passes, a scan, three barriers) and hashed every listed cell to validate the list: ≈ 9 µs
+//     in which no CU of the device computes (all workgroups start together).  Now the list lives in global memory
+//     ALREADY SORTED: it goes straight into LDS by LDS-DMA beside the tables, the chunk's fingerprint is a number
+//     computed when the list was built, and one barrier separates the requests from the first batch.  The order
+//     for the NEXT call is produced at the END of the workgroup's life: every batch leaves its lanes' trip counts in
+//     LDS and bumps a 64-bin histogram; the last wave to retire scans the bins and scatters the list back to global
+//     memory — one wave's work, while the CU's other workgroups are still iterating.
+#include <hip/hip_runtime.h>
+
+#include "coflux_lean.hpp"
+#include "coflux_solver_shared.hpp"
+
+namespace coflux {
+
+// per-wave time stamps (scratch/phases_lean.py; -DCF_LEAN_STAMPS builds only): 0 entry, 1 everything requested, 2 my
+// requests have landed, 3 behind the barrier (batches begin), 4 batches done, 5 exit, 6 Σ cycles inside the iteration,
+// 7 batches taken
+#ifdef CF_LEAN_STAMPS
+__device__ unsigned long long g_lean_stamp[4096 * 8];
+#define LEAN_STAMP(q) do { if (lane == 0) g_lean_stamp[((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 8 + (q)] = __builtin_readcyclecounter(); } while (0)
+#define LEAN_STAMP_SET(q, v) do { if (lane == 0) g_lean_stamp[((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 8 + (q)] = (v); } while (0)
+extern "C" int cf_debug_phase_read(unsigned long long* out, int n) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lean_stamp), sizeof(unsigned long long) * n);
+    return 0;
+}
+#else
+#define LEAN_STAMP(q) do { } while (0)
+#define LEAN_STAMP_SET(q, v) do { } while (0)
+#endif
+
+struct LeanArgs {
+    LoopParams L;
+    GridDesc G;
+    OceanIn O;
+    Exchange E;
+    FluxOut F;
+    const double* g_tab;
+    const DevParams* g_params;
+    uint32_t* sorted;         // [chunk·AO_CHUNK + p]: offset of the p-th cell (longest trip count first) in the chunk's range; 0xffffffff-padded
+    const int* info;          // [chunk·4]: wet cells listed, fingerprint x, fingerprint y, 0
+    const int* chunk_begins;
+    double z_surface;         // with mask_kind: how the start phase reads wetness before the parameter block is in LDS
+    long long mask_kind;
+    double T_offset;
+    unsigned long long wx_reciprocal;
+    long long sort_enabled;   // CF_OPT_TRIP_HINTS
+};
+typedef const LeanArgs __attribute__((address_space(4)))* LeanArgsPtr;
+
+__device__ __forceinline__ LeanArgsPtr opaque(LeanArgsPtr p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// Fingerprint of a set of cells (window-linear indices): XOR of a 32-bit mix and a wrapping sum of a multiple.
+// Only a staleness detector for a mask rewritten in place — six instructions per cell, not a hash against adversaries.
+__device__ __forceinline__ unsigned lean_mix(unsigned idx) { return (idx * 0x9e3779b1u) ^ ((idx * 0x85ebca6bu) >> 15); }
+__device__ __forceinline__ unsigned lean_sum(unsigned idx) { return idx * 0xc2b2ae35u + 0x27d4eb2fu; }
+
+// LDS: tables | list (sorted cell offsets; a batch's epilogue leaves this call's trip count in the top byte of its
+// entries) | histogram | cursors | counters | per-wave fingerprints | DevParams.  Narrow geometry: 52.4 KB — a
+// workgroup may use at most 53 760 B for three to fit a CU (the allocation granule eats the rest of 160 KB / 3).
+constexpr int LEAN_LIST_OFFSET = TABLE_BYTES;
+constexpr int LEAN_OFFSET_BITS = 24;
+constexpr unsigned LEAN_OFFSET_MASK = (1u << LEAN_OFFSET_BITS) - 1u;
+static_assert((long)AO_CHUNK_WIDE * AO_WET_COST < (1L << LEAN_OFFSET_BITS), "a chunk's range must fit the offset bits");
+template <int BLOCK>
+struct LeanGeom {
+    static constexpr int CHUNK = BLOCK == AO_BLOCK ? AO_CHUNK : AO_CHUNK_WIDE;
+    static constexpr int WAVES = BLOCK / 64;
+    static constexpr int HIST_OFFSET = LEAN_LIST_OFFSET + CHUNK * 4;
+    static constexpr int CURSOR_OFFSET = HIST_OFFSET + AO_BINS * 4;
+    static constexpr int COUNTERS_OFFSET = CURSOR_OFFSET + AO_BINS * 4;  // [0] batch cursor, [2] wet count of the classification path
+    static constexpr int WAVEHASH_OFFSET = COUNTERS_OFFSET + 16;
+    static constexpr int PARAMS_OFFSET = WAVEHASH_OFFSET + WAVES * 8;
+    static constexpr int LDS_BYTES = PARAMS_OFFSET + (int)sizeof(DevParams);
+    static_assert(PARAMS_OFFSET % 16 == 0 && LEAN_LIST_OFFSET % 1024 == 0 && (CHUNK * 4) % 1024 == 0, "LDS-DMA pieces");
+};
+static_assert(LeanGeom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow lean solver workgroups must fit the CU's 160 KB of LDS");
+static_assert(LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
+
+__device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_offset, const FluxOut& F, size_t k) {
+    CellFluxes Z{};
+    Z.Ts_ocean = -T_offset;
+    Z.iterations = L.fixed ? L.maxiter : 0;
+    store_fluxes(F, k, Z);
+}
+
+template <bool COARE, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_name) {
+    using Geo = LeanGeom<BLOCK>;
+    constexpr int CHUNK = Geo::CHUNK;
+    LeanArgsPtr K = opaque((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
+    const LoopParams L = kread(&K->L);
+    const GridDesc G = kread(&K->G);
+    const double* __restrict__ g_tab = K->g_tab;
+    const DevParams* __restrict__ g_params = K->g_params;
+    const void* mask = K->O.mask;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tab = reinterpret_cast<double*>(smem);
+    unsigned* list = reinterpret_cast<unsigned*>(smem + LEAN_LIST_OFFSET);
+    int* hist = reinterpret_cast<int*>(smem + Geo::HIST_OFFSET);
+    int* cursor = reinterpret_cast<int*>(smem + Geo::CURSOR_OFFSET);
+    int* counters = reinterpret_cast<int*>(smem + Geo::COUNTERS_OFFSET);
+    unsigned* wavehash = reinterpret_cast<unsigned*>(smem + Geo::WAVEHASH_OFFSET);
+    DevParams* lp = reinterpret_cast<DevParams*>(smem + Geo::PARAMS_OFFSET);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    LEAN_STAMP(0);
+    const int wx = G.nx + 2 * G.ring;
+    const unsigned wx_rcp = (unsigned)K->wx_reciprocal;
+    const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
+    const bool use_static = K->sorted != nullptr;
+    unsigned long long stamp_iter = 0, stamp_batches = 0, stamp_trips = 0;
+    // ---- start phase: everything is REQUESTED before anything is looked at, in straight-line code ----------------
+    // (1) LDS-DMA (global_load_lds, 1 KB per wave instruction, no VGPR round trip): the parameter block, the tables,
+    //     the chunk's sorted list; (2) the raw mask words of my share of the chunk's cell range (fingerprint, land).
+    static_assert(sizeof(DevParams) % 16 == 0 && sizeof(DevParams) <= 1024, "the parameter block is one LDS-DMA piece");
+    if (tid < (int)(sizeof(DevParams) / 16))
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g_params) + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(smem + Geo::PARAMS_OFFSET), 16, 0, 0);
+    static_assert(TABLE_BYTES % 1024 == 0, "the table stage copies whole 1 KB pieces");
+    {
+        const char* gb = reinterpret_cast<const char*>(g_tab);
+        constexpr int PIECES = TABLE_BYTES / 1024, WAVES = Geo::WAVES;
+#pragma unroll
+        for (int r = 0; r < (PIECES + WAVES - 1) / WAVES; ++r) {
+            const int c = wave + r * WAVES;
+            if (c < PIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(smem + c * 1024), 16, 0, 0);
+        }
+    }
+    if (use_static) {
+        const char* gl = reinterpret_cast<const char*>(K->sorted + (size_t)chunk * CHUNK);
+        constexpr int PIECES = CHUNK * 4 / 1024, WAVES = Geo::WAVES;
+#pragma unroll
+        for (int r = 0; r < (PIECES + WAVES - 1) / WAVES; ++r) {
+            const int c = wave + r * WAVES;
+            if (c < PIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gl + c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(smem + LEAN_LIST_OFFSET + c * 1024), 16, 0, 0);
+        }
+    }
+    constexpr int LAND_UNROLL = 8;  // strips of the range whose mask values are requested up front
+    typedef const __attribute__((address_space(1))) unsigned* GlobalWords;
+    unsigned raw_lo[LAND_UNROLL], raw_hi[LAND_UNROLL], raw_shift = 0;  // raw_shift: 2 bits per strip, the byte within its word
+    // (scalar loads through the constant address space: a vector load here would sit behind the DMA in the in-order
+    // vector-memory queue)
+    const __attribute__((address_space(4))) int* cb = (const __attribute__((address_space(4))) int*)K->chunk_begins;
+    const int range_begin = cb[chunk], range_end = cb[chunk + 1];
+    int listed = 0;
+    unsigned want_x = 0, want_y = 0;
+    if (use_static) {
+        const __attribute__((address_space(4))) int* ci = (const __attribute__((address_space(4))) int*)K->info;
+        listed = ci[chunk * 4];
+        want_x = (unsigned)ci[chunk * 4 + 1];
+        want_y = (unsigned)ci[chunk * 4 + 2];
+    }
+    const int mask_kind = (mask == nullptr) ? CF_MASK_NONE : (int)K->mask_kind;
+    const double z_surface = K->z_surface;
+    const double T_offset = K->T_offset;
+    const bool sorting = use_static && K->sort_enabled != 0;
+    {
+        const unsigned long long mbase = mask_kind == CF_MASK_NONE ? (unsigned long long)g_tab : (unsigned long long)mask;
+        const unsigned stride = mask_kind == CF_MASK_NONE ? 0u : (mask_kind == CF_MASK_U8 ? 1u : 8u);
+        const unsigned hi_step = mask_kind == CF_MASK_BOTTOM_HEIGHT ? 4u : 0u;
+#pragma unroll
+        for (int n = 0; n < LAND_UNROLL; ++n) {
+            const int ic = min(range_begin + tid + n * BLOCK, range_end - 1);
+            const int jj = row_of(ic, wx, wx_rcp);
+            const unsigned long long a = mbase + (unsigned long long)cell_index(G, ic - jj * wx - G.ring, jj - G.ring) * stride;
+            raw_shift |= ((unsigned)a & 3u) << (2 * n);
+            raw_lo[n] = *(GlobalWords)(a & ~3ull);
+            raw_hi[n] = *(GlobalWords)((a & ~3ull) + hi_step);
+        }
+    }
+    if (tid < 4) counters[tid] = 0;
+    if (tid < AO_BINS) hist[tid] = 0;
+    LEAN_STAMP(1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): my mask words and my share of the DMA have landed
+    LEAN_STAMP(2);
+#pragma unroll
+    for (int n = 0; n < LAND_UNROLL; ++n) asm volatile("" : "+v"(raw_lo[n]), "+v"(raw_hi[n]));
+    // fingerprint of the range's wet set as the mask is NOW; land gets its zeros behind the barrier
+    unsigned hx = 0, hy = 0, land = 0;
+#pragma unroll
+    for (int n = 0; n < LAND_UNROLL; ++n) {
+        const int idx = range_begin + tid + n * BLOCK;
+        const bool w = mask_kind == CF_MASK_NONE ? true
+                       : mask_kind == CF_MASK_U8 ? ((raw_lo[n] >> (8 * ((raw_shift >> (2 * n)) & 3u))) & 0xffu) != 0
+                                                 : !(z_surface <= __hiloint2double((int)raw_hi[n], (int)raw_lo[n]));
+        if (idx < range_end) {
+            if (w) {
+                hx ^= lean_mix((unsigned)idx);
+                hy += lean_sum((unsigned)idx);
+            } else {
+                land |= 1u << n;
+            }
+        }
+    }
+    // a range longer than LAND_UNROLL strips (a chunk that is mostly land): the rest the plain way, zeros at once
+    for (int idx = range_begin + tid + LAND_UNROLL * BLOCK; idx < range_end; idx += BLOCK) {
+        const int jj = row_of(idx, wx, wx_rcp);
+        const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+        const bool w = mask_kind == CF_MASK_NONE ? true
+                       : mask_kind == CF_MASK_U8 ? ((const uint8_t*)mask)[k] != 0 : !(z_surface <= ((const double*)mask)[k]);
+        if (w) {
+            hx ^= lean_mix((unsigned)idx);
+            hy += lean_sum((unsigned)idx);
+        } else {
+            const FluxOut F = kread(&opaque(K)->F);
+            lean_zero_cell(L, T_offset, F, k);
+        }
+    }
+    for (int d = 32; d; d >>= 1) {
+        hx ^= (unsigned)__shfl_xor((int)hx, d);
+        hy += (unsigned)__shfl_xor((int)hy, d);
+    }
+    if (lane == 0) {
+        wavehash[2 * wave] = hx;
+        wavehash[2 * wave + 1] = hy;
+    }
+    __syncthreads();  // the ONE barrier of the start phase: tables, parameters, list and fingerprints are in LDS
+    LEAN_STAMP(3);
+    const DevParams& P = *lp;
+    bool have_list = false;
+    int nwet = 0;
+    if (use_static) {
+        unsigned got_x = 0, got_y = 0;
+#pragma unroll
+        for (int w = 0; w < Geo::WAVES; ++w) {
+            got_x ^= wavehash[2 * w];
+            got_y += wavehash[2 * w + 1];
+        }
+        have_list = got_x == want_x && got_y == want_y;  // the list is the range's wet set
+        nwet = listed;
+    }
+    if (have_list && land) {
+        // zero_interface_state of the range's land: nothing waits for these stores but the first batch's loads
+        const FluxOut F = kread(&opaque(K)->F);
+#pragma unroll
+        for (int n = 0; n < LAND_UNROLL; ++n)
+            if (land & (1u << n)) {
+                const int idx = range_begin + tid + n * BLOCK;
+                const int jj = row_of(idx, wx, wx_rcp);
+                lean_zero_cell(L, T_offset, F, cell_index(G, idx - jj * wx - G.ring, jj - G.ring));
+            }
+    }
+    int begin = range_begin, end = range_end;
+    for (;;) {
+        if (!have_list) {
+            // ---- no (valid) sorted list: classify the piece [begin, end), zero its land (every call, unsorted) ---------
+            for (int base = begin; base < end; base += BLOCK) {
+                const int idx = base + tid;
+                bool wet = false;
+                if (idx < end) {
+                    const int jj = row_of(idx, wx, wx_rcp);
+                    const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+                    wet = cell_is_wet(P, mask, k);
+                    if (!wet) {
+                        const FluxOut F = kread(&opaque(K)->F);
+                        lean_zero_cell(L, T_offset, F, k);
+                    }
+                }
+                const unsigned long long m = __ballot(wet);
+                int wave_base = 0;
+                if (lane == 0 && m) wave_base = atomicAdd(&counters[2], __popcll(m));
+                wave_base = __shfl(wave_base, 0);
+                if (wet) {
+                    const int p = wave_base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (p < CHUNK) list[p] = (unsigned)(idx - range_begin);
+                }
+            }
+            __syncthreads();
+            nwet = counters[2];
+            if (nwet > CHUNK) {  // more wet cells than the list holds: retry on a piece that cannot overflow it
+                end = begin + CHUNK;
+                __syncthreads();
+                if (tid < 4) counters[tid] = 0;
+                __syncthreads();
+                continue;
+            }
+        }
+        // ---- waves pull 64 wet cells at a time -------------------------------------------------------------------
+        for (;;) {
+            int start = 0;
+            if (lane == 0) start = atomicAdd(&counters[0], 64);
+            start = __shfl(start, 0);
+            if (start >= nwet) break;
+            const int q = start + lane;
+            const bool in_range = q < nwet;
+            const int qc = in_range ? q : nwet - 1;
+            LeanCell c;
+            {
+                const int idx = range_begin + (int)(list[qc] & LEAN_OFFSET_MASK);
+                const int jj = row_of(idx, wx, wx_rcp);
+                const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+                LeanArgsPtr Kb = opaque(K);  // this batch's view of the arguments: pointers are (re)loaded here, scalar loads
+                // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
+                const double* __restrict__ Ou = Kb->O.u;
+                const double* __restrict__ Ov = Kb->O.v;
+                const double uo = 0.5 * (Ou[k] + Ou[k + 1]);
+                const double vo = 0.5 * (Ov[k] + Ov[k + (size_t)G.sj]);
+                c = lean_prologue(P, L.kappa, tab, Kb->E.u[k], Kb->E.v[k], Kb->E.T[k], Kb->E.p[k], Kb->E.q[k], uo, vo, Kb->O.T[k],
+                                  Kb->O.S[k]);
+                // the interface temperature does not depend on the iteration: written now, not carried across it
+                if (in_range) Kb->F.Ts[k] = c.Ts - T_offset;
+            }
+#ifdef CF_LEAN_STAMPS
+            const unsigned long long t_it = __builtin_readcyclecounter();
+#endif
+            const Scales s = mo_iterate_lean<COARE>(L, c, tab, in_range);
+#ifdef CF_LEAN_STAMPS
+            stamp_iter += __builtin_readcyclecounter() - t_it;
+            ++stamp_batches;
+            {
+                int m = in_range ? s.it : 0;
+                for (int d = 32; d; d >>= 1) m = max(m, __shfl_xor(m, d));
+                stamp_trips += (unsigned long long)m;
+            }
+#endif
+            if (in_range) {
+                LeanArgsPtr Ke = opaque(K);
+                // (cell coordinates recomputed from the list entry: cheaper than registers held across the iteration)
+                const unsigned entry = list[qc] & LEAN_OFFSET_MASK;
+                const int idx2 = range_begin + (int)entry;
+                const int jj2 = row_of(idx2, wx, wx_rcp);
+                const size_t k = cell_index(G, idx2 - jj2 * wx - G.ring, jj2 - G.ring);
+                const CellFluxes R = lean_epilogue(c, T_offset, s);
+                const FluxOut F = kread(&Ke->F);
+                F.Qc[k] = R.Qc;
+                F.Qv[k] = R.Qv;
+                F.Fv[k] = R.Fv;
+                F.tx[k] = R.rho_tau_x;
+                F.ty[k] = R.rho_tau_y;
+                if (F.ustar) F.ustar[k] = R.ustar;
+                if (F.tstar) F.tstar[k] = R.tstar;
+                if (F.qstar) F.qstar[k] = R.qstar;
+                if (F.iters) F.iters[k] = R.iterations;
+                if (sorting && have_list) {
+                    const int w = min(s.work, 255);
+                    list[q] = entry | ((unsigned)w << LEAN_OFFSET_BITS);
+                    atomicAdd(&hist[AO_BINS - 1 - trip_bin(w)], 1);
+                }
+            }
+        }
+        if (have_list || end >= range_end) break;
+        begin = end;  // classification path: the rest of the range
+        end = range_end;
+        __syncthreads();  // list and counters are reused
+        if (tid < 4) counters[tid] = 0;
+        __syncthreads();
+    }
+    LEAN_STAMP(4);
+    LEAN_STAMP_SET(6, stamp_iter | (stamp_trips << 40));
+    LEAN_STAMP_SET(7, stamp_batches | ((unsigned long long)(have_list ? 1 : 0) << 32) | ((unsigned long long)(sorting ? 1 : 0) << 33));
+    // ---- end phase: the list in next call's order (counting sort by this call's trip counts, longest first) --------
+    // Behind a barrier, by the whole workgroup: a wave that runs out of batches has nothing else to do — every
+    // workgroup of the kernel is resident from the start, no slot it could free is waited for — and the workgroup
+    // is as old as its last wave either way.
+    if (sorting && have_list) {
+        __syncthreads();
+        if (tid < AO_BINS) {
+            const int v = hist[tid];
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            cursor[tid] = incl - v;
+        }
+        __syncthreads();
+        uint32_t* out = opaque(K)->sorted + (size_t)chunk * CHUNK;
+        constexpr int PER_THREAD = CHUNK / BLOCK;
+        unsigned word[PER_THREAD];
+        int at[PER_THREAD];
+#pragma unroll
+        for (int n = 0; n < PER_THREAD; ++n) word[n] = list[min(tid + n * BLOCK, CHUNK - 1)];
+#pragma unroll
+        for (int n = 0; n < PER_THREAD; ++n)
+            at[n] = tid + n * BLOCK < nwet ? atomicAdd(&cursor[AO_BINS - 1 - trip_bin((int)(word[n] >> LEAN_OFFSET_BITS))], 1) : -1;
+#pragma unroll
+        for (int n = 0; n < PER_THREAD; ++n)
+            if (at[n] >= 0) out[at[n]] = word[n] & LEAN_OFFSET_MASK;
+    }
+    LEAN_STAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side: the sorted lists start as the static wet lists of the chunk table (index order); the fingerprint and
+// the wet count of every chunk are computed here, once per mask.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lean_list_build_kernel(const uint32_t* __restrict__ wet_pos, const int* __restrict__ begins, int stride,
+                                                              uint32_t* __restrict__ sorted, int* __restrict__ info) {  // stride: AO_CHUNK or AO_CHUNK_WIDE
+    __shared__ unsigned sx[4], sy[4];
+    __shared__ int sn[4];
+    const int chunk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int begin = begins[chunk];
+    unsigned hx = 0, hy = 0;
+    int n = 0;
+    for (int e = threadIdx.x; e < stride; e += 256) {
+        const uint32_t idx = wet_pos[(size_t)chunk * stride + e];
+        const bool listed = idx != 0xffffffffu;
+        sorted[(size_t)chunk * stride + e] = listed ? idx - (uint32_t)begin : LEAN_OFFSET_MASK;
+        if (listed) {
+            hx ^= lean_mix(idx);
+            hy += lean_sum(idx);
+            ++n;
+        }
+    }
+    for (int d = 32; d; d >>= 1) {
+        hx ^= (unsigned)__shfl_xor((int)hx, d);
+        hy += (unsigned)__shfl_xor((int)hy, d);
+        n += __shfl_xor(n, d);
+    }
+    if (lane == 0) {
+        sx[wave] = hx;
+        sy[wave] = hy;
+        sn[wave] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        info[chunk * 4] = sn[0] + sn[1] + sn[2] + sn[3];
+        info[chunk * 4 + 1] = (int)(sx[0] ^ sx[1] ^ sx[2] ^ sx[3]);
+        info[chunk * 4 + 2] = (int)(sy[0] + sy[1] + sy[2] + sy[3]);
+        info[chunk * 4 + 3] = 0;
+    }
+}
+
+hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32_t* d_wet_pos, const int* d_begins, uint32_t* d_sorted, int* d_info) {
+    hipLaunchKernelGGL(lean_list_build_kernel, dim3(nchunks), dim3(256), 0, st, d_wet_pos, d_begins, wide ? AO_CHUNK_WIDE : AO_CHUNK, d_sorted, d_info);
+    return hipGetLastError();
+}
+
+hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
+                                 const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f) {
+    if (!L.d_chunk_begins || L.n_chunks <= 0 || !L.d_lean_info) return hipErrorInvalidValue;
+    LeanArgs A{};
+    A.L = C;
+    A.G = G;
+    A.O = make_ocean(o);
+    A.E = make_exchange(e);
+    A.F = make_fluxes(f);
+    A.g_tab = L.d_tables;
+    A.g_params = L.d_params;
+    A.sorted = L.d_wet_pos ? L.d_lean_sorted : nullptr;  // (no static lists: every workgroup classifies its range per call)
+    A.info = L.d_lean_info;
+    A.chunk_begins = L.d_chunk_begins;
+    A.z_surface = P.z_surface;
+    A.mask_kind = P.mask_kind;
+    A.T_offset = P.T_offset;
+    A.wx_reciprocal = row_reciprocal(G.nx + 2 * G.ring);
+    A.sort_enabled = L.lean_hints;
+    const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
+    if (L.ao_wide) {
+        if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK_WIDE>), dim3(L.n_chunks), dim3(AO_BLOCK_WIDE), LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);
+        else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK_WIDE>), dim3(L.n_chunks), dim3(AO_BLOCK_WIDE), LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);
+    } else {
+        if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace coflux

@@ -325,8 +325,10 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                      the LDS-free one-cell-per-lane gather kernel (≤ 56 VGPRs: small enough to run
                                      beside the resident solver workgroups from a second stream)            */
 #define CF_OPT_MAX_BLOCKS 2       /* reserved for persistent-grid experiments (multiple of 8)        */
-#define CF_OPT_TRIP_HINTS 3       /* 1 (default): order each chunk's cells by their iteration count in the
-                                     previous call so that the lanes of a wave finish together; scheduling only */
+#define CF_OPT_TRIP_HINTS 3       /* order each chunk's cells by the iteration count of the previous call (batches of equal trip
+                                   * counts): 0 off, 1 on, 2 (default) automatic = on for the atmosphere–sea-ice solve, whose counts span
+                                   * 10…100, off for the ocean solve, where with forcing that evolves from call to call the scattered
+                                   * memory access of a sorted batch costs more than the one-step-old order saves (0.085 vs 0.073 ms)  */
 #define CF_OPT_AO_CHUNK 4         /* wet cells per workgroup of the flux solver: 0 = automatic (arrival layers of 1280 / 512 / 512
                                      on a surface that fills the device, 256 on a slab that does not), 256 … 1280 = that size for
                                      every 256-thread workgroup, 3072 = the wide geometry (one 768-thread workgroup per CU;
@@ -344,6 +346,7 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path, LDS-tabulated ψ/log, ≤1e-12 of libm */
 #define CF_SOLVER_LIBM 1    /* same iteration on ocml's libm (slow; cross-check)                     */
 #define CF_SOLVER_TABLES_R2 2 /* CF_SOLVER_TABLES with round 2's body of the ocean iteration (A/B measurements) */
+#define CF_SOLVER_TABLES_R2_OUTER 3 /* round 3's iteration inside round 2's kernel structure (start-phase sort; A/B measurements) */
 int cf_set_option(cf_ctx* ctx, int option, int value);
 /* Self-test hook: y[k] = f(x[k]) with the device primitives the solver uses
  * (f: 0 log, 1 exp, 2 cbrt, 3 sqrt, 4 1/x, 5 ψ_m(ζ), 6 ψ_h(ζ)); d_x, d_y device pointers.        */

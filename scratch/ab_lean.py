@@ -28,6 +28,8 @@ SCALE = dict(sensible_heat=1.0, latent_heat=1.0, water_vapor=1e-6, x_momentum=1e
 for cfg in configs:
     params = ic.flux_params(mk[cfg]())
     ctx = FluxContext(nx, ny, h, h, params)
+    if os.environ.get("CHUNK"): ctx.set_option(abi.OPT_AO_CHUNK, int(os.environ["CHUNK"]))
+    if os.environ.get("HINTS"): ctx.set_option(abi.OPT_TRIP_HINTS, int(os.environ["HINTS"]))
     ocean = {k: ctx.to_device(ocean_np[k]) for k in ("T", "S", "u", "v", "mask")}
     src = {k: ctx.to_device(v) for k, v in src_np.items()}
     w = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj), latitude=ctx.to_device(phi))
@@ -43,12 +45,15 @@ for cfg in configs:
         at_np = {k: v.cpu().numpy() for k, v in atmos.items()}
         ref = orc.compute_atmosphere_ocean_fluxes(g, params, ocean_np, at_np, nthreads=0)
     out = {}
-    for name, solver in (("lean", abi.SOLVER_TABLES), ("r2", SOLVER_R2)):
+    for _ in range(4):  # clocks settle (a cold device is ~9 % slower)
+        ctx.time_stage(abi.STAGE_AO_FLUXES, 500, ocean=ocean, atmos=atmos, fluxes=fluxes)
+    for name, solver in (("lean", abi.SOLVER_TABLES), ("r2", SOLVER_R2), ("lean_r2outer", 3), ("lean", abi.SOLVER_TABLES), ("r2", SOLVER_R2), ("lean_r2outer", 3)):
         ctx.set_option(abi.OPT_SOLVER, solver)
-        ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
+        for _ in range(3):
+            ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
         ctx.sync()
-        t = min(ctx.time_stage(abi.STAGE_AO_FLUXES, reps, ocean=ocean, atmos=atmos, fluxes=fluxes) for _ in range(3))
-        rec = dict(ao_us=round(t * 1e3, 2))
+        t = min(ctx.time_stage(abi.STAGE_AO_FLUXES, reps, ocean=ocean, atmos=atmos, fluxes=fluxes) for _ in range(5))
+        rec = dict(ao_us=round(min(t * 1e3, out.get(name, {}).get("ao_us", 1e9)), 2))
         if ref is not None:
             W = (slice(h - 1, h + ny + 1), slice(h - 1, h + nx + 1))
             got = {k: v.cpu().numpy() for k, v in fluxes.items()}

@@ -22,5 +22,5 @@ open('_solver_phase.hip', 'w').write(s)
 PY
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -c _solver_phase.hip -o /tmp/_solver_phase.o
 rm -f _solver_phase.hip
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libcoflux_phase.so coflux_interp.o /tmp/_solver_phase.o coflux_solver_libm.o coflux_net.o coflux_halo.o coflux_abi.o coflux_window.o coflux_steps.o coflux_tables.o -ldl
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libcoflux_phase.so coflux_interp.o /tmp/_solver_phase.o coflux_solver_lean.o coflux_solver_libm.o coflux_net.o coflux_halo.o coflux_abi.o coflux_window.o coflux_steps.o coflux_tables.o -ldl
 echo built scratch/libcoflux_phase.so

@@ -1,0 +1,59 @@
+"""Per-wave time stamps of the lean ocean kernel's phases (needs scratch/libcoflux_leanstamp.so, make_lean_stamp_build.sh).
+usage: LIBCOFLUX=scratch/libcoflux_leanstamp.so python scratch/phases_lean.py [config]"""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "climaocean.jl_amd"))
+import numpy as np, torch
+from coflux import abi, synthetic as syn, interface_computations as ic
+from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, FluxContext
+nx, ny, h = 1440, 560, 7
+ocean_np = syn.ocean_state(nx, ny, h, h); src_np = syn.jra55_snapshots(2)
+fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h)
+cfgs = sys.argv[1:] or ["default", "fixed0", "fixed12"]
+for label in cfgs:
+    fl = ic.corrected_atmosphere_ocean_fluxes() if label == "corrected" else ic.SimilarityTheoryFluxes()
+    if label.startswith("fixed"): fl.solver_stop_criteria = ic.FixedIterations(int(label[5:]))
+    ctx = FluxContext(nx, ny, h, h, ic.flux_params(fl))
+    if os.environ.get("CHUNK"): ctx.set_option(abi.OPT_AO_CHUNK, int(os.environ["CHUNK"]))
+    ocean = {k: ctx.to_device(ocean_np[k]) for k in ("T", "S", "u", "v", "mask")}
+    src = {k: ctx.to_device(v) for k, v in src_np.items()}
+    w = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj), latitude=ctx.to_device(phi))
+    atmos = ctx.field_set(EXCHANGE_NAMES); fluxes = ctx.field_set(FLUX_NAMES)
+    ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
+    for _ in range(3): ctx.time_stage(abi.STAGE_AO_FLUXES, 500, ocean=ocean, atmos=atmos, fluxes=fluxes)
+    ms = min(ctx.time_stage(abi.STAGE_AO_FLUXES, 50, ocean=ocean, atmos=atmos, fluxes=fluxes) for _ in range(3))
+    ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
+    NWG = int(os.environ.get('NWG', '752')); WPG = int(os.environ.get('WPG', '4'))
+    n = NWG * WPG * 8
+    out = (C.c_ulonglong * n)()
+    ctx.lib.cf_debug_phase_read(out, n)
+    flags = (np.array(out, dtype=np.uint64).reshape(NWG * WPG, 8)[:, 7] >> np.uint64(32)).astype(int)
+    print("   waves with a valid sorted list:", int((flags & 1).sum()), "of", NWG * WPG, "; sorting:", int(((flags >> 1) & 1).sum()))
+    raw = np.array(out, dtype=np.float64).reshape(NWG * WPG, 8)
+    raw[:, 7] = np.array(out, dtype=np.uint64).reshape(NWG * WPG, 8)[:, 7] & np.uint64(0xffffffff)
+    u6 = np.array(out, dtype=np.uint64).reshape(NWG * WPG, 8)[:, 6]
+    raw[:, 6] = u6 & np.uint64((1 << 40) - 1)
+    trips = (u6 >> np.uint64(40)).astype(np.float64)
+    print("   loop trips per batch (wave max): %.2f over %d batches" % (trips.sum() / raw[:, 7].sum(), int(raw[:, 7].sum())))
+    # s_memtime bases differ between CUs: only differences within a wave (or a workgroup) are meaningful
+    life = raw[:, 5] - raw[:, 0]
+    tick = life.max() / (ms * 1e3)  # ticks per µs, assuming the longest-lived wave spans the kernel
+    print(f"{label}: kernel {ms*1e3:.1f} us; {tick:.1f} ticks/us (longest wave = kernel)")
+    D = lambda a, b: (raw[:, a] - raw[:, b]) / tick
+    def row(name, a):
+        print(f"   {name:46s} min {a.min():6.1f}  median {np.median(a):6.1f}  p90 {np.percentile(a,90):6.1f}  max {a.max():6.1f} us")
+    row("entry -> everything requested", D(1, 0))
+    row("requested -> landed (vmcnt 0)", D(2, 1))
+    row("landed -> behind the barrier", D(3, 2))
+    row("start phase total", D(3, 0))
+    row("batches", D(4, 3))
+    row("  of which inside the iteration", raw[:, 6] / tick)
+    row("  batches per wave", raw[:, 7])
+    row("end phase (retire / sort)", D(5, 4))
+    row("wave lifetime", D(5, 0))
+    for lo, hi in ((0, 256), (256, 512), (512, NWG)):
+        sel = np.repeat((np.arange(NWG) >= lo) & (np.arange(NWG) < hi), WPG)
+        wg_life = (raw[sel, 5].reshape(-1, WPG).max(axis=1) - raw[sel, 0].reshape(-1, WPG).min(axis=1)) / tick
+        nb = np.maximum(raw[sel, 7], 1)
+        print(f"   blockIdx {lo:3d}-{hi:3d}: workgroup lifetime median {np.median(wg_life):.1f} p10 {np.percentile(wg_life,10):.1f} max {wg_life.max():.1f}; batches/wave {raw[sel,7].mean():.2f}; per batch {np.median(D(4,3)[sel]/nb):.1f} us of which iterating {np.median(raw[sel,6]/tick/nb):.1f}")
+    ctx.close()
