@@ -29,6 +29,9 @@ sys.path.insert(0, os.path.join(ROOT, "climaocean.jl_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Algorithmic bytes per surface cell (derivation in DESIGN.md §5)
 BYTES_AO = 128.0                       # compute_atmosphere_ocean_fluxes!: 80 read + 48 written
+BYTES_AO_FUSED = 128.0 + 24.0 + 24.0   # + the cell-local net fluxes in its epilogue: Qs, Qℓ, Mp read; JT, JS, SW written
+BYTES_STRESS = 16.0 + 8.0 + 16.0       # the face-stress kernel of the fused form: ρτx, ρτy + mask read; τx, τy written
+FP64_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # wave-instructions/s: 1024 SIMDs, one FP64 VALU instruction per 4 cycles at the 2.4 GHz spec clock
 BYTES_INTERP = 18.3 + 64.0             # JRA55 window amortised + 8 exchange fields written
 BYTES_NET = 88.0 + 40.0
 SNAPSHOT_INTERVAL, DT = 3 * 3600.0, 20 * 60.0   # JRA55 is 3-hourly; Δt = 20 min (README.md:76)
@@ -112,9 +115,35 @@ def cpu_baseline(case_np, params, nx, ny, h, seconds):
     t_first = one_pass()
     repeats = min(100, max(3, int(seconds / max(t_first, 1e-3))))
     t_best = min([t_first] + [one_pass() for _ in range(repeats - 1)])
-    return dict(value=nx * ny / t_best, unit="cells/s", cores=cores, kind="port",
-                sample=f"{repeats} full update_state passes over the {nx}x{ny} surface (best of {repeats}, "
-                       f"{t_best * 1e3:.1f} ms); oracle/coflux_oracle.c, OpenMP over rows (dynamic, 1 row)")
+    rec = dict(value=nx * ny / t_best, unit="cells/s", cores=cores, kind="port",
+               sample=f"{repeats} full update_state passes over the {nx}x{ny} surface (best of {repeats}, "
+                      f"{t_best * 1e3:.1f} ms); oracle/coflux_oracle.c, OpenMP over rows (dynamic, 1 row)")
+    return rec, dict(atmos=atmos, fluxes=fl, net=net)
+
+
+# field scales of the parity metric |Δ| ≤ tol · max(|ref|, scale) (tests/util.py::FIELD_SCALE)
+PARITY_SCALE = dict(sensible_heat=1.0, latent_heat=1.0, water_vapor=1e-6, x_momentum=1e-3, y_momentum=1e-3, temperature=1.0,
+                    u=1e-6, v=1e-6, T=1e-6, S=1e-7, shortwave_surface_flux=1e-6)
+
+
+def measured_parity(ctx, ref, dev_case, nx, ny, h):
+    """One cf_update_state on the inputs the CPU baseline ran on (time fraction 0.37, snapshot levels 0/1), compared
+    with the oracle's outputs of that leg: worst |Δ| / max(|ref|, field scale) per field over interior + ring (fluxes)
+    / interior (net fluxes).  The oracle is the checker here, never the thing measured."""
+    import numpy as np
+    from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, NET_NAMES
+    atmos, fl, net = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+    ctx.update_state(dev_case["src"], dev_case["weights"], dev_case["ocean"], atmos, fl, net, time_fraction=0.37)
+    ctx.sync()
+    out = {}
+    W1 = (slice(h - 1, h + ny + 1), slice(h - 1, h + nx + 1))
+    W0 = (slice(h, h + ny), slice(h, h + nx))
+    for name, got, want, W in (("fluxes", fl, ref["fluxes"], W1), ("net", net, ref["net"], W0)):
+        for k in want:
+            g = got[k].cpu().numpy()[W]
+            r = want[k][W]
+            out[f"{name}.{k}"] = float(np.max(np.abs(g - r) / np.maximum(np.abs(r), PARITY_SCALE[k])))
+    return out
 
 
 def main():
@@ -387,18 +416,32 @@ def main():
         copy_bytes = 256 << 20
         copy_ms = ctx.time_copy(copy_bytes, 20)
 
-        # HBM bytes per launch from committed rocprofv3 PMC passes (separate runs, see profiles/): a property of the
-        # kernel on this workload, not re-measured in this run — `traffic_source` says so
-        traffic, traffic_source = {}, None
-        for tag in ("r02", "r01"):
+        # HBM bytes and VALU instructions per launch from committed rocprofv3 PMC passes (separate runs of this command,
+        # scratch/round_profile.sh; see profiles/): properties of the kernels on this workload, not re-measured in this
+        # run — `traffic_source` / `instructions_source` name the file and the commit it was taken at
+        lean, fused = ctx.solver_path()
+        traffic, traffic_source, sq, sq_source = {}, None, {}, None
+        canonical = (nx, ny, a.flux_configuration, world, a.config) == (1440, 560, "default", 1, "ocean")
+        for tag in ("r03", "r02", "r01"):
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))["kernels"]
-                if (nx, ny, a.flux_configuration, world, a.config) == (1440, 560, "default", 1, "ocean"):
-                    traffic = {k.split("<")[0]: v["hbm_bytes_per_launch"] for k, v in pmc.items()}
-                    traffic_source = f"committed: profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
+                if canonical:
+                    traffic = {k.split("<")[0]: v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()}
+                    traffic_source = (f"committed: profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes"
+                                      f"{', tree ' + pmc['commit'] if pmc.get('commit') else ''})")
                 break
             except Exception:
                 continue
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq.json")))
+            if canonical:
+                sq = {k.split("<")[0]: v for k, v in pmc["kernels"].items()}
+                sq_source = f"committed: profiles/r03_pmc_sq.json (rocprofv3 --pmc SQ_INSTS_VALU …, tree {pmc.get('commit')})"
+        except Exception:
+            pass
+        ao_kernel = "ao_lean_kernel" if lean else "ao_flux_fast_kernel"
+        ao_what = "compute_atmosphere_ocean_fluxes!" + (" + the cell-local part of compute_net_ocean_fluxes! in its epilogue" if fused else "")
+        ao_bytes = BYTES_AO_FUSED if fused else BYTES_AO
 
         def roof(name, nbytes, ncells, ms, **extra):
             achieved = nbytes * ncells / (ms * 1e-3) / 1e9
@@ -425,24 +468,46 @@ def main():
                    settle_steps=settle.get(best), repetitions=reps, ms_per_step_samples=[s / steps * 1e3 for s in samples],
                    halo_paths_ms_per_step={k: v[0] / steps * 1e3 for k, v in results.items()} if world > 1 else None,
                    # dominant kernel = compute_atmosphere_ocean_fluxes! (SURVEY.md §8d contract figure 128 B/cell)
-                   roofline=roof("ao_flux_fast_kernel (compute_atmosphere_ocean_fluxes!)", BYTES_AO, cells_rank, ao_ms,
+                   roofline=roof(f"{ao_kernel} ({ao_what})", ao_bytes, cells_rank, ao_ms,
                                  launches_timed=nrec,
+                                 bytes_per_cell_note=("80 B read + 48 B written (SURVEY §8d, the contract figure of the solver) + Qs, Ql, Mp read "
+                                                      "and JT, JS, SW written by the fused net-flux epilogue" if fused else
+                                                      "80 B read + 48 B written (SURVEY §8d)"),
+                                 frac_at_contract_128_B_per_cell=BYTES_AO * cells_rank / (ao_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  measured="HIP events around the kernel inside a separate event-bracketed pass over the timed schedule",
                                  avg_launch_ms_batches_sorted_by_trip_hints=prof_sorted[1][0] if prof_sorted else None,
                                  avg_launch_ms_back_to_back_same_inputs=ao_ms_alone),
                    roofline_interpolate=roof("interpolate_kernel (interpolate_atmosphere_state!)", BYTES_INTERP, cells_rank, interp_ms),
-                   roofline_net_fluxes=roof("net_flux_kernel (compute_net_ocean_fluxes!)", BYTES_NET, nx * ny, net_ms),
+                   roofline_net_fluxes=(roof("net_stress_kernel (compute_net_ocean_fluxes!: the two face stresses)", BYTES_STRESS, nx * ny, net_ms)
+                                        if fused else roof("net_flux_kernel (compute_net_ocean_fluxes!)", BYTES_NET, nx * ny, net_ms)),
                    stages_ms=dict(interpolate_tiled_standalone=interp_ms,
                                   interpolate_background_standalone=interp_bg_ms if pipeline else None,
                                   ao_fluxes=ao_ms, net_fluxes=net_ms, ao_fluxes_standalone=ao_ms_alone,
                                   net_fluxes_standalone=net_ms_alone),
                    device_copy_GBs=2 * copy_bytes / (copy_ms * 1e-3) / 1e9,
                    parity="vs reference: unpinned (self-consistent restatements only; see DESIGN.md)")
+        # the ceiling that binds the solver: FP64 VALU issue
+        k_sq = sq.get(ao_kernel)
+        if k_sq:
+            insts = k_sq["SQ_INSTS_VALU"]
+            rate = insts / (ao_ms * 1e-3)
+            out["roofline_fp64_valu"] = dict(
+                bound="fp64_valu_issue", kernel=ao_kernel, achieved=rate / 1e9, peak=FP64_ISSUE_PEAK / 1e9, unit="G wave-instr/s",
+                frac=rate / FP64_ISSUE_PEAK, valu_instructions_per_launch=insts, instructions_source=sq_source,
+                valu_busy_of_wave_lifetime=k_sq.get("valu_busy"),
+                note=("peak = 1024 SIMDs x 2.4 GHz / 4 cycles per FP64 wave-instruction; under this load the device clocks at "
+                      "about 1.9-2.0 GHz (scratch/ubench_valu.hip: 480 G wave-instr/s of v_fma_f64 sustained), so frac <= 0.80 is the "
+                      "practical ceiling; every VALU instruction is counted at the FP64 rate"))
         if a.share_device:
             out["rehearsal"] = f"{world} ranks time-sharing ONE device: a test of the N-rank code path, not a scaling number"
         if not a.no_cpu_baseline and world == 1:
             case_np = dict(ocean=ocean_np[0], src=src_np, weights=w_np)
-            out["cpu_baseline"] = cpu_baseline(case_np, params, nx, ny, h, a.cpu_seconds)
+            out["cpu_baseline"], ref = cpu_baseline(case_np, params, nx, ny, h, a.cpu_seconds)
+            if a.config == "ocean" and not tripolar:
+                worst = measured_parity(ctx, ref, dict(src=src, weights=w, ocean=states[0]), nx, ny, h)
+                out["parity_measured"] = dict(worst_scaled_error=worst, max=max(worst.values()),
+                                              metric="|got - oracle| / max(|oracle|, field scale), one cf_update_state on the cpu_baseline leg's inputs",
+                                              against="oracle/coflux_oracle.c (CPU restatement; parity vs the reference itself: unpinned)")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -202,6 +202,7 @@ EXPORTED_SYMBOLS = (
     "cf_interpolate_land_freshwater", "cf_set_land_freshwater", "cf_materialize_salinity_restoring",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
     "cf_window_upload", "cf_window_find", "cf_window_source",
+    "cf_ensure_chunk_table", "cf_solver_path",
 )
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -286,6 +287,8 @@ def load_library(path=None):
         vp, C.c_int64, C.c_int, C.POINTER(RunSchedule), C.POINTER(AtmosSource), C.POINTER(InterpWeights),
         C.POINTER(InterfaceFluxes), C.POINTER(SeaIceFields), C.POINTER(NetOceanFluxes)]
     lib.cf_prefetch_atmosphere_state.argtypes = [vp, C.POINTER(AtmosSource), C.POINTER(InterpWeights), C.POINTER(ExchangeFields)]
+    lib.cf_ensure_chunk_table.argtypes = [vp, vp]
+    lib.cf_solver_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.cf_default_sea_ice_albedo_params.argtypes = [C.POINTER(SeaIceAlbedoParams)]
     lib.cf_set_sea_ice_albedo.argtypes = [vp, C.POINTER(SeaIceAlbedoParams)]
     lib.cf_compute_sea_ice_albedo.argtypes = [vp, C.POINTER(SeaIceAlbedoParams), vp, vp, vp, vp]

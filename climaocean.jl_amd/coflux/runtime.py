@@ -293,6 +293,16 @@ class FluxContext:
                                            C.byref(n), C.byref(ms)), "cf_time_stage")
         return ms.value
 
+    def ensure_chunk_table(self, mask):
+        """Build the solver's schedule for `mask` now instead of inside the first step."""
+        self._check(self.lib.cf_ensure_chunk_table(self._h, _ptr(mask)), "cf_ensure_chunk_table")
+
+    def solver_path(self):
+        """(lean_kernel, fused_net): which kernels cf_update_state launches for the current formulation and options."""
+        lean, fused = C.c_int(), C.c_int()
+        self._check(self.lib.cf_solver_path(self._h, C.byref(lean), C.byref(fused)), "cf_solver_path")
+        return bool(lean.value), bool(fused.value)
+
     def time_copy(self, nbytes, launches=20):
         a = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)
         b = torch.empty_like(a)

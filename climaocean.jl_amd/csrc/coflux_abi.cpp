@@ -498,7 +498,8 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->launch.lean_hints = ctx->lean_hints ? 1 : 0;
             return CF_OK;
         case CF_OPT_FUSED_NET:
-            ctx->fused_net = value != 0;
+            if (value < 0 || value > 2) return fail(ctx, CF_ERR_INVALID, "fused net fluxes %d: 0 (never), 1 (when possible), 2 (automatic)", value);
+            ctx->fused_net = value;
             return CF_OK;
         case CF_OPT_ICE_ORBIT_SHORTCUT:
             ctx->ice_orbit_shortcut = value != 0;
@@ -632,11 +633,29 @@ static int wait_for_halos(cf_ctx* ctx) {
     return CF_OK;
 }
 
-}  // extern "C"
 // (coflux_steps.cpp: the table is built before the first halo exchange of a step loop is queued — building it
 // synchronises the stream, which must not hold a peer-direct exchange that waits for a neighbour still to be launched)
-int cf_ensure_chunk_table(cf_ctx* ctx, const void* mask) { return ensure_chunk_table(ctx, mask); }
-extern "C" {
+int cf_ensure_chunk_table(cf_ctx* ctx, const void* mask) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ensure_chunk_table(ctx, mask);
+}
+
+static bool net_fluxes_fused(const cf_ctx* ctx) {
+    const bool lean = ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
+    return (ctx->fused_net == 1 || (ctx->fused_net == 2 && lean)) &&
+           (ctx->launch.solver == CF_SOLVER_TABLES || ctx->launch.solver == CF_SOLVER_TABLES_R2 ||
+            ctx->launch.solver == CF_SOLVER_TABLES_R2_OUTER) &&
+           ctx->dev.albedo_kind == CF_ALBEDO_CONSTANT &&
+           (lean || !ctx->launch.ao_wide);  // (round 2's kernel has the fused epilogue in the narrow geometry only)
+}
+
+int cf_solver_path(cf_ctx* ctx, int* lean_kernel, int* fused_net) {
+    if (!ctx || !lean_kernel || !fused_net) return fail(ctx, CF_ERR_INVALID, "cf_solver_path: bad arguments");
+    *lean_kernel = ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
+    *fused_net = net_fluxes_fused(ctx) ? 1 : 0;
+    return CF_OK;
+}
 
 int cf_interpolate_atmosphere_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
                                     const cf_exchange_fields* out) {
@@ -712,8 +731,7 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     // Fused form: the cell-local part of compute_net_ocean_fluxes! (everything but the two face stresses, which
     // need the west / south neighbour's ρτ) is computed in the solver's epilogue from registers, and a thin stress
     // kernel follows — bitwise the same numbers as the three-launch sequence (shared arithmetic, contraction off).
-    const bool fuse = ctx->fused_net && ctx->launch.solver == CF_SOLVER_TABLES && ctx->dev.albedo_kind == CF_ALBEDO_CONSTANT &&
-                      !ctx->launch.ao_wide;  // (the fused epilogue exists in the narrow workgroup geometry only)
+    const bool fuse = net_fluxes_fused(ctx);
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes,
                                   fuse ? ice : nullptr, fuse ? net : nullptr, ctx->d_land_freshwater));
     // the next step's interpolation goes out behind the solver: its workgroups are dispatched first, the gather kernel

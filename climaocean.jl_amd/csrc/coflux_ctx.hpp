@@ -53,7 +53,7 @@ struct cf_ctx {
     int* d_lean_info = nullptr;         // per chunk: listed wet cells + fingerprint (4 ints)
     bool trip_hints = true;
     bool lean_hints = false;         // the lean ocean kernel sorts its lists by trip count only when CF_OPT_TRIP_HINTS = 1
-    bool fused_net = false;          // cf_update_state: net fluxes in the solver's epilogue + a stress kernel (measured slower: off)
+    int fused_net = 2;               // cf_update_state: net fluxes in the solver's epilogue + a stress kernel: 0 never, 1 when possible, 2 with the lean ocean kernel
     // cost-balanced chunk table of the solver, rebuilt when the wet mask (pointer / kind / surface z) changes
     int* d_chunk_sums = nullptr;
     int* d_chunk_begins = nullptr;

@@ -8,6 +8,9 @@
 // device's resident-workgroup slots in whole rounds.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "coflux_solver_shared.hpp"
 #include "coflux_lean.hpp"
 
@@ -30,7 +33,7 @@ struct Geom {
     static constexpr int LDS_BYTES = PARAMS_OFFSET + (int)sizeof(DevParams);
 };
 static_assert(Geom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
-constexpr int AO_LAYER_1 = 1280, AO_LAYER_2 = 512, AO_LAYER_3 = 512;  // wet cells per chunk of the last three arrival layers (plan_chunk_rounds)
+constexpr int AO_LAYER_1 = 1024, AO_LAYER_2 = 768, AO_LAYER_3 = 512;  // wet cells per chunk of the last three arrival layers (plan_chunk_rounds)
 static_assert(AO_LAYER_1 <= AO_CHUNK && AO_LAYER_1 >= AO_LAYER_2 && AO_LAYER_2 >= AO_LAYER_3, "layer sizes");
 static_assert(AO_BINS == 64, "Geom<>::PARAMS_OFFSET spells the bin count out");
 static_assert(Geom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow solver workgroups must fit the CU's 160 KB of LDS");
@@ -43,7 +46,7 @@ static_assert(Geom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow solver workgroup
 // holds 3 workgroups per CU, and a dispatch "round" that is only half full runs at half throughput.
 // The wet mask is static, so the surface is cut ONCE per mask into chunks of prescribed cost with
 // wet = AO_WET_COST, land = 1.  The host picks a descending sequence of rounds (plan_chunk_rounds below: arrival
-// layers of 1280 / 512 / 512 wet cells on a surface that fills the device, 256-cell chunks on one that does not)
+// layers of 1024 / 768 / 512 wet cells on a surface that fills the device, 256-cell chunks on one that does not)
 // so that the long workgroups start first and whatever tail is left is short.  An open-ocean chunk holds
 // exactly its nominal wet count, a coastal one slightly fewer, a land chunk at most 64× as many cells (it
 // only writes zeros).  The table and the static wet lists built with it only steer scheduling: the solver checks
@@ -150,10 +153,11 @@ __global__ __launch_bounds__(256) void chunk_begins_kernel(const DevParams* __re
 // is the (b / CUs)-th arrival on its CU — and the SIMD arbiter serves the OLDEST wave first (s_setprio does not
 // change that: measured).  With three equal workgroups per CU the first finishes at 60 % of the kernel and the
 // third runs the last third alone, too few waves to keep the FP64 pipe busy (lifetimes 58 / 73 / 92 µs at
-// equal work).  So the work is handed out in proportion to the share each arrival gets: 1280, 512 and 512
-// wet cells for the last three layers (all multiples of 256 = whole batches for four waves; measured against
-// 1024/768/512 — the first layer then fills the list capacity of last round — 1280/768/256, 1280/640/384 and
-// 1152/…: 0.1161 vs 0.1174 ms per step, sizes that are not whole batches per wave lose 3 µs), 1280 for every
+// equal work).  So the work is handed out in proportion to the share each arrival gets: 1024, 768 and 512
+// wet cells for the last three layers (all multiples of 256 = whole batches for four waves).  Round 2's kernel, whose
+// start phase took 9 µs, did best with 1280/512/512; with round 3's (4 µs start phase, batches in index order)
+// the same-box scan reads 1024/768/512 65.6 µs, 1280/512/512 68.1, 1280/768/256 68.0, 1152/640/512 67.5, 1280/640/384
+// 68.4, 1024/640/640 70.3, 768/768/768 70.8 (profiles/r03_experiments.md).  1024 for every
 // layer before them (on larger surfaces a new workgroup starts whenever the oldest one retires and the
 // pipeline staggers itself; only the tail needs shaping).  Pure host arithmetic (tests/test_abi.py checks it
 // without a GPU through cf_debug_chunk_plan); returns the largest chunk size used.
@@ -196,7 +200,15 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
     } else {
         // 1024s for everything before the last two layers (none on a surface that fits three layers), then as
         // many 768s as still needed, then 512s
-        constexpr int W1 = AO_LAYER_1, W2 = AO_LAYER_2, W3 = AO_LAYER_3;
+        int W1 = AO_LAYER_1, W2 = AO_LAYER_2, W3 = AO_LAYER_3;
+        if (const char* env = std::getenv("COFLUX_LAYERS")) {  // experiments only: "w1,w2,w3" (multiples of 64, w1 ≥ w2 ≥ w3, w1 ≤ AO_CHUNK)
+            int a = 0, b = 0, c = 0;
+            if (std::sscanf(env, "%d,%d,%d", &a, &b, &c) == 3 && a <= AO_CHUNK && a >= b && b >= c && c >= 64 && a % 64 == 0 && b % 64 == 0 && c % 64 == 0) {
+                W1 = a;
+                W2 = b;
+                W3 = c;
+            }
+        }
         const long body = need - cap(W2) - cap(W3);
         const long n1 = body > 0 ? (body + cap(W1) - 1) / cap(W1) * layer : 0;  // whole layers of the largest size
         add_round(W1, n1, false);
@@ -833,9 +845,9 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
                             const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net,
                             const double* land) {
     if (L.solver == CF_SOLVER_LIBM) return net ? hipErrorInvalidValue : launch_ao_fluxes_libm(st, P, G, o, e, f);
-    // the production ocean configurations on narrow workgroups, net fluxes as their own launch: the round-3 kernel
-    if (C.specialization == SOLVER_OCEAN_LEAN && L.solver == CF_SOLVER_TABLES && !net && L.d_lean_info)
-        return launch_ao_fluxes_lean(st, L, P, C, G, o, e, f);
+    // the production ocean configurations: the round-3 kernel
+    if (C.specialization == SOLVER_OCEAN_LEAN && L.solver == CF_SOLVER_TABLES && L.d_lean_info)
+        return launch_ao_fluxes_lean(st, L, P, C, G, o, e, f, ice, net, land);
     OceanIn O = make_ocean(o);
     Exchange E = make_exchange(e);
     FluxOut F = make_fluxes(f);

@@ -22,6 +22,10 @@
 #include "coflux_lean.hpp"
 #include "coflux_solver_shared.hpp"
 
+#ifndef CF_LEAN_PREFETCH
+#define CF_LEAN_PREFETCH 0  // 1: the next batch's inputs are requested before the current batch iterates (measured: 23 more live registers cost more than the wait, 70.3 vs 68.3 us)
+#endif
+
 namespace coflux {
 
 // per-wave time stamps (scratch/phases_lean.py; -DCF_LEAN_STAMPS builds only): 0 entry, 1 everything requested, 2 my
@@ -57,6 +61,8 @@ struct LeanArgs {
     double T_offset;
     unsigned long long wx_reciprocal;
     long long sort_enabled;   // CF_OPT_TRIP_HINTS
+    IceIn I;                  // fused net fluxes only
+    NetOut N;
 };
 typedef const LeanArgs __attribute__((address_space(4)))* LeanArgsPtr;
 
@@ -92,14 +98,26 @@ struct LeanGeom {
 static_assert(LeanGeom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow lean solver workgroups must fit the CU's 160 KB of LDS");
 static_assert(LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
 
-__device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_offset, const FluxOut& F, size_t k) {
+// zero_interface_state of a land cell: all fluxes 0, T = 0 K (and, in the fused form, zero net fluxes inside the interior)
+template <bool FUSE>
+__device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_offset, const GridDesc& G, LeanArgsPtr K, size_t k, int i, int j) {
     CellFluxes Z{};
     Z.Ts_ocean = -T_offset;
     Z.iterations = L.fixed ? L.maxiter : 0;
+    const FluxOut F = kread(&K->F);
     store_fluxes(F, k, Z);
+    if constexpr (FUSE) {
+        if (i >= 0 && i < G.nx && j >= 0 && j < G.ny) {
+            const NetOut N = kread(&K->N);
+            store_net_cell(N, k, NetCell{});
+        }
+    }
 }
 
-template <bool COARE, int BLOCK>
+// FUSE: the cell-local part of compute_net_ocean_fluxes! (everything but the two face stresses, which need the west /
+// south neighbour's ρτ: launch_net_stress) in the epilogue — the same arithmetic as net_flux_kernel, bit for bit
+// (net_cell_local, contraction off).  With batches in index order its nine extra accesses per cell are coalesced.
+template <bool COARE, int BLOCK, bool FUSE>
 __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_name) {
     using Geo = LeanGeom<BLOCK>;
     constexpr int CHUNK = Geo::CHUNK;
@@ -221,8 +239,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
             hx ^= lean_mix((unsigned)idx);
             hy += lean_sum((unsigned)idx);
         } else {
-            const FluxOut F = kread(&opaque(K)->F);
-            lean_zero_cell(L, T_offset, F, k);
+            lean_zero_cell<FUSE>(L, T_offset, G, opaque(K), k, idx - jj * wx - G.ring, jj - G.ring);
         }
     }
     for (int d = 32; d; d >>= 1) {
@@ -250,13 +267,14 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
     }
     if (have_list && land) {
         // zero_interface_state of the range's land: nothing waits for these stores but the first batch's loads
-        const FluxOut F = kread(&opaque(K)->F);
+        LeanArgsPtr Kz = opaque(K);
 #pragma unroll
         for (int n = 0; n < LAND_UNROLL; ++n)
             if (land & (1u << n)) {
                 const int idx = range_begin + tid + n * BLOCK;
                 const int jj = row_of(idx, wx, wx_rcp);
-                lean_zero_cell(L, T_offset, F, cell_index(G, idx - jj * wx - G.ring, jj - G.ring));
+                const int i = idx - jj * wx - G.ring, j = jj - G.ring;
+                lean_zero_cell<FUSE>(L, T_offset, G, Kz, cell_index(G, i, j), i, j);
             }
     }
     int begin = range_begin, end = range_end;
@@ -268,12 +286,10 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                 bool wet = false;
                 if (idx < end) {
                     const int jj = row_of(idx, wx, wx_rcp);
-                    const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+                    const int i = idx - jj * wx - G.ring, j = jj - G.ring;
+                    const size_t k = cell_index(G, i, j);
                     wet = cell_is_wet(P, mask, k);
-                    if (!wet) {
-                        const FluxOut F = kread(&opaque(K)->F);
-                        lean_zero_cell(L, T_offset, F, k);
-                    }
+                    if (!wet) lean_zero_cell<FUSE>(L, T_offset, G, opaque(K), k, i, j);
                 }
                 const unsigned long long m = __ballot(wet);
                 int wave_base = 0;
@@ -294,31 +310,57 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                 continue;
             }
         }
-        // ---- waves pull 64 wet cells at a time -------------------------------------------------------------------
-        for (;;) {
-            int start = 0;
-            if (lane == 0) start = atomicAdd(&counters[0], 64);
-            start = __shfl(start, 0);
-            if (start >= nwet) break;
+        // ---- waves pull 64 wet cells at a time; the NEXT batch's inputs are requested before this batch iterates ------
+        // (a batch's eleven loads take ≈ 2 µs to come back and its ≈ 2000 FP64 instructions ≈ 6 µs to issue: requested
+        // one batch ahead, the loads cost 23 registers across the iteration and no wait)
+        auto claim = [&]() {
+            int st = 0;
+            if (lane == 0) st = atomicAdd(&counters[0], 64);
+            return __shfl(st, 0);
+        };
+        auto cell_of = [&](int st) -> size_t {
+            const int qq = min(st + lane, nwet - 1);
+            const int idx = range_begin + (int)(list[qq] & LEAN_OFFSET_MASK);
+            const int jj = row_of(idx, wx, wx_rcp);
+            return cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+        };
+        struct Raw {
+            double ua, va, Ta, pa, qa, u0, u1, v0, v1, To, So;
+        };
+        auto request = [&](int st) {
+            const size_t k = cell_of(st);
+            LeanArgsPtr Kb = opaque(K);  // this batch's view of the arguments: pointers are (re)loaded here, scalar loads
+            const double* __restrict__ Ou = Kb->O.u;
+            const double* __restrict__ Ov = Kb->O.v;
+            Raw r;
+            r.u0 = Ou[k];
+            r.u1 = Ou[k + 1];
+            r.v0 = Ov[k];
+            r.v1 = Ov[k + (size_t)G.sj];
+            r.ua = Kb->E.u[k];
+            r.va = Kb->E.v[k];
+            r.Ta = Kb->E.T[k];
+            r.pa = Kb->E.p[k];
+            r.qa = Kb->E.q[k];
+            r.To = Kb->O.T[k];
+            r.So = Kb->O.S[k];
+            return r;
+        };
+        int start = claim();
+        Raw raw{};
+        if (start < nwet) raw = request(start);
+        while (start < nwet) {
             const int q = start + lane;
             const bool in_range = q < nwet;
-            const int qc = in_range ? q : nwet - 1;
-            LeanCell c;
-            {
-                const int idx = range_begin + (int)(list[qc] & LEAN_OFFSET_MASK);
-                const int jj = row_of(idx, wx, wx_rcp);
-                const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
-                LeanArgsPtr Kb = opaque(K);  // this batch's view of the arguments: pointers are (re)loaded here, scalar loads
-                // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
-                const double* __restrict__ Ou = Kb->O.u;
-                const double* __restrict__ Ov = Kb->O.v;
-                const double uo = 0.5 * (Ou[k] + Ou[k + 1]);
-                const double vo = 0.5 * (Ov[k] + Ov[k + (size_t)G.sj]);
-                c = lean_prologue(P, L.kappa, tab, Kb->E.u[k], Kb->E.v[k], Kb->E.T[k], Kb->E.p[k], Kb->E.q[k], uo, vo, Kb->O.T[k],
-                                  Kb->O.S[k]);
-                // the interface temperature does not depend on the iteration: written now, not carried across it
-                if (in_range) Kb->F.Ts[k] = c.Ts - T_offset;
-            }
+            // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
+            const LeanCell c = lean_prologue(P, L.kappa, tab, raw.ua, raw.va, raw.Ta, raw.pa, raw.qa, 0.5 * (raw.u0 + raw.u1),
+                                             0.5 * (raw.v0 + raw.v1), raw.To, raw.So);
+            // the interface temperature does not depend on the iteration: written now, not carried across it
+            if (in_range) opaque(K)->F.Ts[cell_of(start)] = c.Ts - T_offset;
+#if CF_LEAN_PREFETCH
+            const int next = claim();
+            if (next < nwet) raw = request(next);
+#endif
 #ifdef CF_LEAN_STAMPS
             const unsigned long long t_it = __builtin_readcyclecounter();
 #endif
@@ -335,10 +377,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
             if (in_range) {
                 LeanArgsPtr Ke = opaque(K);
                 // (cell coordinates recomputed from the list entry: cheaper than registers held across the iteration)
-                const unsigned entry = list[qc] & LEAN_OFFSET_MASK;
-                const int idx2 = range_begin + (int)entry;
-                const int jj2 = row_of(idx2, wx, wx_rcp);
-                const size_t k = cell_index(G, idx2 - jj2 * wx - G.ring, jj2 - G.ring);
+                const size_t k = cell_of(start);
                 const CellFluxes R = lean_epilogue(c, T_offset, s);
                 const FluxOut F = kread(&Ke->F);
                 F.Qc[k] = R.Qc;
@@ -350,12 +389,32 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                 if (F.tstar) F.tstar[k] = R.tstar;
                 if (F.qstar) F.qstar[k] = R.qstar;
                 if (F.iters) F.iters[k] = R.iterations;
+                if constexpr (FUSE) {
+                    // compute_net_ocean_fluxes!, the part that needs no neighbour: interior cells only
+                    const int qq = min(start + lane, nwet - 1);
+                    const int idx = range_begin + (int)(list[qq] & LEAN_OFFSET_MASK);
+                    const int jj = row_of(idx, wx, wx_rcp);
+                    const int ci = idx - jj * wx - G.ring, cj = jj - G.ring;
+                    if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {
+                        const IceIn I = kread(&Ke->I);
+                        const NetOut N = kread(&Ke->N);
+                        const double Ts_ocean = (Ke->O.T[k] + P.T_offset) - T_offset;  // what F.Ts holds (written before the iteration)
+                        store_net_cell(N, k, net_cell_local(P, P.albedo, I.conc ? I.conc[k] : 0.0, Ke->O.S[k], Ts_ocean + P.T_offset,
+                                                            Ke->E.Mp[k], Ke->E.Qs[k], Ke->E.Ql[k], R.Qc, R.Qv, R.Fv,
+                                                            I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0, I.land ? I.land[k] : 0.0));
+                    }
+                }
                 if (sorting && have_list) {
                     const int w = min(s.work, 255);
-                    list[q] = entry | ((unsigned)w << LEAN_OFFSET_BITS);
+                    list[q] = (list[q] & LEAN_OFFSET_MASK) | ((unsigned)w << LEAN_OFFSET_BITS);
                     atomicAdd(&hist[AO_BINS - 1 - trip_bin(w)], 1);
                 }
             }
+#if !CF_LEAN_PREFETCH
+            const int next = claim();
+            if (next < nwet) raw = request(next);
+#endif
+            start = next;
         }
         if (have_list || end >= range_end) break;
         begin = end;  // classification path: the rest of the range
@@ -447,7 +506,8 @@ hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32
 }
 
 hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
-                                 const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f) {
+                                 const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
+                                 const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land) {
     if (!L.d_chunk_begins || L.n_chunks <= 0 || !L.d_lean_info) return hipErrorInvalidValue;
     LeanArgs A{};
     A.L = C;
@@ -465,14 +525,29 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
     A.T_offset = P.T_offset;
     A.wx_reciprocal = row_reciprocal(G.nx + 2 * G.ring);
     A.sort_enabled = L.lean_hints;
-    const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
-    if (L.ao_wide) {
-        if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK_WIDE>), dim3(L.n_chunks), dim3(AO_BLOCK_WIDE), LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);
-        else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK_WIDE>), dim3(L.n_chunks), dim3(AO_BLOCK_WIDE), LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);
-    } else {
-        if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
-        else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+    if (net) {  // the fused form: the epilogue also writes the cell-local net ocean fluxes (constant ocean albedo only)
+        if (ice) A.I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress, nullptr};
+        A.I.land = land;
+        A.N = NetOut{net->u, net->v, net->T, net->S, net->shortwave_surface_flux, net->upwelling_longwave, net->downwelling_longwave,
+                     net->downwelling_shortwave};
     }
+    const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
+#define CF_LEAN_LAUNCH(COARE_, BLOCK_, FUSE_) \
+    hipLaunchKernelGGL((ao_lean_kernel<COARE_, BLOCK_, FUSE_>), dim3(L.n_chunks), dim3(BLOCK_), LeanGeom<BLOCK_>::LDS_BYTES, st, A)
+    if (L.ao_wide) {
+        if (net) {
+            if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK_WIDE, true); else CF_LEAN_LAUNCH(false, AO_BLOCK_WIDE, true);
+        } else {
+            if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK_WIDE, false); else CF_LEAN_LAUNCH(false, AO_BLOCK_WIDE, false);
+        }
+    } else {
+        if (net) {
+            if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK, true); else CF_LEAN_LAUNCH(false, AO_BLOCK, true);
+        } else {
+            if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK, false); else CF_LEAN_LAUNCH(false, AO_BLOCK, false);
+        }
+    }
+#undef CF_LEAN_LAUNCH
     return hipGetLastError();
 }
 

@@ -13,7 +13,6 @@
 static std::mutex g_peer_mutex;
 static std::map<std::string, std::pair<char*, int>> g_peer_local;  // handle bytes → (mailbox, device)
 
-int cf_ensure_chunk_table(cf_ctx* ctx, const void* mask);  // coflux_abi.cpp
 
 static int ensure_aux_stream(cf_ctx* ctx) {
     if (ctx->aux_stream) return CF_OK;

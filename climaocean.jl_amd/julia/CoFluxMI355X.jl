@@ -260,6 +260,10 @@ prefetch_atmosphere_state!(b, src_next::CfAtmosSource, w::CfInterpWeights, out::
     check(b.ctx, ccall((:cf_prefetch_atmosphere_state, libcoflux), Cint,
                        (Ptr{Cvoid}, Ref{CfAtmosSource}, Ref{CfInterpWeights}, Ref{CfExchangeFields}), b.ctx, src_next, w, out))
 
+# the solver's schedule for a wet mask, built ahead of the first step (optional: the first call builds it otherwise)
+ensure_chunk_table!(b, mask::Ptr{Cvoid}) =
+    check(b.ctx, ccall((:cf_ensure_chunk_table, libcoflux), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), b.ctx, mask))
+
 # ---- run!(simulation) of a prescribed-ocean model inside the library (bench / offline forcing runs) -------------------
 struct CfRunSchedule
     struct_size::Int32; n_ocean_states::Int32

@@ -329,16 +329,18 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * counts): 0 off, 1 on, 2 (default) automatic = on for the atmosphere–sea-ice solve, whose counts span
                                    * 10…100, off for the ocean solve, where with forcing that evolves from call to call the scattered
                                    * memory access of a sorted batch costs more than the one-step-old order saves (0.085 vs 0.073 ms)  */
-#define CF_OPT_AO_CHUNK 4         /* wet cells per workgroup of the flux solver: 0 = automatic (arrival layers of 1280 / 512 / 512
+#define CF_OPT_AO_CHUNK 4         /* wet cells per workgroup of the flux solver: 0 = automatic (arrival layers of 1024 / 768 / 512
                                      on a surface that fills the device, 256 on a slab that does not), 256 … 1280 = that size for
                                      every 256-thread workgroup, 3072 = the wide geometry (one 768-thread workgroup per CU;
                                      measured 3 % slower on the 1/4° surface) */
 #define CF_OPT_PROFILE_STRIDE 5   /* cf_profile_enable: bracket only every n-th cf_update_state with events (1); the event
                                      records between the kernels cost ≈ 4 µs of stream time each               */
-#define CF_OPT_FUSED_NET 6        /* 1: cf_update_state computes the cell-local net ocean fluxes in the solver's epilogue and
-                                     follows with a face-stress kernel; 0 (default): the three-launch sequence.  Bitwise the
-                                     same results; measured SLOWER on MI355X (the epilogue's nine extra scattered 8-byte
-                                     accesses per cell cost the solver 18 µs and save 14 µs of net-flux kernel). */
+#define CF_OPT_FUSED_NET 6        /* cf_update_state computes the cell-local net ocean fluxes in the solver's epilogue and follows
+                                   * with a face-stress kernel instead of the three-launch sequence (bitwise the same results):
+                                   * 0 never, 1 whenever the configuration allows it (constant ocean albedo), 2 (default) when the
+                                   * round-3 ocean kernel runs — its batches are in index order, so the epilogue's nine extra
+                                   * accesses per cell are coalesced: update_state 0.107 → 0.096 ms; in round 2's trip-sorted
+                                   * kernels the same accesses were scattered and cost more than the net-flux kernel they save. */
 #define CF_OPT_ICE_ORBIT_SHORTCUT 7 /* 1 (default): the atmosphere–sea-ice iteration stops as soon as its state repeats the state of two
                                      iterations ago bit for bit — an exact period-2 orbit, where the skin-temperature balance does not
                                      contract — and returns the iterate the remaining steps up to maxiter would end on (the same
@@ -712,6 +714,18 @@ int cf_time_steps(cf_ctx* ctx, int64_t first_step, int nsteps, const cf_run_sche
                   const cf_atmos_source* src /* levels / fraction are overridden per step */,
                   const cf_interp_weights* w, const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice,
                   const cf_net_ocean_fluxes* net);
+
+/* Builds the flux solver's schedule for `mask` (the cost-balanced chunk table and the wet lists, three tiny kernels and
+ * two 4-byte read-backs) ahead of the first step instead of inside it.  Optional: cf_compute_atmosphere_ocean_fluxes,
+ * cf_update_state and cf_time_steps build it on first use and whenever the mask pointer, its kind or the surface z
+ * changes.  A mask rewritten in place keeps the old schedule: slower at worst, never wrong.                          */
+int cf_ensure_chunk_table(cf_ctx* ctx, const void* mask);
+
+/* Which kernels cf_update_state launches for the context's current formulation and options (a measurement aid:
+ * bench.py names the dominant kernel and its algorithmic bytes from it).  *lean_kernel = 1: the round-3 ocean kernel
+ * (coflux_solver_lean.hip), 0: the general solver; *fused_net = 1: the solver's epilogue also writes the cell-local net
+ * ocean fluxes and a face-stress kernel follows, 0: compute_net_ocean_fluxes! is its own launch.                     */
+int cf_solver_path(cf_ctx* ctx, int* lean_kernel, int* fused_net);
 
 /* The pipelined form of update_state! for callers that drive the steps themselves: start the interpolation of the
  * NEXT step's atmosphere state into `out` on the auxiliary stream now; the next cf_update_state whose (levels, time

@@ -27,9 +27,27 @@ for name in ("FETCH_SIZE","WRITE_SIZE"):
 open("$OUT/pmc_traffic_raw.json","w").write(json.dumps(res,indent=1))
 print(json.dumps(res,indent=1))
 PY
-rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+# FP64-issue side: VALU instructions and busy cycles per launch (one SQ pass, counters only)
+(cd /tmp && rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -d $OUT/pmc_SQ -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --repetitions 1 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1)
+(cd /tmp && rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/pmc_SQ2 -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --repetitions 1 --no-cpu-baseline > $OUT/pmc_SQ2.log 2>&1)
+python - <<PY
+import csv,glob,collections,json
+res=collections.defaultdict(dict)
+for d in ("pmc_SQ","pmc_SQ2"):
+    for f in glob.glob("$OUT/%s/**/*counter_collection.csv"%d, recursive=True):
+        agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(collections.Counter)
+        for r in csv.DictReader(open(f)):
+            k=r["Kernel_Name"].split("(")[0].replace("void coflux::","").replace("coflux::","")
+            agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[k][r["Counter_Name"]]+=1
+        for k in agg:
+            for c in agg[k]: res[k][c]=agg[k][c]/cnt[k][c]
+            res[k]["launches"]=max(cnt[k].values())
+open("$OUT/pmc_sq_raw.json","w").write(json.dumps(res,indent=1))
+print(json.dumps({k:v for k,v in res.items() if "ao_" in k or "interp" in k or "net_" in k},indent=1))
+PY
+rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ $OUT/pmc_SQ2
 for f in bench bench_steps20 bench_corrected bench_ncar bench_slab70 bench_profiled; do python -c "
 import json,sys
 d=json.load(open('$OUT/$f.json')); r=d['roofline']
-print('$f', 'ms/step %.4f'%d['ms_per_step'], 'value %.3e'%d['value'], 'ao %.4f frac %.4f nohint %s'%(r['avg_launch_ms'], r['frac'], r.get('avg_launch_ms_without_hints')), 'cpu', (d.get('cpu_baseline') or {}).get('value'))"; done
+print('$f', 'ms/step %.4f'%d['ms_per_step'], 'value %.3e'%d['value'], 'ao %.4f frac %.4f sorted %s'%(r['avg_launch_ms'], r['frac'], r.get('avg_launch_ms_batches_sorted_by_trip_hints')), 'cpu', (d.get('cpu_baseline') or {}).get('value'), 'parity', (d.get('parity_measured') or {}).get('max'))"; done
 head -8 $OUT/kernel_stats.csv | cut -c1-160
