@@ -71,6 +71,8 @@ def parse():
                          "tried (peer-direct through HIP IPC; RCCL refuses duplicate devices).  The line is marked "
                          "'rehearsal' and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sorted-pass", action="store_true",
+                    help="skip the informational pass with CF_OPT_TRIP_HINTS = 1 (profiling runs: only the default configuration's launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample: passes that fit this wall time")
     return ap.parse_args()
 
@@ -396,7 +398,7 @@ def main():
     # CF_OPT_TRIP_HINTS: 2 = the library's default (what the timed region ran), 1 = every solver orders its batches by
     # the previous call's trip counts (round 2's default; reported beside it)
     prof = instrumented(n_prof, 2) if a.config == "ocean" and best != "torch" else None
-    prof_sorted = instrumented(n_prof, 1) if prof else None
+    prof_sorted = instrumented(n_prof, 1) if prof and not a.no_sorted_pass else None
     ctx.set_option(abi.OPT_TRIP_HINTS, 2)
 
     if rank == 0:

@@ -16,8 +16,8 @@ compute_atmosphere_ocean_fluxes! → compute_net_ocean_fluxes!, all inside libco
 The net fluxes land in the ocean's top-boundary-condition fields exactly where the reference puts
 them (model.interfaces.net_fluxes.ocean.{u,v,T,S}, omip_diagnostics.jl:77-80).
 
-There is no JRA55 file reader here (NetCDF staging is SURVEY §8f "next"): the atmosphere holds a
-window of snapshots in HBM that the caller fills (synthetic in tests/bench).
+The atmosphere holds a window of snapshots in HBM filled from a provider: synthetic in tests/bench, or the raw
+Float32 plane files of coflux/jra55.py (`omip_forcing`; NetCDF decoding itself is not possible in this image).
 """
 from dataclasses import dataclass, field
 from types import SimpleNamespace
@@ -61,6 +61,82 @@ class LatitudeLongitudeGrid:
         nx, ny, _ = self.size
         hx, hy, _ = self.halo
         return synthetic.latlon_fractional_indices(nx, ny, hx, hy, latitude=self.latitude, nsx=nsx, nsy=nsy)
+
+    fold_north = False
+
+    def interpolation_weights(self, to_device, nsx=synthetic.JRA55_NX, nsy=synthetic.JRA55_NY):
+        """cf_interp_weights for this grid: separable fractional indices into the JRA55 grid (no rotation)."""
+        fi, fj, phi = self.fractional_indices(nsx, nsy)
+        return dict(separable=True, fi=to_device(fi), fj=to_device(fj), latitude=to_device(phi))
+
+
+@dataclass
+class TripolarGrid:
+    """TripolarGrid(arch; size = (360, 180, Nz), halo = (5, 5, 4), z, …) — OceanConfigurations/one_degree_tripolar.jl:32,48-51
+    (1°), half_degree_tripolar.jl:48-51 (720×360), sixth_degree_tripolar.jl:33-36 (2160×1080, halo 7), tenth_degree… (3600×1800).
+    Only what the surface path needs: cell-centre positions → general (2-D) fractional indices into the JRA55 grid, the
+    rotation of the grid's i-axis against geographic east (visualize/cache.jl:406-427: the winds are rotated into the
+    grid frame) and the north fold (the last row of tracer points is its own mirror image; Oceananigans' zipper
+    boundary).  The mesh itself comes from `synthetic.tripolar_mesh` (a bipolar cap with the real fold topology) unless
+    `longitude` / `latitude` / rotation arrays of the real grid are handed in."""
+    size: tuple = (360, 180, 10)
+    halo: tuple = (5, 5, 4)
+    z: tuple = (-3000.0, 0.0)
+    southernmost_latitude: float = -80.0
+    first_pole_longitude: float = 75.0
+    north_poles_latitude: float = 55.0
+    device: int = 0
+    longitude: Optional[np.ndarray] = None     # (ny, nx) cell-centre λ [deg] of a real grid (else synthetic)
+    latitude: Optional[np.ndarray] = None      # (ny, nx) cell-centre φ [deg]
+    cos_rotation: Optional[np.ndarray] = None
+    sin_rotation: Optional[np.ndarray] = None
+
+    fold_north = True
+
+    @property
+    def surface_shape(self):
+        (nx, ny, _), (hx, hy, _) = self.size, self.halo
+        return (ny + 2 * hy, nx + 2 * hx)
+
+    @property
+    def surface_z(self):
+        nz = self.size[2]
+        dz = (self.z[1] - self.z[0]) / nz
+        return self.z[1] - 0.5 * dz
+
+    def mesh(self):
+        nx, ny, _ = self.size
+        if self.longitude is not None:
+            if self.latitude is None or self.cos_rotation is None or self.sin_rotation is None:
+                raise ValueError("TripolarGrid: longitude, latitude, cos_rotation and sin_rotation come together")
+            return self.longitude, self.latitude, self.cos_rotation, self.sin_rotation
+        return synthetic.tripolar_mesh(nx, ny, southernmost_latitude=self.southernmost_latitude,
+                                       cap_latitude=self.north_poles_latitude, pole_longitude=self.first_pole_longitude)
+
+    def interpolation_weights(self, to_device, nsx=synthetic.JRA55_NX, nsy=synthetic.JRA55_NY, rows=2):
+        """General weights + rotation, halo-inclusive: periodic in x, the north halo rows are the fold images of the
+        interior rows (their i-axis points the other way: rotation reversed), as synthetic.tripolar_case builds them."""
+        (nx, ny, _), (hx, hy, _) = self.size, self.halo
+        lam, phi, cos_t, sin_t = self.mesh()
+
+        def halo2d(a):
+            g = np.empty((ny + 2 * hy, nx + 2 * hx))
+            g[hy:hy + ny, hx:hx + nx] = a
+            g[:hy] = g[hy:hy + 1]
+            g[hy + ny:] = g[hy + ny - 1:hy + ny]
+            g[:, :hx], g[:, hx + nx:] = g[:, nx:nx + hx], g[:, hx:2 * hx]
+            return g
+        LAM, PHI, COS, SIN = (halo2d(a) for a in (lam, phi, cos_t, sin_t))
+        r = min(rows, hy)
+        for a in (LAM, PHI, COS, SIN):
+            synthetic.fold_north(a, nx, ny, hx, hy, r, "center", 1)
+        COS[hy + ny:hy + ny + r] *= -1.0
+        SIN[hy + ny:hy + ny + r] *= -1.0
+        fi = LAM / (360.0 / nsx)
+        fj = (PHI - synthetic.JRA55_LAT0) / (2 * 89.57 / (nsy - 1))
+        c = np.ascontiguousarray
+        return dict(separable=False, fi=to_device(c(fi)), fj=to_device(c(fj)), cos_rot=to_device(c(COS)), sin_rot=to_device(c(SIN)),
+                    latitude=to_device(c(PHI)))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -266,6 +342,7 @@ class Radiation:
     atmosphere.jl:41-44 (the downwelling fields themselves ride in the atmosphere window)."""
     ocean_surface: ic.SurfaceRadiationProperties = field(default_factory=ic.SurfaceRadiationProperties)
     stefan_boltzmann_constant: float = 5.67e-8
+    sea_ice_surface: Optional[ic.SurfaceRadiationProperties] = None   # SurfaceRadiationProperties(SeaIceAlbedo(hi, hs, Ts), 1.0)
 
 
 JRA55PrescribedRadiation = Radiation
@@ -331,8 +408,8 @@ class ComponentInterfaces:
                                 stefan_boltzmann_constant=self.radiation.stefan_boltzmann_constant)
         self.context = FluxContext(nx, ny, hx, hy, params, ring=1, device=grid.device)
         ctx = self.context
-        fi, fj, phi = grid.fractional_indices()
-        self.weights = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj), latitude=ctx.to_device(phi))
+        self.weights = grid.interpolation_weights(ctx.to_device)
+        self.fold_north = bool(getattr(grid, "fold_north", False))
         self.exchange_atmosphere_state = ctx.field_set(EXCHANGE_NAMES)
         fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL if store_similarity_scales else ())
         self.atmosphere_ocean_interface = SimpleNamespace(fluxes=SimpleNamespace(**fluxes), _fields=fluxes)
@@ -383,6 +460,61 @@ class OceanSeaIceModel:
         update_state(self)
 
 
+def omip_forcing(arch, sea_ice, *, forcing_dir, start_date, end_date, repeat_year_forcing=False, backend_size=30, device=0):
+    """omip_forcing(arch, sea_ice; forcing_dir, start_date, end_date, repeat_year_forcing = false, backend_size = 30)
+    — /root/reference/src/OMIPConfigurations/atmosphere.jl:13-49: the prescribed forcing components of an OMIP-2
+    simulation.  Returns `(atmosphere, radiation, land)`: the JRA55-do atmosphere on a sliding window of `backend_size`
+    snapshots with prefetch, the downwelling radiation with the OMIP-2 ocean surface (albedo 0.06, emissivity 1) and
+    the CCSM3 `SeaIceAlbedo(hi, hs, Ts)` over ice, and the land freshwater (river runoff + iceberg calving).
+    `arch` is accepted for signature parity (the device is `device`).  Files: raw Float32 planes, see coflux/jra55.py."""
+    from . import jra55
+    dataset = jra55.RepeatYearJRA55(year=start_date.year) if repeat_year_forcing else jra55.MultiYearJRA55()
+    calendar = jra55.SnapshotCalendar(dataset, start_date, end_date)
+    files = jra55.RawPlaneFiles(forcing_dir)
+    atmosphere = JRA55PrescribedAtmosphere(provider=jra55.atmosphere_provider(forcing_dir, calendar, files), total_snapshots=calendar.total,
+                                           time_indices_in_memory=backend_size, prefetch=True, cyclic=dataset.cyclic, device=device)
+    atmosphere.dataset, atmosphere.calendar = dataset, calendar
+    sea_ice_albedo = ic.SeaIceAlbedo() if sea_ice is not None else None   # SeaIceAlbedo(hi, hs, Ts): reads the live ice fields
+    radiation = Radiation(ocean_surface=ic.SurfaceRadiationProperties(0.06, 1.00),
+                          sea_ice_surface=ic.SurfaceRadiationProperties(sea_ice_albedo, 1.0) if sea_ice is not None else None)
+    land = JRA55PrescribedLand(jra55.land_snapshots(forcing_dir, calendar, 0, min(backend_size, calendar.total), files),
+                               time_indices_in_memory=min(backend_size, calendar.total), device=device)
+    return atmosphere, radiation, land
+
+
+def build_coupled_model(ocean, sea_ice, atmosphere, radiation, land, flux_configuration, *, velocity_formulation="relative",
+                        ocean_minimum_salinity=1):
+    """build_coupled_model(ocean, sea_ice, atmosphere, radiation, land, flux_configuration; velocity_formulation = :relative,
+    ocean_minimum_salinity = 1) — /root/reference/src/OMIPConfigurations/omip_simulation.jl:115-164, the same three-way
+    switch and the same error strings.  Options for `flux_configuration`: "default", "corrected", "ncar" (Julia symbols
+    as strings); for `velocity_formulation`: "relative", "wind"."""
+    flux_configuration = str(flux_configuration).lstrip(":")
+    velocity_formulation = str(velocity_formulation).lstrip(":")
+    albedo = getattr(getattr(radiation, "sea_ice_surface", None), "albedo", None)
+    common = dict(radiation=radiation, ocean_minimum_salinity=float(ocean_minimum_salinity),
+                  sea_ice_albedo=albedo if isinstance(albedo, ic.SeaIceAlbedo) else None)
+    if flux_configuration == "default":
+        interfaces = ComponentInterfaces(atmosphere, ocean, sea_ice, **common)
+        return OceanSeaIceModel(ocean, sea_ice, atmosphere=atmosphere, land=land, interfaces=interfaces)
+    if velocity_formulation == "relative":
+        velocity_difference = ic.RelativeVelocity()
+    elif velocity_formulation == "wind":
+        velocity_difference = ic.WindVelocity()
+    else:
+        raise ValueError(f"Unknown velocity_formulation: {velocity_formulation}. Options: :relative, :wind")
+    if flux_configuration == "corrected":
+        ao, ai = ic.corrected_atmosphere_ocean_fluxes(), ic.corrected_atmosphere_sea_ice_fluxes()
+    elif flux_configuration == "ncar":
+        ao, ai = ic.ncar_atmosphere_ocean_fluxes(), ic.ncar_atmosphere_sea_ice_fluxes()
+    else:
+        raise ValueError(f"Unknown flux_configuration: {flux_configuration}. Options: :default, :corrected, :ncar")
+    interfaces = ComponentInterfaces(atmosphere, ocean, sea_ice, atmosphere_ocean_fluxes=ao, atmosphere_sea_ice_fluxes=ai,
+                                     sea_ice_ocean_heat_flux=ic.corrected_ice_ocean_heat_flux() if sea_ice is not None else None,
+                                     atmosphere_ocean_velocity_difference=velocity_difference,
+                                     atmosphere_sea_ice_velocity_difference=velocity_difference, **common)
+    return OceanSeaIceModel(ocean, sea_ice, atmosphere=atmosphere, land=land, interfaces=interfaces)
+
+
 def OceanOnlyModel(ocean, *, atmosphere, **kw):
     """docs/src/index.md:64 alias."""
     return OceanSeaIceModel(ocean, None, atmosphere=atmosphere, **kw)
@@ -392,6 +524,12 @@ def update_state(model):
     """update_state!(coupled_model) — the accelerated path."""
     itf, atm = model.interfaces, model.atmosphere
     src, n1, n2, frac = atm.source(itf.context, model.clock.time)
+    if itf.fold_north:
+        # TripolarGrid: the north halo of the ocean surface state is the fold of its own rows (Oceananigans' zipper
+        # boundary fills it in the reference; here cf_fold_north_halo, ring + 1 rows: the solver's ring row reads v[j+1])
+        st = model.ocean.surface_state()
+        itf.context.fold_north_halo([st["T"], st["S"], st["u"], st["v"]],
+                                    [abi.FOLD_CENTER, abi.FOLD_CENTER, abi.FOLD_X_FACE, abi.FOLD_Y_FACE], [1.0, 1.0, -1.0, -1.0], rows=2)
     if getattr(model, "land", None) is not None:
         # JRA55PrescribedLand: river discharge + calving at the model time, handed to compute_net_ocean_fluxes!
         land = model.land

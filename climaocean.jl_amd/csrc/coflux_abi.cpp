@@ -287,6 +287,8 @@ static int install_params(cf_ctx* ctx, const cf_flux_params* params) {
     return CF_OK;
 }
 
+void cf_peer_forget_local(const char* mailbox);  // coflux_steps.cpp
+
 extern "C" {
 
 int cf_version(void) { return CF_ABI_VERSION; }
@@ -443,7 +445,10 @@ int cf_destroy(cf_ctx* ctx) {
     }
     if (ctx->peer_south_mapped) (void)hipIpcCloseMemHandle(ctx->peer.south);
     if (ctx->peer_north_mapped) (void)hipIpcCloseMemHandle(ctx->peer.north);
-    if (ctx->peer.mine) (void)hipFree(ctx->peer.mine);
+    if (ctx->peer.mine) {
+        cf_peer_forget_local(ctx->peer.mine);
+        (void)hipFree(ctx->peer.mine);
+    }
     if (ctx->d_peer_status) (void)hipFree(ctx->d_peer_status);
     if (ctx->d_trip) (void)hipFree(ctx->d_trip);
     if (ctx->d_trip_ice) (void)hipFree(ctx->d_trip_ice);

@@ -90,6 +90,13 @@ static int request_prefetch(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
     return CF_OK;
 }
 
+// cf_destroy: the mailbox of a context that goes away must not be handed to a later cf_peer_halo_connect of this process
+void cf_peer_forget_local(const char* mailbox) {
+    std::lock_guard<std::mutex> lock(g_peer_mutex);
+    for (auto it = g_peer_local.begin(); it != g_peer_local.end();)
+        it = it->second.first == mailbox ? g_peer_local.erase(it) : std::next(it);
+}
+
 extern "C" {
 
 // ---- peer-direct halo rows --------------------------------------------------------------------
@@ -104,10 +111,16 @@ int cf_peer_halo_export(cf_ctx* ctx, int max_fields, int max_rows, void* handle_
     const size_t slot = (size_t)max_fields * max_rows * ctx->grid.sj;
     const size_t bytes = PEER_FLAG_BYTES + 4 * slot * sizeof(double);
     void* p = nullptr;
-    // fine-grained: stores arriving over xGMI and the owner's polling loads must meet in memory, not in a cache
-    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-        (void)hipGetLastError();
-        HIP_TRY(ctx, hipMalloc(&p, bytes));
+    // fine-grained: stores arriving over xGMI and the owner's polling loads must meet in memory, not in a cache.
+    // Mandatory: on coarse-grained memory the flag poll can spin to its timeout and — worse — the rows read
+    // behind the flag can come from stale L2 lines, a silently wrong halo.  The caller falls back to the RCCL exchange.
+    {
+        const hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, CF_ERR_COMM, "cf_peer_halo_export: no fine-grained device memory for the halo mailbox (%s); use cf_halo_exchange_rows (RCCL)",
+                        hipGetErrorString(e));
+        }
     }
     HIP_TRY(ctx, hipMemset(p, 0, bytes));
     if (!ctx->d_peer_status) {
@@ -254,6 +267,12 @@ int cf_time_steps(cf_ctx* ctx, int64_t first_step, int nsteps, const cf_run_sche
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int n = 0; n < S->n_ocean_states; ++n) {
         if (ctx->dev.mask_kind != CF_MASK_NONE && !S->ocean_states[n].mask) return fail(ctx, CF_ERR_INVALID, "ocean state %d has no mask", n);
+        // one static wet mask per schedule: another mask pointer would make cf_update_state rebuild the solver's schedule
+        // INSIDE the step loop (a stream synchronisation behind a queued peer-direct halo kernel that waits for its
+        // neighbour, and a rebuild per step when states alternate: ADVICE r2)
+        if (S->ocean_states[n].mask != S->ocean_states[0].mask)
+            return fail(ctx, CF_ERR_INVALID, "cf_time_steps: ocean state %d carries a different mask pointer than state 0; the states of a "
+                        "schedule share one wet mask", n);
         if (n == 0) CHECK(cf_ensure_chunk_table(ctx, S->ocean_states[n].mask));
     }
     static const int fold_loc[4] = {CF_FOLD_CENTER, CF_FOLD_CENTER, CF_FOLD_X_FACE, CF_FOLD_Y_FACE};

@@ -503,7 +503,10 @@ int cf_compute_sea_ice_albedo(cf_ctx* ctx, const cf_sea_ice_albedo_params* param
 /* compute_sea_ice_ocean_fluxes!(coupled_model) with ThreeEquationHeatFlux(; friction_velocity =
  * MomentumBasedFrictionVelocity()) (omip_simulation.jl:71-77: "three-equation ice-ocean heat flux with momentum-based
  * friction velocity computed from actual ice-ocean stress, McPhee 1992, 2008") and frazil formation.  Per wet cell:
- *   u★   = max(√|τ_io|, u★_min),  τ_io the kinematic ice–ocean stress averaged from its faces to the cell centre;
+ *   u★   = max(√|τ_io|, u★_min),  τ_io the kinematic ice–ocean stress averaged from its faces to the cell centre:
+ *           cell (i, j) reads x_stress[i], x_stress[i+1], y_stress[j], y_stress[j+1], so the two stress fields need
+ *           their EAST x-halo column and NORTH halo row filled (periodic / slab exchange / tripolar fold) by whoever
+ *           produces them — cf_time_steps and the halo entry points only move T, S, u, v;
  *   frazil: T_o < T_f(S_o) = −m S_o  ⇒  Q_frazil = ρ_o c_o Δz (T_o − T_f)/Δt (< 0: heat the ice model must supply by
  *           freezing), and the exchange below sees T_o = T_f;
  *   three equations (Holland & Jenkins 1999; McPhee et al. 2008) for the interface (T_b, S_b) and melt rate w:
@@ -656,10 +659,12 @@ int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int
  * into the halo rows — one launch, no host round trip.  Mailboxes are double-buffered by sequence parity; a rank can
  * only write parity p again after its own step-(s+1) wait, which implies the neighbour has drained step s.
  *   cf_peer_halo_export   allocate this rank's mailbox for at most `max_fields` fields × `max_rows` rows, write its
- *                         IPC handle (CF_PEER_HANDLE_BYTES) — the host distributes handles (MPI / torch.distributed)
+ *                         IPC handle (CF_PEER_HANDLE_BYTES) — the host distributes handles (MPI / torch.distributed).
+ *                         Fails with CF_ERR_COMM when the device has no fine-grained memory to give (the protocol is
+ *                         not safe on coarse-grained memory): use the RCCL exchange then.
  *   cf_peer_halo_connect  map the south (rank−1) and north (rank+1) mailboxes; NULL at the ends of the slab ring.
- *                         `fold` != 0 on the LAST rank of a tripolar grid: its north boundary is the fold
- *                         (one_degree_tripolar.jl:48-51), served locally by cf_fold_north_halo, not by a peer.
+ *                         On the LAST rank of a tripolar grid the north handle is NULL too: its north boundary is the
+ *                         fold (one_degree_tripolar.jl:48-51), served locally by cf_fold_north_halo, not by a peer.
  *   cf_halo_exchange_rows_peer   the per-step exchange, same meaning as cf_halo_exchange_rows.
  * A spin that exceeds its bound sets a sticky error that the next cf_sync reports (CF_ERR_COMM).            */
 #define CF_PEER_HANDLE_BYTES 64

@@ -8,10 +8,10 @@ python bench.py --steps 20 --no-cpu-baseline > $OUT/bench_steps20.json 2>> $OUT/
 python bench.py --flux-configuration corrected --no-cpu-baseline > $OUT/bench_corrected.json 2>> $OUT/bench.err
 python bench.py --flux-configuration ncar --no-cpu-baseline > $OUT/bench_ncar.json 2>> $OUT/bench.err
 python bench.py --ny 70 --no-cpu-baseline > $OUT/bench_slab70.json 2>> $OUT/bench.err
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/kt.log)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-sorted-pass > $OUT/bench_profiled.json 2> $OUT/kt.log)
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --repetitions 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --repetitions 1 --no-cpu-baseline --no-sorted-pass > $OUT/pmc_$c.log 2>&1)
 done
 python - <<PY
 import csv,glob,collections,json
@@ -28,8 +28,8 @@ open("$OUT/pmc_traffic_raw.json","w").write(json.dumps(res,indent=1))
 print(json.dumps(res,indent=1))
 PY
 # FP64-issue side: VALU instructions and busy cycles per launch (one SQ pass, counters only)
-(cd /tmp && rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -d $OUT/pmc_SQ -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --repetitions 1 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1)
-(cd /tmp && rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/pmc_SQ2 -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --repetitions 1 --no-cpu-baseline > $OUT/pmc_SQ2.log 2>&1)
+(cd /tmp && rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -d $OUT/pmc_SQ -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --repetitions 1 --no-cpu-baseline --no-sorted-pass > $OUT/pmc_SQ.log 2>&1)
+(cd /tmp && rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/pmc_SQ2 -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --repetitions 1 --no-cpu-baseline --no-sorted-pass > $OUT/pmc_SQ2.log 2>&1)
 python - <<PY
 import csv,glob,collections,json
 res=collections.defaultdict(dict)

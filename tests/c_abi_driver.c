@@ -1,6 +1,7 @@
 /* c_abi_driver.c — exercises libcoflux exactly as a non-Python host (the Julia ccall stub) would:
  * plain C, device memory through cf_device_alloc / cf_h2d / cf_d2h, no torch.  Built and run by
- * tests/test_gpu_parity.py::test_c_driver_through_the_abi.  Prints "OK <checksum>" on success. */
+ * tests/test_gpu_parity.py::test_c_driver_through_the_abi.  Covers cf_update_state, the step loop cf_time_steps (a
+ * cf_run_schedule built in C) and the sea-ice interface (a cf_sea_ice_state built in C).  Prints "OK <checksum>". */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -101,6 +102,71 @@ int main(void) {
             sum += f[k];
         }
     if (!(first > 20.0 && first < 400.0)) { fprintf(stderr, "implausible latent heat %g\n", first); return 5; }
+    /* run!(simulation) in the library: three steps of cf_time_steps over the same uniform state must reproduce the
+     * single cf_update_state above (the uniform JRA55 planes make every time fraction equivalent) */
+    {
+        cf_run_schedule sch;
+        memset(&sch, 0, sizeof sch);
+        sch.struct_size = (int)sizeof sch;
+        sch.n_ocean_states = 1;
+        sch.ocean_states = &oc;
+        sch.n_atmos_sets = 1;
+        sch.atmos = &e;
+        sch.halo_backend = CF_HALO_NONE;
+        sch.time_fraction = 0.1;
+        sch.time_fraction_increment = 1.0 / 9.0;
+        double* again = malloc(n * 8);
+        memcpy(again, f, n * 8);
+        CHECK(cf_h2d(ctx, fl[1], T, n * 8)); /* garbage into the output the steps must overwrite */
+        CHECK(cf_time_steps(ctx, 0, 3, &sch, &src, &w, &fx, NULL, &net));
+        CHECK(cf_sync(ctx));
+        CHECK(cf_d2h(ctx, f, fl[1], n * 8));
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t k = (size_t)(j + h) * sj + (i + h);
+                if (fabs(f[k] - again[k]) > 1e-9 * fabs(first)) { fprintf(stderr, "cf_time_steps differs at %d %d: %g vs %g\n", i, j, f[k], again[k]); return 7; }
+            }
+        free(again);
+    }
+    /* compute_atmosphere_sea_ice_fluxes!: a cf_sea_ice_state passed by a C-compiled caller; uniform thin ice under the
+     * uniform atmosphere: every wet cell gets the same, finite skin temperature at or below the melting point */
+    {
+        cf_flux_params ip;
+        cf_sea_ice_params sp;
+        cf_default_flux_params(&ip);
+        CHECK(cf_default_sea_ice_params(&sp));
+        ip.momentum_roughness.kind = CF_ROUGHNESS_CONSTANT;
+        ip.momentum_roughness.constant_length = 5e-4;
+        ip.temperature_roughness.kind = CF_SCALAR_ROUGHNESS_CONSTANT;
+        ip.temperature_roughness.constant_length = 5e-5;
+        ip.water_vapor_roughness = ip.temperature_roughness;
+        CHECK(cf_set_sea_ice_formulation(ctx, &ip, &sp));
+        double *hi = malloc(n * 8), *ts = malloc(n * 8), *conc = malloc(n * 8);
+        for (size_t k = 0; k < n; ++k) { hi[k] = 0.3; ts[k] = -5.0; conc[k] = 0.9; }
+        DEV(dhi, hi, n * 8) DEV(dts, ts, n * 8) DEV(dconc, conc, n * 8)
+        cf_sea_ice_state st;
+        memset(&st, 0, sizeof st);
+        st.concentration = dconc;
+        st.thickness = dhi;
+        st.top_temperature = dts;
+        double* io[6];
+        for (int k = 0; k < 6; ++k) { io[k] = cf_device_alloc(ctx, n * 8); CHECK(cf_h2d(ctx, io[k], u, n * 8)); }
+        cf_interface_fluxes ix;
+        memset(&ix, 0, sizeof ix);
+        ix.sensible_heat = io[0]; ix.latent_heat = io[1]; ix.water_vapor = io[2];
+        ix.x_momentum = io[3]; ix.y_momentum = io[4]; ix.temperature = io[5];
+        CHECK(cf_compute_atmosphere_sea_ice_fluxes(ctx, &st, &oc, &e, &ix));
+        CHECK(cf_sync(ctx));
+        CHECK(cf_d2h(ctx, f, io[5], n * 8)); /* skin temperature [deg C] */
+        double skin = NAN;
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                size_t k = (size_t)(j + h) * sj + (i + h);
+                if (!mask[k]) continue;
+                if (isnan(skin)) skin = f[k];
+                if (!(f[k] <= 1e-9 && f[k] > -60.0) || fabs(f[k] - skin) > 1e-9) { fprintf(stderr, "sea-ice skin temperature %g (first %g)\n", f[k], skin); return 8; }
+            }
+    }
     /* error path: invalid parameters are refused with a message */
     cf_flux_params bad = p;
     bad.velocity_difference = 9;

@@ -80,12 +80,16 @@ ICE_FLUX_FIELDS = ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", 
                    "friction_velocity", "temperature_scale", "humidity_scale")
 
 
-def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=None, maxiter=100, tol_slow=1e-6, slow=40):
+def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=None, maxiter=100, tol_slow=1e-6, slow=40,
+                       orbit_shares=((1e-9, 0.97), (1e-6, 0.995), (1e-3, 0.999))):
     """Sea-ice interface comparison, same-shape windows.  The recalled skin-temperature balance does not contract for
     thick ice in wind (gain ≈ (h/k)·∂Q/∂T > 1, explicit and semi-implicit form alike): such cells orbit under the ±ΔTmax
-    limiter until `maxiter`, and the orbit amplifies rounding differences without bound.  Cells the reference leaves at
-    `maxiter` are therefore NOT compared in value — a loose tolerance there would be decoration, not parity —: both sides
-    must abandon the same cells and return finite numbers.  Cells that converge but need more than `slow` iterations (a
+    limiter until `maxiter`.  Most of those orbits are attracting cycles both sides land on — measured on the GPU
+    (scratch/orbit_cells.py): 98.9–99.6 % of the abandoned cells agree with the oracle to 1e-9, ≥ 99.8 % to 1e-6 — and a
+    few per ten thousand amplify rounding without bound (errors up to O(1)).  So the cells the reference leaves at
+    `maxiter` ARE compared in value, as a distribution: at least `orbit_shares` of them within each
+    tolerance, every one finite, and both sides must abandon the same cells.  A wrong Q_d, albedo or ℒ_s on thick ice
+    moves every one of them and fails the first share.  Cells that converge but need more than `slow` iterations (a
     weakly contracting orbit, ≈ 1.3× amplification per iteration) are held to the north star's `tol_slow` = 1e-6, every
     other cell to `tol_converged`; trip counts must be identical on all converged cells."""
     unconv = np.asarray(ref["iterations"]) >= maxiter
@@ -110,6 +114,16 @@ def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=None, maxiter=10
         if tol_unconverged is not None:
             assert worst[k][2] <= tol_unconverged, (k, worst[k])
         assert np.all(np.isfinite(g[unconv])), k
-    if tol_unconverged is None:   # orbiting cells are not compared in value: both sides must have given up on the same cells
+    if tol_unconverged is None:   # both sides must have given up on the same cells, and the bulk of them agrees in value
         assert np.array_equal(np.asarray(got["iterations"])[unconv], np.asarray(ref["iterations"])[unconv])
+        n = int(unconv.sum())
+        if n >= 50:
+            e = np.zeros(unconv.shape)
+            for k in ICE_FLUX_FIELDS:
+                g, r = np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64)
+                e = np.maximum(e, np.abs(g - r) / np.maximum(np.abs(r), FIELD_SCALE[k]))
+            for tol, share in orbit_shares:
+                have = float((e[unconv] <= tol).mean())
+                assert have >= share, ("abandoned cells within", tol, have, "needed", share, n)
+                worst["abandoned<=%g" % tol] = have
     return worst
