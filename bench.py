@@ -248,6 +248,10 @@ def main():
         ice_state = dict(concentration=ice["concentration"], **{k: ctx.to_device(si_np[k]) for k in ("thickness", "top_temperature", "u", "v", "albedo")})
         ai = ctx.field_set(FLUX_NAMES)
         net_ice = ctx.field_set(("top_heat", "bottom_heat"))
+        # the skin temperature the interface solve finds IS the sea-ice model's top_surface_temperature — the next step's
+        # first guess (atmosphere.jl:34-39; coflux/models.py::update_state): one buffer for both, as in a coupled run
+        ai["temperature"].copy_(ice_state["top_temperature"])
+        ice_state["top_temperature"] = ai["temperature"]
 
     # ---- halo rows: prove each backend on this machine before timing it ------------------------------
     # The synthetic state is a function of the GLOBAL cell index, so every rank knows what its neighbours' boundary

@@ -384,6 +384,7 @@ constexpr int SOLVER_ICE = 1;      // constant roughness lengths, U_G,min > 0
 constexpr int SOLVER_GENERIC = 2;  // anything else (runtime kinds, u★ = 0 guards)
 constexpr int SOLVER_LY = 3;       // CoefficientBasedFluxes: Large & Yeager iteration on (Cd, Ch, Ce)
 constexpr int SOLVER_SEAICE = 4;   // atmosphere–sea-ice interface: skin temperature inside the iteration (ice_iterate)
+constexpr int SOLVER_SEAICE_LEAN = 6;  // SOLVER_SEAICE with constant roughness lengths and U_G,min > 0 on ice_iterate_lean (coflux_lean.hpp)
 constexpr int SOLVER_OCEAN_LEAN = 5;  // SOLVER_OCEAN's configurations on the round-3 iteration body (mo_iterate_lean): the default
 
 using FastConsts = LoopParams;  // name kept for the launcher signatures

@@ -242,6 +242,150 @@ __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const Lea
     return Scales{us, ts, qq, it, it};
 }
 
+// ---------------------------------------------------------------------------------------------
+// Atmosphere–sea-ice interface on the lean primitives (SOLVER_SEAICE with constant roughness lengths and U_G,min > 0:
+// corrected_/ncar_atmosphere_sea_ice_fluxes, omip_simulation.jl:62-69,105-113).  The same iteration as ice_iterate
+// (coflux_fast.hpp) — skin temperature from the energy balance with the previous scales, limited to ±ΔTmax and capped
+// at the melting point, saturation over ice and the surface air's phase-equilibrium state at the new skin temperature,
+// then the similarity step — with everything that does not depend on the skin temperature hoisted (the three
+// log(h/ℓ), the roughness-length ψ arguments' factors, 1/p, 1/(ρ R_v)), one reciprocal for the three profile
+// denominators, 1/u★ from the wind scale's reciprocal square root, table exponentials, one Newton step per reciprocal.
+// Round 2's body re-derived the constant roughness lengths' exponentials and viscosities every iteration and spent
+// ≈ 510 instructions per iteration; this one ≈ 230.
+// ---------------------------------------------------------------------------------------------
+struct LeanIceConsts {
+    double rho, cp, qav, Ls, Ti, hk, Qd, theta_a, pa, inv_pa, inv_rho_Rv, dU2;
+};
+
+template <bool COARE>
+__device__ __forceinline__ Scales ice_iterate_lean(const DevParams& P, const LoopParams& L, const IceParams& I, const LeanIceConsts& c,
+                                                   const double* tab, bool active, double& Ts) {
+    const double* logt = tab + LOG_OFFSET;
+    double us = 1e-4, ius = 1e4, ts = 1e-4, qq = 1e-4, drift = __builtin_inf();
+    int it = 0, work = 0;
+    // the state two iterations ago: an exact period-2 orbit ends the iteration early (see ice_iterate)
+    // (1/u★ is part of the state here: the orbit is exact only if it repeats too)
+    double us_2 = -1.0, ius_2 = 0.0, ts_2 = 0.0, qq_2 = 0.0, Ts_2 = 0.0;
+    // iteration-invariant: log(h/ℓ) of the three constant roughness lengths, the lengths themselves
+    const double lgu = L.log_h - L.log_const_m, lgq = L.log_h - L.log_const_q, lgt = L.log_h - L.log_const_t;
+    const double lu = L.const_m, lq = fexp(L.log_const_q), lt = fexp(L.log_const_t);
+    const bool same_scalar = L.log_const_q == L.log_const_t;
+    const double dcp_i = P.cp_v - P.cp_i;
+    const double a_ice = dcp_i * P.inv_R_v, b_ice = (P.LH_s0 - dcp_i * P.T_0) * P.inv_R_v;
+    for (;;) {
+        const bool go = active && it < L.maxiter && !(drift < L.tol);
+        if (__ballot(go) == 0ull) break;
+        if (go) {
+            const double us_1 = us, ius_1 = ius, ts_1 = ts, qq_1 = qq, Ts_1 = Ts;  // state(it)
+            // skin temperature from the energy balance with the previous scales
+            const double T2 = Ts * Ts;
+            const double rho_u = c.rho * us;
+            double Tstar;
+            if (I.semi_implicit != 0.0) {
+                const double Qrest = -rho_u * c.Ls * qq - rho_u * c.cp * ts + c.Qd;
+                Tstar = __builtin_fma(-Qrest, c.hk, c.Ti) * frcp1(__builtin_fma(c.hk * I.eps_sigma, T2 * Ts, 1.0));
+            } else {
+                const double Qnet = -rho_u * c.Ls * qq + I.eps_sigma * T2 * T2 - rho_u * c.cp * ts + c.Qd;
+                Tstar = __builtin_fma(-Qnet, c.hk, c.Ti);
+            }
+            Tstar = (Tstar != Tstar) ? Ts : Tstar;
+            const double dT = fmin(fmax(Tstar - Ts, -I.dT_max), I.dT_max);
+            Ts = fmin(Ts + dT, I.T_melt);
+            const double inv_Ts = frcp1(Ts);
+            // saturation over ice and the phase-equilibrium saturation pressure at Ts: one logarithm, two table exponentials
+            const double Ll = flog_lean_end(flog_pos_begin(logt, Ts * P.inv_T_triple)), Dd = P.inv_T_triple - inv_Ts;
+            const double qs = (P.p_triple * fexp_tab(tab, __builtin_fma(a_ice, Ll, b_ice * Dd))) * (c.inv_rho_Rv * inv_Ts);
+            const double dq = c.qav - qs, dtheta = c.theta_a - Ts;
+            const double lam_s = liquid_fraction_fast(P, logt, Ts);
+            double pvs_s;
+            {
+                const double LH_0 = lam_s * P.LH_v0 + (1.0 - lam_s) * P.LH_s0;
+                const double dcp = lam_s * (P.cp_v - P.cp_l) + (1.0 - lam_s) * dcp_i;
+                pvs_s = P.p_triple * fexp_tab(tab, __builtin_fma(dcp * P.inv_R_v, Ll, ((LH_0 - dcp * P.T_0) * P.inv_R_v) * Dd));
+            }
+            // PhaseEquil_pTq(pa, Ts, qs): vapour and virtual temperature of the surface air (air_state_fast's relations)
+            const double tiny = 2.220446049250313e-16;
+            const double q = fmin(fmax(qs, 0.0), 1.0);
+            const double dp = c.pa - pvs_s;
+            const double q_vs_p = (dp >= tiny) ? P.Rd_over_Rv * (1.0 - q) * pvs_s * frcp1(dp) : 1.0 / tiny;
+            const double q_c0 = fmax(q - q_vs_p, 0.0);
+            const double inv_rho_s = P.R_d * (1.0 + P.delta * q - P.eps * q_c0) * Ts * c.inv_pa;
+            const double q_c = fmax(q - pvs_s * inv_rho_s * P.inv_R_v * inv_Ts, 0.0);
+            const double q_vap = fmax(0.0, q - lam_s * q_c - (1.0 - lam_s) * q_c);
+            const double Tv = (1.0 + P.delta * q - P.eps * q_c) * Ts;
+            const double kg = (L.kappa * P.g) * frcp1(Tv);
+            const double kb = kg * __builtin_fma(ts, 1.0 + P.delta * q_vap, (P.delta * Tv) * qq);  // κ b★
+            const double inv_L = kb * (ius * ius);
+            // wind speed scale with gustiness
+            double U, rU;  // rU = 1/(2U)
+            if (L.beta_gust != 0.0) {
+                const double w = fmax(-(us * kb) * L.gust_c, 1e-18);
+                sqrt_rsqrt_lean(c.dU2 + vmax_u(pow23_lean(w), L.min_gust2), U, rU);
+            } else {
+                sqrt_rsqrt_lean(c.dU2 + L.min_gust2, U, rU);
+            }
+            const double2 ps = psi_eval_pair(tab, psi_arg_x(__builtin_fma(L.x_scale, fabs(inv_L), 1.0), kb < 0.0));
+            double Du = lgu - ps.x, Dq = lgq - ps.y, Dt = lgt - ps.y;
+            if constexpr (!COARE) {
+                const double zu = lu * inv_L, zq = lq * inv_L, zt = lt * inv_L;
+                if (fabs(zu) < SMALL_Z0 && fabs(zq) < SMALL_Z0 && fabs(zt) < SMALL_Z0) {
+                    asm volatile("" ::: "memory");
+                    const double2 pl = psi_small_mh(tab, inv_L < 0.0, zu, zq);
+                    Du += pl.x;
+                    Dq += pl.y;
+                    Dt += same_scalar ? pl.y : psi_small_mh(tab, inv_L < 0.0, zu, zt).y;
+                } else {
+                    asm volatile("" ::: "memory");
+                    Du += psi_eval(tab, 0, psi_arg(zu));
+                    const double pq = psi_eval(tab, 1, psi_arg(zq));
+                    Dq += pq;
+                    Dt += same_scalar ? pq : psi_eval(tab, 1, psi_arg(zt));
+                }
+            }
+            Du = vmax_u(Du, L.profile_floor);
+            Dq = vmax_u(Dq, L.profile_floor);
+            Dt = vmax_u(Dt, L.profile_floor);
+            double iDu, iDq, iDt;
+            if (same_scalar) {  // (wave-uniform) D_t = D_q: one reciprocal for both profiles
+                const double r = frcp1(Du * Dq);
+                iDu = r * Dq;
+                iDq = iDt = r * Du;
+            } else {
+                const double DqDt = Dq * Dt;
+                const double r = frcp1(Du * DqDt);
+                iDu = r * DqDt;
+                iDq = r * (Du * Dt);
+                iDt = r * (Du * Dq);
+            }
+            const double un = (L.kappa * U) * iDu, tn = (L.kappa * iDt) * dtheta, qn = (L.kappa * iDq) * dq;
+            ius = (Du * rU) * L.two_inv_kappa;
+            drift = fabs(un - us) + fabs(tn - ts) + fabs(qn - qq);
+            us = un;
+            ts = tn;
+            qq = qn;
+            ++it;
+            work = it;
+            if (I.orbit_shortcut != 0.0 && us == us_2 && ius == ius_2 && ts == ts_2 && qq == qq_2 && Ts == Ts_2 && !(drift < L.tol)) {
+                // exact period 2: jump to the last iteration (an odd number of steps left lands on the other state of the orbit)
+                if ((L.maxiter - it) & 1) {
+                    us = us_1;
+                    ius = ius_1;
+                    ts = ts_1;
+                    qq = qq_1;
+                    Ts = Ts_1;
+                }
+                it = L.maxiter;
+            }
+            us_2 = us_1;
+            ius_2 = ius_1;
+            ts_2 = ts_1;
+            qq_2 = qq_1;
+            Ts_2 = Ts_1;
+        }
+    }
+    return Scales{us, ts, qq, it, work};
+}
+
 __device__ __forceinline__ CellFluxes lean_epilogue(const LeanCell& c, double T_offset, const Scales& s) {
     CellFluxes R;
     const double mu2 = -(s.us * s.us);

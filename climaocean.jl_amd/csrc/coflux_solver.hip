@@ -601,7 +601,7 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
             const int q = start + lane;
             const bool in_range = q < nwet;
             const int qc = in_range ? q : nwet - 1;
-            if constexpr (SPEC == SOLVER_SEAICE) {
+            if constexpr (SPEC == SOLVER_SEAICE || SPEC == SOLVER_SEAICE_LEAN) {
                 // ---- atmosphere–sea-ice interface: same list, same batches, the skin temperature inside the loop ----
                 const IceParams Ice = kread(&K->Ice);
                 IceConsts c;
@@ -640,7 +640,13 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
                     c.alpha_g = alpha * P.inv_g;
                     Ts = S.top_temperature[k] + Ice.T_offset;
                 }
-                const Scales s = ice_iterate<COARE>(P, L, Ice, c, tab, in_range, Ts);
+                Scales s;
+                if constexpr (SPEC == SOLVER_SEAICE_LEAN) {
+                    const LeanIceConsts lc{c.rho, c.cp, c.qav, c.Ls, c.Ti, c.hk, c.Qd, c.theta_a, c.pa, frcp1(c.pa), frcp1(c.rho * P.R_v), c.dU2};
+                    s = ice_iterate_lean<COARE>(P, L, Ice, lc, tab, in_range, Ts);
+                } else {
+                    s = ice_iterate<COARE>(P, L, Ice, c, tab, in_range, Ts);
+                }
                 if (in_range) {
                     SolverArgsPtr Ke = opaque(K);
                     const int idx2 = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
@@ -898,16 +904,18 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     A.wx_reciprocal = row_reciprocal(G.nx + 2 * G.ring);
     dim3 grid(L.n_chunks);
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
+    // constant roughness lengths and a gustiness floor (both production presets): the lean iteration body
+    const bool lean = C.specialization == SOLVER_ICE && L.solver == CF_SOLVER_TABLES;
+#define CF_AI_LAUNCH(COARE_, SPEC_, BLOCK_) \
+    hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, false, BLOCK_>), grid, dim3(BLOCK_), Geom<BLOCK_>::LDS_BYTES, st, A)
     if (L.ao_wide) {
-        if (coare)
-            hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE, false, AO_BLOCK_WIDE>), grid, dim3(AO_BLOCK_WIDE), Geom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);
-        else
-            hipLaunchKernelGGL((ao_flux_fast_kernel<false, SOLVER_SEAICE, false, AO_BLOCK_WIDE>), grid, dim3(AO_BLOCK_WIDE), Geom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);
-    } else if (coare) {
-        hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE, false, AO_BLOCK>), grid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, st, A);
+        if (lean) { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE_LEAN, AO_BLOCK_WIDE); else CF_AI_LAUNCH(false, SOLVER_SEAICE_LEAN, AO_BLOCK_WIDE); }
+        else { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE, AO_BLOCK_WIDE); else CF_AI_LAUNCH(false, SOLVER_SEAICE, AO_BLOCK_WIDE); }
     } else {
-        hipLaunchKernelGGL((ao_flux_fast_kernel<false, SOLVER_SEAICE, false, AO_BLOCK>), grid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, st, A);
+        if (lean) { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE_LEAN, AO_BLOCK); else CF_AI_LAUNCH(false, SOLVER_SEAICE_LEAN, AO_BLOCK); }
+        else { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE, AO_BLOCK); else CF_AI_LAUNCH(false, SOLVER_SEAICE, AO_BLOCK); }
     }
+#undef CF_AI_LAUNCH
     return hipGetLastError();
 }
 

@@ -462,7 +462,10 @@ int cf_default_sea_ice_params(cf_sea_ice_params* p);
 typedef struct cf_sea_ice_state {
     const double* concentration;    /* ℵ                                                             */
     const double* thickness;        /* hᵢ [m]                                                        */
-    const double* top_temperature;  /* previous skin temperature [°C]: initial guess of the iteration */
+    const double* top_temperature;  /* previous skin temperature [°C]: initial guess of the iteration.  May be the very buffer
+                                       cf_compute_atmosphere_sea_ice_fluxes writes the new one to (out->temperature): every
+                                       cell reads its guess before it writes its result — the in-place update of
+                                       sea_ice.model.ice_thermodynamics.top_surface_temperature in a coupled run          */
     const double* u;                /* ice velocity [m/s] or NULL (⇒ 0)                              */
     const double* v;
     const double* albedo;           /* per-cell albedo or NULL: then cf_set_sea_ice_albedo's scheme, else the constant */
