@@ -298,10 +298,11 @@ class FluxContext:
         self._check(self.lib.cf_ensure_chunk_table(self._h, _ptr(mask)), "cf_ensure_chunk_table")
 
     def solver_path(self):
-        """(lean_kernel, fused_net): which kernels cf_update_state launches for the current formulation and options."""
+        """(lean_kernel, fused): which kernels cf_update_state launches for the current formulation and options; fused = 0
+        three launches, 1 net fluxes in the solver's epilogue, 2 the interpolation in its prologue as well."""
         lean, fused = C.c_int(), C.c_int()
         self._check(self.lib.cf_solver_path(self._h, C.byref(lean), C.byref(fused)), "cf_solver_path")
-        return bool(lean.value), bool(fused.value)
+        return bool(lean.value), fused.value
 
     def time_copy(self, nbytes, launches=20):
         a = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)

@@ -506,6 +506,10 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             if (value < 0 || value > 2) return fail(ctx, CF_ERR_INVALID, "fused net fluxes %d: 0 (never), 1 (when possible), 2 (automatic)", value);
             ctx->fused_net = value;
             return CF_OK;
+        case CF_OPT_FUSED_INTERP:
+            if (value < 0 || value > 1) return fail(ctx, CF_ERR_INVALID, "fused interpolation %d: 0 (off), 1 (when possible)", value);
+            ctx->fused_interp = value;
+            return CF_OK;
         case CF_OPT_ICE_ORBIT_SHORTCUT:
             ctx->ice_orbit_shortcut = value != 0;
             ctx->ice_kernel.orbit_shortcut = value != 0 ? 1.0 : 0.0;
@@ -658,7 +662,9 @@ static bool net_fluxes_fused(const cf_ctx* ctx) {
 int cf_solver_path(cf_ctx* ctx, int* lean_kernel, int* fused_net) {
     if (!ctx || !lean_kernel || !fused_net) return fail(ctx, CF_ERR_INVALID, "cf_solver_path: bad arguments");
     *lean_kernel = ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
+    // 2: the interpolation is fused into the solver as well (cf_update_state without a pending prefetch)
     *fused_net = net_fluxes_fused(ctx) ? 1 : 0;
+    if (*fused_net && *lean_kernel && ctx->fused_interp != 0 && !ctx->launch.ao_wide) *fused_net = 2;
     return CF_OK;
 }
 
@@ -730,15 +736,20 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
         prefetched = p.level1 == src->level1 && p.level2 == src->level2 && p.tf == src->time_fraction;
         p.valid = false;
     }
-    if (!prefetched) HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
+    // Fused forms.  Net fluxes: the cell-local part of compute_net_ocean_fluxes! (everything but the two face stresses,
+    // which need the west / south neighbour's ρτ) is computed in the solver's epilogue from registers, and a thin stress
+    // kernel follows — bitwise the same numbers as the three-launch sequence (shared arithmetic, contraction off).
+    // Interpolation: the round-3 ocean kernel computes a batch's exchange fields in its prologue (the same per-cell
+    // routine as the stand-alone kernels: same bits) — update_state! is then two launches.
+    const bool fuse = net_fluxes_fused(ctx);
+    const bool fuse_interp = fuse && !prefetched && ctx->fused_interp != 0 && !ctx->launch.ao_wide &&
+                             ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
+    if (!prefetched && !fuse_interp) HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     CHECK(wait_for_halos(ctx));  // the interpolation above overlapped the halo rows
-    // Fused form: the cell-local part of compute_net_ocean_fluxes! (everything but the two face stresses, which
-    // need the west / south neighbour's ρτ) is computed in the solver's epilogue from registers, and a thin stress
-    // kernel follows — bitwise the same numbers as the three-launch sequence (shared arithmetic, contraction off).
-    const bool fuse = net_fluxes_fused(ctx);
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes,
-                                  fuse ? ice : nullptr, fuse ? net : nullptr, ctx->d_land_freshwater));
+                                  fuse ? ice : nullptr, fuse ? net : nullptr, ctx->d_land_freshwater,
+                                  fuse_interp ? src : nullptr, fuse_interp ? w : nullptr));
     // the next step's interpolation goes out behind the solver: its workgroups are dispatched first, the gather kernel
     // takes the registers and issue slots they leave free
     CHECK(cf_flush_deferred_prefetch(ctx));

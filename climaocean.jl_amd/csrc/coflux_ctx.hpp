@@ -53,6 +53,7 @@ struct cf_ctx {
     int* d_lean_info = nullptr;         // per chunk: listed wet cells + fingerprint (4 ints)
     bool trip_hints = true;
     bool lean_hints = false;         // the lean ocean kernel sorts its lists by trip count only when CF_OPT_TRIP_HINTS = 1
+    int fused_interp = 0;            // cf_update_state: the interpolation in the lean ocean kernel's prologue (0 off: measured slower; 1 when possible)
     int fused_net = 2;               // cf_update_state: net fluxes in the solver's epilogue + a stress kernel: 0 never, 1 when possible, 2 with the lean ocean kernel
     // cost-balanced chunk table of the solver, rebuilt when the wet mask (pointer / kind / surface z) changes
     int* d_chunk_sums = nullptr;

@@ -12,17 +12,12 @@
 // waves of a CU hide each other's load latency.
 #include <hip/hip_runtime.h>
 
-#include "coflux_kernel_types.hpp"
+#include "coflux_interp_cell.hpp"
 #include "coflux_kernels.h"
 
 namespace coflux {
 
 constexpr int IT_WAVES = 4;  // waves per workgroup (independent of each other)
-
-__device__ __forceinline__ int wrap_index(int i, int n) {
-    int r = i % n;
-    return r < 0 ? r + n : r;
-}
 
 // Wave-wide min / max as a wave-uniform value.  Four DPP steps (xor 1, xor 2, mirror within 8, mirror within 16)
 // leave every lane with its 16-lane row's result, then one lane per row is read: ≈ 10 short instructions, where the
@@ -41,16 +36,7 @@ __device__ __forceinline__ int wave_reduce(int v) {
 __device__ __forceinline__ int wave_min(int v) { return wave_reduce<true>(v); }
 __device__ __forceinline__ int wave_max(int v) { return wave_reduce<false>(v); }
 
-// The two halves of a cell's value, shared by every kernel in this file so that they agree bitwise: a source node's
-// two time levels are blended first (once per NODE in the tiled kernel: a tile has half as many nodes as it has cell
-// corners, and the f32→f64 conversions go with them), the four blended corners are interpolated second.  The
-// reference interpolates each level and blends last; the two orders differ by rounding (≈ 1e-16 relative).
-__device__ __forceinline__ double blend_levels(float a, float b, double tf) { return (double)b * tf + (double)a * (1.0 - tf); }
-__device__ __forceinline__ double bilinear(double w00, double w01, double w10, double w11, double c00, double c01, double c10,
-                                           double c11) {
-    return w00 * c00 + w01 * c01 + w10 * c10 + w11 * c11;
-}
-
+// (blend_levels, bilinear, the corner convention: coflux_interp_cell.hpp — shared with the solver's fused prologue)
 // LDS traffic of one wave is ordered by issue; this only stops the compiler from moving accesses.
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

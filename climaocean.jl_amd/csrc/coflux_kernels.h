@@ -33,7 +33,8 @@ hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc
 hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
                             const cf_interface_fluxes* f, const cf_sea_ice_fields* ice = nullptr,
-                            const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr);
+                            const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr,
+                            const cf_atmos_source* src = nullptr, const cf_interp_weights* w = nullptr);
 hipError_t launch_net_stress(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* n);
 hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks, bool wide,
@@ -41,7 +42,8 @@ hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const Grid
 hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32_t* d_wet_pos, const int* d_begins, uint32_t* d_sorted, int* d_info);
 hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
                                  const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
-                                 const cf_sea_ice_fields* ice = nullptr, const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr);
+                                 const cf_sea_ice_fields* ice = nullptr, const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr,
+                                 const cf_atmos_source* src = nullptr, const cf_interp_weights* w = nullptr);
 size_t wet_list_capacity(int ncells);
 int wet_list_stride(bool wide);
 hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,

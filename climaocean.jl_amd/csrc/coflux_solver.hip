@@ -849,11 +849,12 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
 hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
                             const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net,
-                            const double* land) {
+                            const double* land, const cf_atmos_source* src, const cf_interp_weights* w) {
     if (L.solver == CF_SOLVER_LIBM) return net ? hipErrorInvalidValue : launch_ao_fluxes_libm(st, P, G, o, e, f);
     // the production ocean configurations: the round-3 kernel
     if (C.specialization == SOLVER_OCEAN_LEAN && L.solver == CF_SOLVER_TABLES && L.d_lean_info)
-        return launch_ao_fluxes_lean(st, L, P, C, G, o, e, f, ice, net, land);
+        return launch_ao_fluxes_lean(st, L, P, C, G, o, e, f, ice, net, land, src, w);
+    if (src) return hipErrorInvalidValue;  // only the lean ocean kernel interpolates in its prologue
     OceanIn O = make_ocean(o);
     Exchange E = make_exchange(e);
     FluxOut F = make_fluxes(f);

@@ -19,6 +19,7 @@
 //     memory — one wave's work, while the CU's other workgroups are still iterating.
 #include <hip/hip_runtime.h>
 
+#include "coflux_interp_cell.hpp"
 #include "coflux_lean.hpp"
 #include "coflux_solver_shared.hpp"
 
@@ -63,6 +64,8 @@ struct LeanArgs {
     long long sort_enabled;   // CF_OPT_TRIP_HINTS
     IceIn I;                  // fused net fluxes only
     NetOut N;
+    SourceDesc S;             // fused interpolation only: the JRA55 window and the weights of interpolate_atmosphere_state!
+    WeightDesc Wt;
 };
 typedef const LeanArgs __attribute__((address_space(4)))* LeanArgsPtr;
 
@@ -99,8 +102,14 @@ static_assert(LeanGeom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow lean solver 
 static_assert(LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
 
 // zero_interface_state of a land cell: all fluxes 0, T = 0 K (and, in the fused form, zero net fluxes inside the interior)
-template <bool FUSE>
+template <bool FUSE, bool FUSE_INTERP = false>
 __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_offset, const GridDesc& G, LeanArgsPtr K, size_t k, int i, int j) {
+    if constexpr (FUSE_INTERP) {  // interpolate_atmosphere_state! fills the exchange fields of land cells too
+        const SourceDesc S = kread(&K->S);
+        const WeightDesc Wt = kread(&K->Wt);
+        const Exchange E = kread(&K->E);
+        store_exchange(E, k, interp_cell(S, Wt, G, i, j, k));
+    }
     CellFluxes Z{};
     Z.Ts_ocean = -T_offset;
     Z.iterations = L.fixed ? L.maxiter : 0;
@@ -117,7 +126,11 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 // FUSE: the cell-local part of compute_net_ocean_fluxes! (everything but the two face stresses, which need the west /
 // south neighbour's ρτ: launch_net_stress) in the epilogue — the same arithmetic as net_flux_kernel, bit for bit
 // (net_cell_local, contraction off).  With batches in index order its nine extra accesses per cell are coalesced.
-template <bool COARE, int BLOCK, bool FUSE>
+// FUSE_INTERP (with FUSE): interpolate_atmosphere_state! as well — a batch computes its cells' eight exchange fields
+// from the JRA55 window in its prologue (72 gathers per cell that hit L2 and ride the vector-memory pipe the FP64-bound
+// solver leaves idle), writes them (the API's outputs) and keeps what it needs in registers; land cells get theirs with
+// their zeros.  update_state! is then two launches: this kernel and the face stresses.
+template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false>
 __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_name) {
     using Geo = LeanGeom<BLOCK>;
     constexpr int CHUNK = Geo::CHUNK;
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
             hx ^= lean_mix((unsigned)idx);
             hy += lean_sum((unsigned)idx);
         } else {
-            lean_zero_cell<FUSE>(L, T_offset, G, opaque(K), k, idx - jj * wx - G.ring, jj - G.ring);
+            lean_zero_cell<FUSE, FUSE_INTERP>(L, T_offset, G, opaque(K), k, idx - jj * wx - G.ring, jj - G.ring);
         }
     }
     for (int d = 32; d; d >>= 1) {
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                 const int idx = range_begin + tid + n * BLOCK;
                 const int jj = row_of(idx, wx, wx_rcp);
                 const int i = idx - jj * wx - G.ring, j = jj - G.ring;
-                lean_zero_cell<FUSE>(L, T_offset, G, Kz, cell_index(G, i, j), i, j);
+                lean_zero_cell<FUSE, FUSE_INTERP>(L, T_offset, G, Kz, cell_index(G, i, j), i, j);
             }
     }
     int begin = range_begin, end = range_end;
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                     const int i = idx - jj * wx - G.ring, j = jj - G.ring;
                     const size_t k = cell_index(G, i, j);
                     wet = cell_is_wet(P, mask, k);
-                    if (!wet) lean_zero_cell<FUSE>(L, T_offset, G, opaque(K), k, i, j);
+                    if (!wet) lean_zero_cell<FUSE, FUSE_INTERP>(L, T_offset, G, opaque(K), k, i, j);
                 }
                 const unsigned long long m = __ballot(wet);
                 int wave_base = 0;
@@ -318,17 +331,25 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
             if (lane == 0) st = atomicAdd(&counters[0], 64);
             return __shfl(st, 0);
         };
-        auto cell_of = [&](int st) -> size_t {
+        auto coords_of = [&](int st, int& ci, int& cj) -> size_t {
             const int qq = min(st + lane, nwet - 1);
             const int idx = range_begin + (int)(list[qq] & LEAN_OFFSET_MASK);
             const int jj = row_of(idx, wx, wx_rcp);
-            return cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
+            ci = idx - jj * wx - G.ring;
+            cj = jj - G.ring;
+            return cell_index(G, ci, cj);
+        };
+        auto cell_of = [&](int st) -> size_t {
+            int ci, cj;
+            return coords_of(st, ci, cj);
         };
         struct Raw {
             double ua, va, Ta, pa, qa, u0, u1, v0, v1, To, So;
+            double Qs, Ql, Mp;  // FUSE_INTERP: kept for the net-flux epilogue
         };
         auto request = [&](int st) {
-            const size_t k = cell_of(st);
+            int ci, cj;
+            const size_t k = coords_of(st, ci, cj);
             LeanArgsPtr Kb = opaque(K);  // this batch's view of the arguments: pointers are (re)loaded here, scalar loads
             const double* __restrict__ Ou = Kb->O.u;
             const double* __restrict__ Ov = Kb->O.v;
@@ -337,13 +358,29 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
             r.u1 = Ou[k + 1];
             r.v0 = Ov[k];
             r.v1 = Ov[k + (size_t)G.sj];
-            r.ua = Kb->E.u[k];
-            r.va = Kb->E.v[k];
-            r.Ta = Kb->E.T[k];
-            r.pa = Kb->E.p[k];
-            r.qa = Kb->E.q[k];
             r.To = Kb->O.T[k];
             r.So = Kb->O.S[k];
+            if constexpr (FUSE_INTERP) {
+                const SourceDesc S = kread(&Kb->S);
+                const WeightDesc Wt = kread(&Kb->Wt);
+                const ExchangeCell e = interp_cell(S, Wt, G, ci, cj, k);
+                if (st + lane < nwet) store_exchange(kread(&Kb->E), k, e);
+                r.ua = e.u;
+                r.va = e.v;
+                r.Ta = e.T;
+                r.pa = e.p;
+                r.qa = e.q;
+                r.Qs = e.Qs;
+                r.Ql = e.Ql;
+                r.Mp = e.Mp;
+            } else {
+                r.ua = Kb->E.u[k];
+                r.va = Kb->E.v[k];
+                r.Ta = Kb->E.T[k];
+                r.pa = Kb->E.p[k];
+                r.qa = Kb->E.q[k];
+                r.Qs = r.Ql = r.Mp = 0.0;
+            }
             return r;
         };
         int start = claim();
@@ -357,6 +394,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                                              0.5 * (raw.v0 + raw.v1), raw.To, raw.So);
             // the interface temperature does not depend on the iteration: written now, not carried across it
             if (in_range) opaque(K)->F.Ts[cell_of(start)] = c.Ts - T_offset;
+            const double Qs_kept = raw.Qs, Ql_kept = raw.Ql, Mp_kept = raw.Mp;  // (dead unless FUSE_INTERP)
 #if CF_LEAN_PREFETCH
             const int next = claim();
             if (next < nwet) raw = request(next);
@@ -400,7 +438,8 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                         const NetOut N = kread(&Ke->N);
                         const double Ts_ocean = (Ke->O.T[k] + P.T_offset) - T_offset;  // what F.Ts holds (written before the iteration)
                         store_net_cell(N, k, net_cell_local(P, P.albedo, I.conc ? I.conc[k] : 0.0, Ke->O.S[k], Ts_ocean + P.T_offset,
-                                                            Ke->E.Mp[k], Ke->E.Qs[k], Ke->E.Ql[k], R.Qc, R.Qv, R.Fv,
+                                                            FUSE_INTERP ? Mp_kept : Ke->E.Mp[k], FUSE_INTERP ? Qs_kept : Ke->E.Qs[k],
+                                                            FUSE_INTERP ? Ql_kept : Ke->E.Ql[k], R.Qc, R.Qv, R.Fv,
                                                             I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0, I.land ? I.land[k] : 0.0));
                     }
                 }
@@ -507,7 +546,8 @@ hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32
 
 hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
                                  const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
-                                 const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land) {
+                                 const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land,
+                                 const cf_atmos_source* src, const cf_interp_weights* w) {
     if (!L.d_chunk_begins || L.n_chunks <= 0 || !L.d_lean_info) return hipErrorInvalidValue;
     LeanArgs A{};
     A.L = C;
@@ -534,6 +574,14 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
 #define CF_LEAN_LAUNCH(COARE_, BLOCK_, FUSE_) \
     hipLaunchKernelGGL((ao_lean_kernel<COARE_, BLOCK_, FUSE_>), dim3(L.n_chunks), dim3(BLOCK_), LeanGeom<BLOCK_>::LDS_BYTES, st, A)
+    if (src) {  // interpolation fused too (narrow geometry, with the fused net fluxes: launch_ao_fluxes checks)
+        if (!net || !w || L.ao_wide) return hipErrorInvalidValue;
+        A.S = make_source(src);
+        A.Wt = make_weights(w);
+        if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK, true, true>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK, true, true>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        return hipGetLastError();
+    }
     if (L.ao_wide) {
         if (net) {
             if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK_WIDE, true); else CF_LEAN_LAUNCH(false, AO_BLOCK_WIDE, true);

@@ -341,6 +341,12 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * round-3 ocean kernel runs — its batches are in index order, so the epilogue's nine extra
                                    * accesses per cell are coalesced: update_state 0.107 → 0.096 ms; in round 2's trip-sorted
                                    * kernels the same accesses were scattered and cost more than the net-flux kernel they save. */
+#define CF_OPT_FUSED_INTERP 8     /* 1: cf_update_state interpolates the atmosphere state in the round-3 ocean kernel's prologue
+                                   * instead of a launch of its own (same bits: one shared per-cell routine; needs the fused net
+                                   * fluxes, no pending prefetch) — update_state! in two launches.  0 (default): measured SLOWER
+                                   * on MI355X, 0.1007 vs 0.0956 ms per step: the 72 corner gathers per cell cost the solver's
+                                   * vector-memory address path more than the tiled kernel's 18 µs (which stages them in LDS the
+                                   * solver has no room for) and push 19 registers to scratch.                                 */
 #define CF_OPT_ICE_ORBIT_SHORTCUT 7 /* 1 (default): the atmosphere–sea-ice iteration stops as soon as its state repeats the state of two
                                      iterations ago bit for bit — an exact period-2 orbit, where the skin-temperature balance does not
                                      contract — and returns the iterate the remaining steps up to maxiter would end on (the same
@@ -732,7 +738,8 @@ int cf_ensure_chunk_table(cf_ctx* ctx, const void* mask);
 /* Which kernels cf_update_state launches for the context's current formulation and options (a measurement aid:
  * bench.py names the dominant kernel and its algorithmic bytes from it).  *lean_kernel = 1: the round-3 ocean kernel
  * (coflux_solver_lean.hip), 0: the general solver; *fused_net = 1: the solver's epilogue also writes the cell-local net
- * ocean fluxes and a face-stress kernel follows, 0: compute_net_ocean_fluxes! is its own launch.                     */
+ * ocean fluxes and a face-stress kernel follows (2: and interpolates the atmosphere state in its prologue), 0:
+ * compute_net_ocean_fluxes! is its own launch.                                                                       */
 int cf_solver_path(cf_ctx* ctx, int* lean_kernel, int* fused_net);
 
 /* The pipelined form of update_state! for callers that drive the steps themselves: start the interpolation of the

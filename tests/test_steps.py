@@ -239,6 +239,25 @@ def test_fused_net_epilogue_is_bitwise_the_three_launch_sequence():
     ctx.close()
 
 
+def test_fused_interpolation_prologue_is_bitwise_the_separate_launch():
+    """CF_OPT_FUSED_INTERP = 1: interpolate_atmosphere_state! inside the round-3 ocean kernel's prologue (land cells
+    included) == the tiled interpolation kernel + solver, bit for bit on every exchange, flux and net field."""
+    ctx, states, src, w, np_states = _setup()
+    ice = {k: ctx.to_device(np_states[0]["ice_" + k]) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")}
+    outs = []
+    for fused in (0, 1):
+        ctx.set_option(abi.OPT_FUSED_INTERP, fused)
+        assert ctx.solver_path() == (True, 2 if fused else 1)
+        a, fl, net = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+        ctx.update_state(src, w, states[0], a, fl, net, ice=ice, time_fraction=0.37)
+        ctx.sync()
+        outs.append((a, fl, net))
+    for grp, names in enumerate((EXCHANGE_NAMES, FLUX_NAMES, NET_NAMES)):
+        for k in names:
+            assert torch.equal(outs[0][grp][k], outs[1][grp][k]), k
+    ctx.close()
+
+
 def _two_device_worker(rank, world, port, backend, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
