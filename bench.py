@@ -504,6 +504,19 @@ def main():
                 note=("peak = 1024 SIMDs x 2.4 GHz / 4 cycles per FP64 wave-instruction; under this load the device clocks at "
                       "about 1.9-2.0 GHz (scratch/ubench_valu.hip: 480 G wave-instr/s of v_fma_f64 sustained), so frac <= 0.80 is the "
                       "practical ceiling; every VALU instruction is counted at the FP64 rate"))
+        # strong-scaling projection from single-GPU measurements of one rank's slab (scratch/slab_curve.py): a PROJECTION,
+        # labelled as such — the driver computes the real curve from its own N-GPU runs
+        try:
+            sc = json.load(open(os.path.join(ROOT, "profiles", "r03_slab_curve.json")))
+            if canonical and world == 1:
+                out["projected_scaling"] = dict(
+                    kind="projection from one GPU, not a multi-GPU measurement",
+                    speedup_before_halo_rows={k: round(v, 3) for k, v in sc["projected_speedup_before_halos"].items()},
+                    slab_ms_per_step={k: round(v["ms_per_step"], 5) for k, v in sc["slabs"].items()},
+                    source="committed: profiles/r03_slab_curve.json (python bench.py --ny 560/280/140/70 on one MI355X)",
+                    note=sc["note"])
+        except Exception:
+            pass
         if a.share_device:
             out["rehearsal"] = f"{world} ranks time-sharing ONE device: a test of the N-rank code path, not a scaling number"
         if not a.no_cpu_baseline and world == 1:

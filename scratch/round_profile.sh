@@ -46,6 +46,10 @@ open("$OUT/pmc_sq_raw.json","w").write(json.dumps(res,indent=1))
 print(json.dumps({k:v for k,v in res.items() if "ao_" in k or "interp" in k or "net_" in k},indent=1))
 PY
 rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ $OUT/pmc_SQ2
+python scratch/slab_curve.py $TAG > $OUT/slab_curve.log 2>&1
+python bench.py --config sea_ice --no-cpu-baseline > $OUT/bench_sea_ice.json 2>> $OUT/bench.err
+python bench.py --grid tripolar --nx 2160 --ny 1080 --flux-configuration corrected --no-cpu-baseline --no-sorted-pass > $OUT/bench_tripolar_2160x1080.json 2>> $OUT/bench.err
+python bench.py --grid tripolar --nx 360 --ny 180 --flux-configuration corrected --no-cpu-baseline --no-sorted-pass > $OUT/bench_tripolar_360x180.json 2>> $OUT/bench.err
 for f in bench bench_steps20 bench_corrected bench_ncar bench_slab70 bench_profiled; do python -c "
 import json,sys
 d=json.load(open('$OUT/$f.json')); r=d['roofline']
