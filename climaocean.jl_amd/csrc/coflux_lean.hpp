@@ -78,6 +78,22 @@ __device__ __forceinline__ double vmin_u(double x, double bound) {
 // pressures (a third of fexp's instructions)
 __device__ __forceinline__ double fexp_tab5(const double* tab, double x) { return fexp_tab(tab, x); }
 
+// liquid_fraction_fast / svp_equil_from with the table exponential: fexp's twelve Taylor coefficients are literals the
+// compiler materialises ahead of the batch loop and then keeps in SCRATCH across the iteration (measured: 12 spilled
+// registers reloaded in every prologue); the table form has none.
+__device__ __forceinline__ double liquid_fraction_lean(const DevParams& P, const double* tab, double T) {
+    const double r = (T - P.T_icenuc) * P.inv_icenuc_span;
+    double ramp = r;
+    if (P.pow_icenuc != 1.0) ramp = r > 0.0 ? fexp_tab(tab, P.pow_icenuc * flog(tab + LOG_OFFSET, r)) : 0.0;
+    return T > P.T_freeze ? 1.0 : (T > P.T_icenuc ? ramp : 0.0);
+}
+__device__ __forceinline__ double svp_equil_lean(const DevParams& P, const double* tab, const SvpArg& s, double lam) {
+    const double LH_0 = lam * P.LH_v0 + (1.0 - lam) * P.LH_s0;
+    const double dcp = lam * (P.cp_v - P.cp_l) + (1.0 - lam) * (P.cp_v - P.cp_i);
+    const double a = dcp * P.inv_R_v, b = (LH_0 - dcp * P.T_0) * P.inv_R_v;
+    return P.p_triple * fexp_tab(tab, __builtin_fma(a, s.L, b * s.D));
+}
+
 // Per-cell, iteration-invariant state of the lean ocean path: what the iteration reads, and what the epilogue needs to
 // turn the converged scales into fluxes (five numbers instead of the seven of CellConsts: ρ and 1/‖Δu‖ are folded in).
 struct LeanCell {
@@ -101,7 +117,7 @@ __device__ __forceinline__ LeanCell lean_prologue(const DevParams& P, double kap
     const double inv_p = frcp1(pa);
     const double tiny = 2.220446049250313e-16;
     // ---- air at the reference height: PhaseEquil_pTq(pa, Ta, qa) ----
-    const double lam_a = liquid_fraction_fast(P, logt, Ta);
+    const double lam_a = liquid_fraction_lean(P, tab, Ta);
     const SvpArg arg_a = svp_arg(P, logt, Ta, inv_Ta);
     double pvs_a;
     {
@@ -146,9 +162,9 @@ __device__ __forceinline__ LeanCell lean_prologue(const DevParams& P, double kap
         inv_dU = moving ? 2.0 * __builtin_fma(h0, e, h0) : 0.0;
     }
     // PhaseEquil_pTq(pa, Ts, qs): virtual temperature and vapour of the surface air
-    const double lam_s = liquid_fraction_fast(P, logt, Ts);
+    const double lam_s = liquid_fraction_lean(P, tab, Ts);
     double pvs_s = pstar_s;  // (water below 0 °C — polar cells only: worth a wave-level branch, and the logarithm is shared)
-    if (__any(lam_s != 1.0)) pvs_s = (lam_s == 1.0) ? pstar_s : svp_equil_from(P, arg_s, lam_s);
+    if (__any(lam_s != 1.0)) pvs_s = (lam_s == 1.0) ? pstar_s : svp_equil_lean(P, tab, arg_s, lam_s);
     const double qss = fmin(fmax(qs, 0.0), 1.0);
     const double dp_s = pa - pvs_s;
     const double qvsp_s = (dp_s >= tiny) ? P.Rd_over_Rv * (1.0 - qss) * pvs_s * frcp1(dp_s) : 1.0 / tiny;
