@@ -200,14 +200,18 @@ __device__ __forceinline__ LeanCell lean_prologue(const DevParams& P, double kap
 template <bool COARE>
 __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const LeanCell& c, const double* tab, bool active) {
     const double* logt = tab + LOG_OFFSET;
-    double us = 1e-4, ius = 1e4, ts = 1e-4, qq = 1e-4;
+    // θ★ = χ Δθ and q★ = χ Δq share one transfer coefficient χ = κ / D_q from the first iterate on (one scalar
+    // roughness length, one stability function), so the state is (u★, 1/u★, χ) and κ b★ = χ·(bθ Δθ + b_q Δq); the drift of
+    // the two scalars is |Δχ|·(|Δθ| + |Δq|).  Five FP64 instructions per iteration fewer; the first iterate, which starts
+    // from θ★ = q★ = 1e-4, takes the general expressions (a wave-uniform branch: every running lane has the same count).
+    const double B = __builtin_fma(c.dtheta, c.bth, c.bqq * c.dq), S = fabs(c.dtheta) + fabs(c.dq);
+    double us = 1e-4, ius = 1e4, chi = 0.0, kb = __builtin_fma(1e-4, c.bth, c.bqq * 1e-4);
     double drift = __builtin_inf();
     int it = 0;
-    for (;;) {
+    for (int trip = 0;; ++trip) {
         const bool go = active && it < L.maxiter && !(drift < L.tol);
         if (__ballot(go) == 0ull) break;  // the wave leaves the loop together
         if (go) {
-            const double kb = __builtin_fma(ts, c.bth, c.bqq * qq);
             const double inv_L = kb * (ius * ius);  // 1/L★ = κ b★ / u★²
             const double lu = vmin_u(__builtin_fma(c.alpha_g * us, us, c.lam_nu * ius), L.lm_m);
             const LogHalf half_u = flog_pos_begin(logt, lu);
@@ -245,17 +249,18 @@ __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const Lea
             Dq = vmax_u(Dq, L.profile_floor);
             const double r = frcp1(Du * Dq);
             const double un = (L.kappa * U) * (r * Dq);
-            const double chi = L.kappa * (r * Du);
-            const double tn = chi * c.dtheta, qn = chi * c.dq;
+            const double chi_n = L.kappa * (r * Du);
             ius = (Du * rU) * L.two_inv_kappa;  // 1/u★ = D_u / (κ U)
-            drift = fabs(un - us) + fabs(tn - ts) + fabs(qn - qq);
+            if (trip == 0) drift = fabs(un - us) + fabs(chi_n * c.dtheta - 1e-4) + fabs(chi_n * c.dq - 1e-4);
+            else drift = __builtin_fma(fabs(chi_n - chi), S, fabs(un - us));
+            kb = chi_n * B;
             us = un;
-            ts = tn;
-            qq = qn;
+            chi = chi_n;
             ++it;
         }
     }
-    return Scales{us, ts, qq, it, it};
+    const bool moved = it > 0;
+    return Scales{us, moved ? chi * c.dtheta : 1e-4, moved ? chi * c.dq : 1e-4, it, it};
 }
 
 // ---------------------------------------------------------------------------------------------

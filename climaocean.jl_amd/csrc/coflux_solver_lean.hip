@@ -353,13 +353,14 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
             LeanArgsPtr Kb = opaque(K);  // this batch's view of the arguments: pointers are (re)loaded here, scalar loads
             const double* __restrict__ Ou = Kb->O.u;
             const double* __restrict__ Ov = Kb->O.v;
+            const unsigned k8 = (unsigned)k * 8u;
             Raw r;
-            r.u0 = Ou[k];
-            r.u1 = Ou[k + 1];
-            r.v0 = Ov[k];
-            r.v1 = Ov[k + (size_t)G.sj];
-            r.To = Kb->O.T[k];
-            r.So = Kb->O.S[k];
+            r.u0 = gload(Ou, k8);
+            r.u1 = gload(Ou, k8 + 8u);
+            r.v0 = gload(Ov, k8);
+            r.v1 = gload(Ov, k8 + (unsigned)G.sj * 8u);
+            r.To = gload(Kb->O.T, k8);
+            r.So = gload(Kb->O.S, k8);
             if constexpr (FUSE_INTERP) {
                 const SourceDesc S = kread(&Kb->S);
                 const WeightDesc Wt = kread(&Kb->Wt);
@@ -374,11 +375,11 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                 r.Ql = e.Ql;
                 r.Mp = e.Mp;
             } else {
-                r.ua = Kb->E.u[k];
-                r.va = Kb->E.v[k];
-                r.Ta = Kb->E.T[k];
-                r.pa = Kb->E.p[k];
-                r.qa = Kb->E.q[k];
+                r.ua = gload(Kb->E.u, k8);
+                r.va = gload(Kb->E.v, k8);
+                r.Ta = gload(Kb->E.T, k8);
+                r.pa = gload(Kb->E.p, k8);
+                r.qa = gload(Kb->E.q, k8);
                 r.Qs = r.Ql = r.Mp = 0.0;
             }
             return r;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
             const LeanCell c = lean_prologue(P, L.kappa, tab, raw.ua, raw.va, raw.Ta, raw.pa, raw.qa, 0.5 * (raw.u0 + raw.u1),
                                              0.5 * (raw.v0 + raw.v1), raw.To, raw.So);
             // the interface temperature does not depend on the iteration: written now, not carried across it
-            if (in_range) opaque(K)->F.Ts[cell_of(start)] = c.Ts - T_offset;
+            if (in_range) gstore(opaque(K)->F.Ts, (unsigned)cell_of(start) * 8u, c.Ts - T_offset);
             const double Qs_kept = raw.Qs, Ql_kept = raw.Ql, Mp_kept = raw.Mp;  // (dead unless FUSE_INTERP)
 #if CF_LEAN_PREFETCH
             const int next = claim();
@@ -418,15 +419,16 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                 const size_t k = cell_of(start);
                 const CellFluxes R = lean_epilogue(c, T_offset, s);
                 const FluxOut F = kread(&Ke->F);
-                F.Qc[k] = R.Qc;
-                F.Qv[k] = R.Qv;
-                F.Fv[k] = R.Fv;
-                F.tx[k] = R.rho_tau_x;
-                F.ty[k] = R.rho_tau_y;
-                if (F.ustar) F.ustar[k] = R.ustar;
-                if (F.tstar) F.tstar[k] = R.tstar;
-                if (F.qstar) F.qstar[k] = R.qstar;
-                if (F.iters) F.iters[k] = R.iterations;
+                const unsigned k8 = (unsigned)k * 8u;
+                gstore(F.Qc, k8, R.Qc);
+                gstore(F.Qv, k8, R.Qv);
+                gstore(F.Fv, k8, R.Fv);
+                gstore(F.tx, k8, R.rho_tau_x);
+                gstore(F.ty, k8, R.rho_tau_y);
+                if (F.ustar) gstore(F.ustar, k8, R.ustar);
+                if (F.tstar) gstore(F.tstar, k8, R.tstar);
+                if (F.qstar) gstore(F.qstar, k8, R.qstar);
+                if (F.iters) gstore_i32(F.iters, (unsigned)k * 4u, R.iterations);
                 if constexpr (FUSE) {
                     // compute_net_ocean_fluxes!, the part that needs no neighbour: interior cells only
                     const int qq = min(start + lane, nwet - 1);
@@ -436,11 +438,18 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                     if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {
                         const IceIn I = kread(&Ke->I);
                         const NetOut N = kread(&Ke->N);
-                        const double Ts_ocean = (Ke->O.T[k] + P.T_offset) - T_offset;  // what F.Ts holds (written before the iteration)
-                        store_net_cell(N, k, net_cell_local(P, P.albedo, I.conc ? I.conc[k] : 0.0, Ke->O.S[k], Ts_ocean + P.T_offset,
-                                                            FUSE_INTERP ? Mp_kept : Ke->E.Mp[k], FUSE_INTERP ? Qs_kept : Ke->E.Qs[k],
-                                                            FUSE_INTERP ? Ql_kept : Ke->E.Ql[k], R.Qc, R.Qv, R.Fv,
-                                                            I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0, I.land ? I.land[k] : 0.0));
+                        const double Ts_ocean = (gload(Ke->O.T, k8) + P.T_offset) - T_offset;  // what F.Ts holds (written before the iteration)
+                        const NetCell C = net_cell_local(P, P.albedo, I.conc ? gload(I.conc, k8) : 0.0, gload(Ke->O.S, k8), Ts_ocean + P.T_offset,
+                                                         FUSE_INTERP ? Mp_kept : gload(Ke->E.Mp, k8), FUSE_INTERP ? Qs_kept : gload(Ke->E.Qs, k8),
+                                                         FUSE_INTERP ? Ql_kept : gload(Ke->E.Ql, k8), R.Qc, R.Qv, R.Fv,
+                                                         I.Qio ? gload(I.Qio, k8) : 0.0, I.Jsio ? gload(I.Jsio, k8) : 0.0,
+                                                         I.land ? gload(I.land, k8) : 0.0);
+                        gstore(N.T, k8, C.JT);  // (store_net_cell's fields, by offset)
+                        gstore(N.S, k8, C.JS);
+                        if (N.sw) gstore(N.sw, k8, C.sw);
+                        if (N.lw_up) gstore(N.lw_up, k8, C.lw_up);
+                        if (N.lw_down) gstore(N.lw_down, k8, C.lw_down);
+                        if (N.sw_down) gstore(N.sw_down, k8, C.sw_down);
                     }
                 }
                 if (sorting && have_list) {

@@ -82,6 +82,20 @@ __device__ __forceinline__ T kread(const __attribute__((address_space(4))) T* p)
     return v;
 }
 
+// Global-memory accesses as (uniform base pointer, 32-bit byte offset per lane): the compiler emits
+// `global_load/store … v_off, s[base:base+1]` — no 64-bit address arithmetic per field in vector registers, and no
+// `flat_` instruction (a pointer read from the argument block is a generic pointer to the compiler, and flat accesses
+// count against the LDS counter as well).  A surface's fields are far below 4 GB.
+__device__ __forceinline__ double gload(const double* base, unsigned byte_off) {
+    return *(const __attribute__((address_space(1))) double*)((const __attribute__((address_space(1))) char*)base + byte_off);
+}
+__device__ __forceinline__ void gstore(double* base, unsigned byte_off, double v) {
+    *(__attribute__((address_space(1))) double*)((__attribute__((address_space(1))) char*)base + byte_off) = v;
+}
+__device__ __forceinline__ void gstore_i32(int* base, unsigned byte_off, int v) {
+    *(__attribute__((address_space(1))) int*)((__attribute__((address_space(1))) char*)base + byte_off) = v;
+}
+
 __device__ __forceinline__ SolverArgsPtr opaque(SolverArgsPtr p) {
     asm volatile("" : "+s"(p));
     return p;
