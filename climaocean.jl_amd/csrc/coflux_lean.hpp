@@ -24,10 +24,12 @@ namespace coflux {
 
 // log of a positive normal double from flog_pos_begin's table read: degree-4 log1p
 __device__ __forceinline__ double flog_lean_end(const LogHalf& h) {
+    // (Estrin form: −½ + r/3 first, then −r²/4 onto it — as a Horner chain the compiler copies the constant ⅓ into the
+    // accumulator of a two-address multiply-add in every evaluation)
     const double r = __builtin_fma(h.m, h.ck.x, -1.0);
-    double q = __builtin_fma(r, -0.25, 1.0 / 3.0);
-    q = __builtin_fma(r, q, -0.5);
-    return __builtin_fma((double)h.e, 0.6931471805599453094, __builtin_fma(r * r, q, r) + h.ck.y);
+    const double r2 = r * r;
+    const double q = __builtin_fma(r2, -0.25, __builtin_fma(r, 1.0 / 3.0, -0.5));
+    return __builtin_fma((double)h.e, 0.6931471805599453094, __builtin_fma(r2, q, r) + h.ck.y);
 }
 
 // w^(2/3) for w ≥ 1e-18: f32 seed (≈ 5e-7), one Newton step on y³ = w² in FP64 (⇒ ≈ 3e-13)
@@ -208,6 +210,8 @@ __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const Lea
     double us = 1e-4, ius = 1e4, chi = 0.0, kb = __builtin_fma(1e-4, c.bth, c.bqq * 1e-4);
     double drift = __builtin_inf();
     int it = 0;
+    double log_A_q = L.log_A_q;  // in a vector register: as the third scalar operand of one multiply-add it would be copied there per iteration
+    asm("" : "+v"(log_A_q));
     for (int trip = 0;; ++trip) {
         const bool go = active && it < L.maxiter && !(drift < L.tol);
         if (__ballot(go) == 0ull) break;  // the wave leaves the loop together
@@ -227,7 +231,7 @@ __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const Lea
             }
             const double2 ps = psi_eval_pair(tab, ah);
             const double log_lu = flog_lean_end(half_u);
-            const double log_lq = vmin_u(__builtin_fma(-L.b_q, flog_lean_end(half_q), L.log_A_q), L.log_lm_q);
+            const double log_lq = vmin_u(__builtin_fma(-L.b_q, flog_lean_end(half_q), log_A_q), L.log_lm_q);
             double Du = (L.log_h - log_lu) - ps.x;
             double Dq = (L.log_h - log_lq) - ps.y;
             if constexpr (!COARE) {
@@ -248,14 +252,23 @@ __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const Lea
             Du = vmax_u(Du, L.profile_floor);
             Dq = vmax_u(Dq, L.profile_floor);
             const double r = frcp1(Du * Dq);
-            const double un = (L.kappa * U) * (r * Dq);
-            const double chi_n = L.kappa * (r * Du);
+            const double kU = L.kappa * U, rDq = r * Dq, rDu = r * Du;
             ius = (Du * rU) * L.two_inv_kappa;  // 1/u★ = D_u / (κ U)
-            if (trip == 0) drift = fabs(un - us) + fabs(chi_n * c.dtheta - 1e-4) + fabs(chi_n * c.dq - 1e-4);
-            else drift = __builtin_fma(fabs(chi_n - chi), S, fabs(un - us));
-            kb = chi_n * B;
-            us = un;
-            chi = chi_n;
+            // the differences as fused multiply-subtracts of the OLD state, then the new state over it: no register copies
+            // for the loop-carried values (un − u★ differs from the two-step form by half an ulp of u★)
+            const double d_u = __builtin_fma(kU, rDq, -us);
+            double kU_after = kU;
+            asm("" : "+v"(kU_after) : "v"(d_u));  // (orders the product behind the last use of the old u★)
+            us = kU_after * rDq;
+            if (trip == 0) {
+                chi = L.kappa * rDu;
+                drift = fabs(d_u) + fabs(chi * c.dtheta - 1e-4) + fabs(chi * c.dq - 1e-4);
+            } else {
+                const double d_c = __builtin_fma(L.kappa, rDu, -chi);
+                chi = L.kappa * rDu;
+                drift = __builtin_fma(fabs(d_c), S, fabs(d_u));
+            }
+            kb = chi * B;
             ++it;
         }
     }
