@@ -426,13 +426,23 @@ def main():
         # scratch/round_profile.sh; see profiles/): properties of the kernels on this workload, not re-measured in this
         # run — `traffic_source` / `instructions_source` name the file and the commit it was taken at
         lean, fused = ctx.solver_path()
+
+        def variant_key(name):
+            """profile kernel name → the key the roofline looks up: the lean solver's template variants are told apart
+            (<COARE, BLOCK, FUSE, FUSE_INTERP[, PIPE]>: the event-bracketed pass runs the un-pipelined one)"""
+            base = name.split("<")[0].split("::")[-1].strip()
+            if base == "ao_lean_kernel" and "<" in name:
+                t = [x.strip() for x in name.split("<")[1].split(">")[0].split(",")]
+                fuse_net, piped = t[2] == "true", len(t) > 4 and t[4] == "true"
+                return base + (":fused" if fuse_net else ":plain") + (":piped" if piped else "")
+            return base
         traffic, traffic_source, sq, sq_source = {}, None, {}, None
         canonical = (nx, ny, a.flux_configuration, world, a.config) == (1440, 560, "default", 1, "ocean")
         for tag in ("r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
                 if canonical:
-                    traffic = {k.split("<")[0]: v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()}
+                    traffic = {variant_key(k): v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()}
                     traffic_source = (f"committed: profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes"
                                       f"{', tree ' + pmc['commit'] if pmc.get('commit') else ''})")
                 break
@@ -441,18 +451,19 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq.json")))
             if canonical:
-                sq = {k.split("<")[0]: v for k, v in pmc["kernels"].items()}
+                sq = {variant_key(k): v for k, v in pmc["kernels"].items()}
                 sq_source = f"committed: profiles/r03_pmc_sq.json (rocprofv3 --pmc SQ_INSTS_VALU …, tree {pmc.get('commit')})"
         except Exception:
             pass
         ao_kernel = "ao_lean_kernel" if lean else "ao_flux_fast_kernel"
+        ao_key = (ao_kernel + (":fused" if fused else ":plain")) if lean else ao_kernel
         ao_what = "compute_atmosphere_ocean_fluxes!" + (" + the cell-local part of compute_net_ocean_fluxes! in its epilogue" if fused else "")
         ao_bytes = BYTES_AO_FUSED if fused else BYTES_AO
 
         def roof(name, nbytes, ncells, ms, **extra):
             achieved = nbytes * ncells / (ms * 1e-3) / 1e9
             return dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=traffic.get(name.split(" ")[0]), traffic_source=traffic_source,
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic.get(extra.pop("traffic_key", name.split(" ")[0])), traffic_source=traffic_source,
                         bytes_per_cell=nbytes, cells_per_launch=ncells, avg_launch_ms=ms,
                         cells_per_s=ncells / (ms * 1e-3), **extra)
 
@@ -474,7 +485,7 @@ def main():
                    settle_steps=settle.get(best), repetitions=reps, ms_per_step_samples=[s / steps * 1e3 for s in samples],
                    halo_paths_ms_per_step={k: v[0] / steps * 1e3 for k, v in results.items()} if world > 1 else None,
                    # dominant kernel = compute_atmosphere_ocean_fluxes! (SURVEY.md §8d contract figure 128 B/cell)
-                   roofline=roof(f"{ao_kernel} ({ao_what})", ao_bytes, cells_rank, ao_ms,
+                   roofline=roof(f"{ao_kernel} ({ao_what})", ao_bytes, cells_rank, ao_ms, traffic_key=ao_key,
                                  launches_timed=nrec,
                                  bytes_per_cell_note=("80 B read + 48 B written (SURVEY §8d, the contract figure of the solver) + Qs, Ql, Mp read "
                                                       "and JT, JS, SW written by the fused net-flux epilogue" if fused else
@@ -493,7 +504,7 @@ def main():
                    device_copy_GBs=2 * copy_bytes / (copy_ms * 1e-3) / 1e9,
                    parity="vs reference: unpinned (self-consistent restatements only; see DESIGN.md)")
         # the ceiling that binds the solver: FP64 VALU issue
-        k_sq = sq.get(ao_kernel)
+        k_sq = sq.get(ao_key)
         if k_sq:
             insts = k_sq["SQ_INSTS_VALU"]
             rate = insts / (ao_ms * 1e-3)
