@@ -213,8 +213,9 @@ __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const Lea
     double log_A_q = L.log_A_q;  // in a vector register: as the third scalar operand of one multiply-add it would be copied there per iteration
     asm("" : "+v"(log_A_q));
     for (int trip = 0;; ++trip) {
-        const bool go = active && it < L.maxiter && !(drift < L.tol);
-        if (__ballot(go) == 0ull) break;  // the wave leaves the loop together
+        // (every running lane has it == trip: the trip limit is a scalar test)
+        const bool go = active && !(drift < L.tol);
+        if (trip >= L.maxiter || __builtin_amdgcn_ballot_w64(go) == 0ull) break;  // the wave leaves the loop together
         if (go) {
             const double inv_L = kb * (ius * ius);  // 1/L★ = κ b★ / u★²
             const double lu = vmin_u(__builtin_fma(c.alpha_g * us, us, c.lam_nu * ius), L.lm_m);
