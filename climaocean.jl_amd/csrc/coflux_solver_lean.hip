@@ -3,20 +3,25 @@
 // omip_simulation.jl:40-49 and the defaults of README.md:75), round-3 kernel.
 //
 // What it keeps from coflux_solver.hip: one 256-thread workgroup per chunk of the cost-balanced chunk table, the ψ /
-// log tables and the parameter block staged in LDS by LDS-DMA, land compacted away, batches of 64 wet cells whose
-// trip counts were equal last call, waves leaving the iteration together on a wave64 ballot, a mask rewritten in place
-// detected by a fingerprint of the chunk's wet set (a stale list costs time, never correctness).
+// log tables and the parameter block staged in LDS by LDS-DMA, land compacted away, batches of 64 wet cells, waves
+// leaving the iteration together on a wave64 ballot, a mask rewritten in place detected by a fingerprint of the chunk's
+// wet set (a stale list costs time, never correctness).
 //
 // What is new (profiles/r03_experiments.md):
-//   * the iteration, its prologue and its epilogue are coflux_lean.hpp's (−17 % VALU instructions per launch);
+//   * the iteration, its prologue and its epilogue are coflux_lean.hpp's;
 //   * the start phase no longer sorts.  Round 2 loaded every chunk's static list and hint bytes, counting-sorted them
 //     in LDS (two atomic passes, a scan, three barriers) and hashed every listed cell to validate the list: ≈ 9 µs
-//     in which no CU of the device computes (all workgroups start together).  Now the list lives in global memory
-//     ALREADY SORTED: it goes straight into LDS by LDS-DMA beside the tables, the chunk's fingerprint is a number
-//     computed when the list was built, and one barrier separates the requests from the first batch.  The order
-//     for the NEXT call is produced at the END of the workgroup's life: every batch leaves its lanes' trip counts in
-//     LDS and bumps a 64-bin histogram; the last wave to retire scans the bins and scatters the list back to global
-//     memory — one wave's work, while the CU's other workgroups are still iterating.
+//     in which no CU of the device computes (all workgroups start together).  Now the list lives in global memory in
+//     the order the batches will take it: it goes straight into LDS by LDS-DMA beside the tables, the chunk's
+//     fingerprint is a number computed when the list was built, and one barrier separates the requests from the first
+//     batch (≈ 4 µs);
+//   * batches are in INDEX order by default (CF_OPT_TRIP_HINTS = 2): sorted by last call's trip counts a batch's cells
+//     are scattered over the chunk and its memory phases cost more than the trips the sort saves once the hints are a
+//     step old; index order also makes the accesses coalesced (HBM traffic 239 → ≈ 100 MB per launch) and the fused
+//     net-flux epilogue cheap.  With CF_OPT_TRIP_HINTS = 1 the order for the NEXT call is produced at the END of the
+//     workgroup's life: every batch leaves its lanes' trip counts in the list words' top byte and bumps a 64-bin
+//     histogram; behind a barrier the workgroup scans the bins and scatters the list back to global memory;
+//   * a batch's loads and stores are uniform base + 32-bit offset (gload / gstore): `global_* v_off, s[base]`.
 #include <hip/hip_runtime.h>
 
 #include "coflux_interp_cell.hpp"
