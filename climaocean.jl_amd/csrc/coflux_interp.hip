@@ -12,6 +12,9 @@
 // waves of a CU hide each other's load latency.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "coflux_interp_cell.hpp"
 #include "coflux_kernels.h"
 
@@ -283,7 +286,8 @@ hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc
     const long tiles4 = (long)tiles_x * ((wy + 3) / 4) * 256 / (L.cu_count > 0 ? L.cu_count : 256);
     const int rows = tiles4 >= 1200 ? 4 : (tiles4 >= 600 ? 2 : 1);
     const int ntiles = tiles_x * ((wy + rows - 1) / rows);
-    const int blocks = (ntiles + IT_WAVES - 1) / IT_WAVES;
+    int blocks = (ntiles + IT_WAVES - 1) / IT_WAVES;
+    if (const char* cap = std::getenv("COFLUX_INTERP_BLOCKS")) blocks = std::min(blocks, std::max(1, std::atoi(cap)));  // (experiments)
     const size_t lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double);
 #define CF_LAUNCH_INTERP(ROWS_)                                                                                        \
     hipLaunchKernelGGL(interpolate_kernel<ROWS_>, dim3(blocks), dim3(64 * IT_WAVES), lds, st, make_source(s),          \
