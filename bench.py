@@ -71,6 +71,9 @@ def parse():
                          "tried (peer-direct through HIP IPC; RCCL refuses duplicate devices).  The line is marked "
                          "'rehearsal' and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trip-hints", type=int, choices=(0, 1, 2, 3), default=2,
+                    help="CF_OPT_TRIP_HINTS for the timed region: 2 = the library's default (index-ordered batches in the round-3 ocean "
+                         "kernel), 1 = batches sorted by last call's trip counts over the whole chunk, 3 = within quarter-chunk windows")
     ap.add_argument("--no-sorted-pass", action="store_true",
                     help="skip the informational pass with CF_OPT_TRIP_HINTS = 1 (profiling runs: only the default configuration's launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample: passes that fit this wall time")
@@ -226,6 +229,8 @@ def main():
         w_np = dict(separable=True, fi=fi, fj=fj, latitude=phi)
 
     ctx = FluxContext(nx, ny, h, h, params, ring=1, device=local_rank)
+    if a.trip_hints != 2:
+        ctx.set_option(abi.OPT_TRIP_HINTS, a.trip_hints)
     ring_rows = ctx.grid.ring + 1
     states = [{k: ctx.to_device(o[k]) for k in ("T", "S", "u", "v", "mask")} for o in ocean_np]
     states[1]["mask"] = states[0]["mask"]   # one static wet mask (the solver's chunk table is keyed on it)
@@ -401,9 +406,9 @@ def main():
     n_prof = min(max(steps, 20), 200)
     # CF_OPT_TRIP_HINTS: 2 = the library's default (what the timed region ran), 1 = every solver orders its batches by
     # the previous call's trip counts (round 2's default; reported beside it)
-    prof = instrumented(n_prof, 2) if a.config == "ocean" and best != "torch" else None
+    prof = instrumented(n_prof, a.trip_hints) if a.config == "ocean" and best != "torch" else None
     prof_sorted = instrumented(n_prof, 1) if prof and not a.no_sorted_pass else None
-    ctx.set_option(abi.OPT_TRIP_HINTS, 2)
+    ctx.set_option(abi.OPT_TRIP_HINTS, a.trip_hints)
 
     if rank == 0:
         kw = dict(src=src, weights=w, ocean=states[0], atmos=atmos_sets[0], fluxes=fl, net=net, time_fraction=0.37)

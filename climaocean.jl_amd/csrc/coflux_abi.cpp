@@ -498,12 +498,13 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->launch.max_blocks = value;
             return CF_OK;
         case CF_OPT_TRIP_HINTS:
-            if (value < 0 || value > 2) return fail(ctx, CF_ERR_INVALID, "trip hints %d: 0 (off), 1 (on), 2 (automatic)", value);
-            if (ctx->lean_hints && value != 1) ctx->chunk_valid = false;  // the lean kernel's lists go back to index order
+            if (value < 0 || value > 3) return fail(ctx, CF_ERR_INVALID, "trip hints %d: 0 (off), 1 (on), 2 (automatic), 3 (on, the lean kernel in quarter-chunk windows)", value);
+            if (ctx->lean_hints && value != 1 && value != 3) ctx->chunk_valid = false;  // the lean kernel's lists go back to index order
+            if (ctx->launch.lean_hints != (value == 1 ? 1 : (value == 3 ? 4 : 0))) ctx->chunk_valid = false;  // another window layout: start from index order
             ctx->trip_hints = value != 0;
-            ctx->lean_hints = value == 1;
+            ctx->lean_hints = value == 1 || value == 3;
             ctx->launch.d_trip = ctx->trip_hints ? ctx->d_trip : nullptr;
-            ctx->launch.lean_hints = ctx->lean_hints ? 1 : 0;
+            ctx->launch.lean_hints = value == 1 ? 1 : (value == 3 ? 4 : 0);
             return CF_OK;
         case CF_OPT_FUSED_NET:
             if (value < 0 || value > 2) return fail(ctx, CF_ERR_INVALID, "fused net fluxes %d: 0 (never), 1 (when possible), 2 (automatic)", value);

@@ -24,6 +24,9 @@
 //   * a batch's loads and stores are uniform base + 32-bit offset (gload / gstore): `global_* v_off, s[base]`.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "coflux_interp_cell.hpp"
 #include "coflux_lean.hpp"
 #include "coflux_solver_shared.hpp"
@@ -209,6 +212,17 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
     const double z_surface = K->z_surface;
     const double T_offset = K->T_offset;
     const bool sorting = use_static && K->sort_enabled != 0;
+    // sort_enabled = number of WINDOWS the chunk's list is sorted in: 1 = the whole chunk by trip count (64 bins);
+    // 4 = each quarter of the list separately (16 one-count bins each): a batch's cells then stay within a quarter of the
+    // chunk's range — a fourth of the lines per access a whole-chunk sort touches — and still run together
+    const int sort_windows = (int)K->sort_enabled;
+    float inv_window = 0.f;
+    auto lean_bin = [&](int q, int trips) -> int {  // ascending bin = taken first; q: position in the current list
+        if (sort_windows <= 1) return AO_BINS - 1 - trip_bin(trips);
+        const int w = min((int)(((float)q + 0.5f) * inv_window), sort_windows - 1);
+        const int bpw = AO_BINS / sort_windows, lo = bpw >= 16 ? 5 : 8;  // one-count bins from `lo` iterations up
+        return w * bpw + (bpw - 1 - min(max(trips - lo, 0), bpw - 1));
+    };
     {
         const unsigned long long mbase = mask_kind == CF_MASK_NONE ? (unsigned long long)g_tab : (unsigned long long)mask;
         const unsigned stride = mask_kind == CF_MASK_NONE ? 0u : (mask_kind == CF_MASK_U8 ? 1u : 8u);
@@ -282,6 +296,8 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
         }
         have_list = got_x == want_x && got_y == want_y;  // the list is the range's wet set
         nwet = listed;
+        if (sort_windows > 1 && nwet > 0)  // windows of whole batches
+            inv_window = 1.0f / (float)(((nwet + sort_windows * 64 - 1) / (sort_windows * 64)) * 64);
     }
     if (have_list && land) {
         // zero_interface_state of the range's land: nothing waits for these stores but the first batch's loads
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
                 if (sorting && have_list) {
                     const int w = min(s.work, 255);
                     list[q] = (list[q] & LEAN_OFFSET_MASK) | ((unsigned)w << LEAN_OFFSET_BITS);
-                    atomicAdd(&hist[AO_BINS - 1 - trip_bin(w)], 1);
+                    atomicAdd(&hist[lean_bin(q, w)], 1);
                 }
             }
 #if !CF_LEAN_PREFETCH
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_na
         for (int n = 0; n < PER_THREAD; ++n) word[n] = list[min(tid + n * BLOCK, CHUNK - 1)];
 #pragma unroll
         for (int n = 0; n < PER_THREAD; ++n)
-            at[n] = tid + n * BLOCK < nwet ? atomicAdd(&cursor[AO_BINS - 1 - trip_bin((int)(word[n] >> LEAN_OFFSET_BITS))], 1) : -1;
+            at[n] = tid + n * BLOCK < nwet ? atomicAdd(&cursor[lean_bin(tid + n * BLOCK, (int)(word[n] >> LEAN_OFFSET_BITS))], 1) : -1;
 #pragma unroll
         for (int n = 0; n < PER_THREAD; ++n)
             if (at[n] >= 0) out[at[n]] = word[n] & LEAN_OFFSET_MASK;
@@ -579,6 +595,8 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
     A.T_offset = P.T_offset;
     A.wx_reciprocal = row_reciprocal(G.nx + 2 * G.ring);
     A.sort_enabled = L.lean_hints;
+    if (L.lean_hints > 1)
+        if (const char* e = std::getenv("COFLUX_SORT_WINDOWS")) A.sort_enabled = std::max(1, std::min(8, std::atoi(e)));  // (experiments: 1, 2, 4, 8)
     if (net) {  // the fused form: the epilogue also writes the cell-local net ocean fluxes (constant ocean albedo only)
         if (ice) A.I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress, nullptr};
         A.I.land = land;

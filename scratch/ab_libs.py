@@ -48,7 +48,8 @@ for rnd in range(2):
         if tag != "prod": env["LIBCOFLUX"] = os.path.join(ROOT, "scratch", f"libcoflux_{tag}.so")
         opts, _, layers = opts.partition("@")
         if opts: env["AB_OPTS"] = json.dumps(dict(kv.split("=") for kv in opts.split(",")))
-        if layers: env["COFLUX_LAYERS"] = layers
+        if layers.startswith("w"): env["COFLUX_SORT_WINDOWS"] = layers[1:]
+        elif layers: env["COFLUX_LAYERS"] = layers
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:

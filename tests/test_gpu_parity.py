@@ -323,7 +323,7 @@ def test_trip_count_hints_only_reorder_work():
     atmos = ctx.field_set(EXCHANGE_NAMES)
     ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
     runs = []
-    for hints in (2, 1, 1, 1, 0, 2):
+    for hints in (2, 1, 1, 1, 0, 2, 3, 3, 3, 2):
         ctx.set_option(abi.OPT_TRIP_HINTS, hints)
         fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL)
         fluxes["iterations"] = ctx.zeros(torch.int32)
