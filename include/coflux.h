@@ -537,7 +537,8 @@ typedef struct cf_ice_ocean_params {
     double ice_density;                 /* 917 kg m⁻³                                                   */
     double latent_heat_of_fusion;       /* 334 000 J kg⁻¹                                               */
     double ice_salinity;                /* 4 g/kg                                                       */
-    double liquidus_slope;              /* m = 0.054 K per g/kg                                         */
+    double liquidus_slope;              /* m = 0.054 K per g/kg: T_f = −m S in °C, i.e. freshwater melts at 0 °C = the 273.15 K of
+                                           cf_sea_ice_params.freshwater_melting_temperature (the two interfaces agree at the default) */
     double top_cell_thickness;          /* Δz of the ocean's top cell [m] (frazil)                      */
     double time_step;                   /* Δt [s] (frazil); ≤ 0 disables frazil                         */
 } cf_ice_ocean_params;
