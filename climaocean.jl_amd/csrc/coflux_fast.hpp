@@ -590,36 +590,51 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
 // (omip_simulation.jl:86-89): the NCAR bulk algorithm of Large & Yeager (2004, 2009) on this
 // package's Δθ, Δq and buoyancy scale.  Fixed trip count ⇒ no divergence, no ballot.
 __device__ __forceinline__ Scales ly_iterate(const LoopParams& L, const CellConsts& c, const double* tab) {
-    auto cdn10 = [&](double u) {
+    // The same recurrence with its square roots and divisions folded (round 3).  With C_d = C_dn / den², den = 1 + √C_dn x_m:
+    //   √C_d = √C_dn / |den|,   √(C_d / C_dn) = 1 / |den|,   C_h / √C_d = c_h / (1 + c_h x_h) with c_h = 1e-3·CH(ζ) — √C_dn
+    // cancels —, 1/u★² = (|den| / (√C_dn U))², 1/u₁₀ = (1 + √C_dn x_m) / U.  State: 1/√C_d, C_h/√C_d, C_e/√C_d, √C_dn.
+    // Two reciprocals and one reciprocal square root per iteration instead of eight and three.
+    auto cdn10 = [&](double u, double inv_u) {
         const double u2 = u * u;
-        const double poly = (L.ly_cd0 * frcp1(u) + L.ly_cd1 + L.ly_cd2 * u + L.ly_cd3 * (u2 * u2 * u2)) * 1e-3;
+        const double poly = (L.ly_cd0 * inv_u + L.ly_cd1 + L.ly_cd2 * u + L.ly_cd3 * (u2 * u2 * u2)) * 1e-3;
         return u >= L.ly_high_wind ? L.ly_cd_high * 1e-3 : poly;
     };
-    const double U = fmax(c.dU, L.ly_min_wind);
-    double cdn = cdn10(U), rt = fsqrt1(cdn);
-    double cd = cdn, ce = L.ly_ce * rt * 1e-3, ch = (c.dtheta > 0.0 ? L.ly_ch_s : L.ly_ch_u) * rt * 1e-3;
+    auto sqrt_pair = [&](double x, double& root, double& inv_root) {  // one v_rsq_f64, one Newton step each
+        const double r = __builtin_amdgcn_rsq(x);
+        const double g0 = x * r, h0 = 0.5 * r;
+        const double e = __builtin_fma(-g0, h0, 0.5);
+        root = __builtin_fma(g0, e, g0);
+        inv_root = 2.0 * __builtin_fma(h0, e, h0);
+    };
+    const double U = fmax(c.dU, L.ly_min_wind), inv_U = frcp1(U);
+    double rt, inv_cr;
+    sqrt_pair(cdn10(U, inv_U), rt, inv_cr);                       // C_d = C_dn: 1/√C_d = 1/√C_dn
+    const double cek = L.ly_ce * 1e-3;
+    double th = (c.dtheta > 0.0 ? L.ly_ch_s : L.ly_ch_u) * 1e-3;  // C_h/√C_d, C_e/√C_d: the neutral coefficients' factors
+    double qh = cek;
+    double den = 1.0;
     for (int it = 0; it < L.maxiter; ++it) {
-        const double cr = fsqrt1(cd), inv_cr = frcp1(cr);
-        const double us = cr * U, ts = ch * inv_cr * c.dtheta, qq = ce * inv_cr * c.dq;  // L-Y eq. 7
+        const double ts = th * c.dtheta, qq = qh * c.dq;                                   // L-Y eq. 7
         const double b = c.gTv * __builtin_fma(ts, c.b_theta, c.b_q * qq);
-        double z = L.kappa * b * L.h_ref * frcp1(us * us);                                // 8a
+        const double w = inv_cr * inv_U;                                                   // 1/u★
+        double z = (L.kappa * L.h_ref) * b * (w * w);                                      // 8a
         z = __builtin_copysign(fmin(fabs(z), L.ly_zeta_bound), z);
         const double2 ps = psi_eval_pair(tab, psi_arg(z));
-        const double xm = (L.ly_lz - ps.x) * L.inv_kappa;
-        const double u10 = U * frcp1(__builtin_fma(rt, xm, 1.0));                          // 9
-        cdn = cdn10(u10);
-        rt = fsqrt1(cdn);
-        const double inv_rt = frcp1(rt);
-        const double cen = L.ly_ce * rt * 1e-3, chn = (z > 0.0 ? L.ly_ch_s : L.ly_ch_u) * rt * 1e-3;
-        const double den = __builtin_fma(rt, xm, 1.0);
-        cd = cdn * frcp1(den * den);                                                      // 10a
-        const double xh = (L.ly_lz - ps.y) * L.inv_kappa;
-        const double r = fsqrt1(cd * frcp1(cdn));
-        ch = chn * frcp1(__builtin_fma(chn * xh, inv_rt, 1.0)) * r;                        // 10b
-        ce = cen * frcp1(__builtin_fma(cen * xh, inv_rt, 1.0)) * r;                        // 10c
+        const double xm = (L.ly_lz - ps.x) * L.inv_kappa, xh = (L.ly_lz - ps.y) * L.inv_kappa;
+        const double d0 = __builtin_fma(rt, xm, 1.0);                                      // with the PREVIOUS √C_dn
+        const double u10 = U * frcp1(d0);                                                  // 9
+        double irt;
+        sqrt_pair(cdn10(u10, d0 * inv_U), rt, irt);
+        den = __builtin_fma(rt, xm, 1.0);
+        inv_cr = fabs(den) * irt;                                                          // 10a: √C_d = √C_dn / |den|
+        const double chk = (z > 0.0 ? L.ly_ch_s : L.ly_ch_u) * 1e-3;
+        const double a = __builtin_fma(chk, xh, 1.0), e = __builtin_fma(cek, xh, 1.0);
+        const double r = frcp1(a * e);
+        th = chk * (r * e);                                                                // 10b, 10c divided by √C_d
+        qh = cek * (r * a);
     }
-    const double cr = fsqrt1(cd), inv_cr = frcp1(cr);
-    return Scales{cr * U, ch * inv_cr * c.dtheta, ce * inv_cr * c.dq, L.maxiter, L.maxiter};
+    const double cr = frcp1(inv_cr);
+    return Scales{cr * U, th * c.dtheta, qh * c.dq, L.maxiter, L.maxiter};
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -342,8 +342,9 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * with a face-stress kernel instead of the three-launch sequence (bitwise the same results):
                                    * 0 never, 1 whenever the configuration allows it (constant ocean albedo), 2 (default) when the
                                    * round-3 ocean kernel runs — its batches are in index order, so the epilogue's nine extra
-                                   * accesses per cell are coalesced: update_state 0.107 → 0.096 ms; in round 2's trip-sorted
-                                   * kernels the same accesses were scattered and cost more than the net-flux kernel they save. */
+                                   * accesses per cell are coalesced: update_state 0.107 → 0.096 ms — or CoefficientBasedFluxes
+                                   * (fixed trip count: index order too; 0.072 → 0.063 ms); in round 2's trip-sorted kernels
+                                   * the same accesses were scattered and cost more than the net-flux kernel they save.        */
 #define CF_OPT_FUSED_INTERP 8     /* 1: cf_update_state interpolates the atmosphere state in the round-3 ocean kernel's prologue
                                    * instead of a launch of its own (same bits: one shared per-cell routine; needs the fused net
                                    * fluxes, no pending prefetch) — update_state! in two launches.  0 (default): measured SLOWER

@@ -12,7 +12,7 @@ from coflux import abi, synthetic as syn, interface_computations as ic
 from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, NET_NAMES, FluxContext
 nx, ny, h = 1440, 560, 7
 cfg = os.environ.get("CONFIG", "default")
-fl = ic.corrected_atmosphere_ocean_fluxes() if cfg == "corrected" else ic.SimilarityTheoryFluxes()
+fl = ic.corrected_atmosphere_ocean_fluxes() if cfg == "corrected" else (ic.ncar_atmosphere_ocean_fluxes() if cfg == "ncar" else ic.SimilarityTheoryFluxes())
 ocean_np = syn.ocean_state(nx, ny, h, h); src_np = syn.jra55_snapshots(2)
 fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h)
 ctx = FluxContext(nx, ny, h, h, ic.flux_params(fl))

@@ -224,18 +224,22 @@ def test_fused_net_epilogue_is_bitwise_the_three_launch_sequence():
     compute_net_ocean_fluxes! kernel, bit for bit (shared arithmetic with contraction off), with and without sea ice."""
     ctx, states, src, w, np_states = _setup()
     ice = {k: ctx.to_device(np_states[0]["ice_" + k]) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")}
-    for use_ice in (None, ice):
-        outs = []
-        for fused in (0, 1):
-            ctx.set_option(abi.OPT_FUSED_NET, fused)
-            a, fl, net = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
-            ctx.update_state(src, w, states[0], a, fl, net, ice=use_ice, time_fraction=0.37)
-            ctx.sync()
-            outs.append((fl, net))
-        for k in FLUX_NAMES:
-            assert torch.equal(outs[0][0][k], outs[1][0][k]), k
-        for k in NET_NAMES:
-            assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+    for fluxes in (None, ic.ncar_atmosphere_ocean_fluxes()):   # the round-3 kernel; CoefficientBasedFluxes in round 2's (fused by default too)
+        if fluxes is not None:
+            ctx.set_flux_params(ic.flux_params(fluxes))
+        for use_ice in (None, ice):
+            outs = []
+            for fused in (0, 1, 2):
+                ctx.set_option(abi.OPT_FUSED_NET, fused)
+                a, fl, net = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+                ctx.update_state(src, w, states[0], a, fl, net, ice=use_ice, time_fraction=0.37)
+                ctx.sync()
+                outs.append((fl, net))
+            for other in outs[1:]:
+                for k in FLUX_NAMES:
+                    assert torch.equal(outs[0][0][k], other[0][k]), k
+                for k in NET_NAMES:
+                    assert torch.equal(outs[0][1][k], other[1][k]), k
     ctx.close()
 
 
