@@ -1,5 +1,7 @@
 """Runs bench.py with the given arguments and prints the headline numbers of its JSON line (scratch)."""
 import json, subprocess, sys
+if not sys.stdin.isatty() and sys.stdin.read(1):
+    sys.exit("bench_brief.py runs bench.py itself: pass bench.py's arguments to it, do not pipe a second bench into it")
 out = subprocess.run([sys.executable, "bench.py"] + sys.argv[1:], capture_output=True, text=True)
 line = [l for l in out.stdout.splitlines() if l.startswith("{")]
 if not line:
