@@ -287,6 +287,12 @@ hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc
     const int rows = tiles4 >= 1200 ? 4 : (tiles4 >= 600 ? 2 : 1);
     const int ntiles = tiles_x * ((wy + rows - 1) / rows);
     int blocks = (ntiles + IT_WAVES - 1) / IT_WAVES;
+    // Everything resident at once (≤ 4 workgroups per CU: LDS) but not evenly — 817 workgroups on 256 CUs leave 49 CUs
+    // with four and the rest with three, and all waves hit the store phase together: a grid of ≈ 78 % of the tiles' waves,
+    // a fifth of them taking a second tile, staggers the phases (measured at 1440×560: 817 → 18.0, 704 → 17.4, 640 → 17.2,
+    // 600 → 17.3, 560 → 17.5 µs; no effect below 2 workgroups per CU, slightly negative above 4: left alone there)
+    const int cus = L.cu_count > 0 ? L.cu_count : 256;
+    if (blocks > 2 * cus && blocks <= 4 * cus) blocks = std::max(2 * cus, blocks * 25 / 32);
     if (const char* cap = std::getenv("COFLUX_INTERP_BLOCKS")) blocks = std::min(blocks, std::max(1, std::atoi(cap)));  // (experiments)
     const size_t lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double);
 #define CF_LAUNCH_INTERP(ROWS_)                                                                                        \
