@@ -24,6 +24,9 @@ atmos = ctx.field_set(EXCHANGE_NAMES); fluxes = ctx.field_set(FLUX_NAMES); net =
 ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
 kw = dict(src=src, weights=w, ocean=ocean, atmos=atmos, fluxes=fluxes, net=net, time_fraction=0.37)
 for _ in range(4): ctx.time_stage(abi.STAGE_AO_FLUXES, 500, **kw)
+for _ in range(int(os.environ.get("AB_REBALANCE", "0"))):   # the trip-weighted chunk table: cut from what the launches above counted
+    ctx.ensure_chunk_table(ocean["mask"])
+    ctx.time_stage(abi.STAGE_AO_FLUXES, 200, **kw)
 ao = min(ctx.time_stage(abi.STAGE_AO_FLUXES, 100, **kw) for _ in range(5))
 # evolving inputs: the time fraction moves by 20 min / 3 h per call (interpolation + solver per step, events around the solver only)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * 60)]
@@ -48,7 +51,8 @@ for rnd in range(2):
         if tag != "prod": env["LIBCOFLUX"] = os.path.join(ROOT, "scratch", f"libcoflux_{tag}.so")
         opts, _, layers = opts.partition("@")
         if opts: env["AB_OPTS"] = json.dumps(dict(kv.split("=") for kv in opts.split(",")))
-        if layers.startswith("w"): env["COFLUX_SORT_WINDOWS"] = layers[1:]
+        if layers.startswith("r"): env["AB_REBALANCE"] = layers[1:]
+        elif layers.startswith("w"): env["COFLUX_SORT_WINDOWS"] = layers[1:]
         elif layers: env["COFLUX_LAYERS"] = layers
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -21,6 +21,9 @@ for label in cfgs:
     atmos = ctx.field_set(EXCHANGE_NAMES); fluxes = ctx.field_set(FLUX_NAMES)
     ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
     for _ in range(3): ctx.time_stage(abi.STAGE_AO_FLUXES, 500, ocean=ocean, atmos=atmos, fluxes=fluxes)
+    if os.environ.get("REBAL"):
+        ctx.ensure_chunk_table(ocean["mask"])
+        ctx.time_stage(abi.STAGE_AO_FLUXES, 200, ocean=ocean, atmos=atmos, fluxes=fluxes)
     ms = min(ctx.time_stage(abi.STAGE_AO_FLUXES, 50, ocean=ocean, atmos=atmos, fluxes=fluxes) for _ in range(3))
     ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
     NWG = int(os.environ.get('NWG', '752')); WPG = int(os.environ.get('WPG', '4'))
@@ -56,4 +59,19 @@ for label in cfgs:
         wg_life = (raw[sel, 5].reshape(-1, WPG).max(axis=1) - raw[sel, 0].reshape(-1, WPG).min(axis=1)) / tick
         nb = np.maximum(raw[sel, 7], 1)
         print(f"   blockIdx {lo:3d}-{hi:3d}: workgroup lifetime median {np.median(wg_life):.1f} p10 {np.percentile(wg_life,10):.1f} max {wg_life.max():.1f}; batches/wave {raw[sel,7].mean():.2f}; per batch {np.median(D(4,3)[sel]/nb):.1f} us of which iterating {np.median(raw[sel,6]/tick/nb):.1f}")
+    # the tail: which workgroups end the kernel, and is it their work (sum of their batches' trips) or their CU's?
+    wg_life_all = (raw[:, 5].reshape(-1, WPG).max(axis=1) - raw[:, 0].reshape(-1, WPG).min(axis=1)) / tick
+    wg_trips = trips.reshape(-1, WPG).sum(axis=1)
+    for lo, hi in ((0, 256), (256, 512), (512, NWG)):
+        L_, T_ = wg_life_all[lo:hi], wg_trips[lo:hi]
+        print(f"   blockIdx {lo:3d}-{hi:3d}: lifetime p50 {np.percentile(L_,50):.1f} p90 {np.percentile(L_,90):.1f} p99 {np.percentile(L_,99):.1f} max {L_.max():.1f};"
+              f" batch-trips per workgroup p10 {np.percentile(T_,10):.0f} p50 {np.percentile(T_,50):.0f} p90 {np.percentile(T_,90):.0f} max {T_.max():.0f};"
+              f" corr(lifetime, trips) {np.corrcoef(L_, T_)[0,1]:.2f}; workgroups later than p50+3us: {int((L_ > np.percentile(L_,50) + 3).sum())}")
+    # per CU (blockIdx mod 256 on a full surface: one workgroup of each layer): total trips and the latest end
+    if NWG >= 752:
+        n = min(256, NWG - 512)
+        cu_tr = wg_trips[0:n] + wg_trips[256:256 + n] + wg_trips[512:512 + n]
+        cu_end = np.maximum.reduce([wg_life_all[0:n], wg_life_all[256:256 + n], wg_life_all[512:512 + n]])
+        print(f"   per CU slot (b, b+256, b+512): total batch-trips p10 {np.percentile(cu_tr,10):.0f} p50 {np.percentile(cu_tr,50):.0f} p90 {np.percentile(cu_tr,90):.0f} max {cu_tr.max():.0f};"
+              f" latest end p50 {np.percentile(cu_end,50):.1f} p90 {np.percentile(cu_end,90):.1f} max {cu_end.max():.1f}; corr {np.corrcoef(cu_tr, cu_end)[0,1]:.2f}")
     ctx.close()
