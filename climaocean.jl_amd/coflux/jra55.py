@@ -11,8 +11,9 @@ Reference surface being mirrored:
 What is here: the dataset objects, the `start_date` / `end_date` → snapshot-counter mapping (repeat-year wrap, multi-year
 clamping, leap days), and a snapshot PROVIDER — `provider(n) -> {variable: float32[320, 640]}` — for
 models.JRA55PrescribedAtmosphere's sliding HBM window (cf_window_*), reading RAW little-endian Float32 planes with
-`np.memmap`.  NetCDF4/HDF5 decoding is not possible in this image (no netCDF4 / h5py / HDF5 library); the one-line
-conversion a maintainer runs once per yearly file, anywhere netCDF4 exists, is
+`np.memmap`, or NetCDF CLASSIC files (`nccopy -k classic tas_1990.nc4 tas_1990.nc`) through scipy.io.netcdf_file
+(ClassicNetCDFFiles).  NetCDF4/HDF5 decoding itself is not possible in this image (no netCDF4 / h5py / HDF5 library);
+the one-line conversion to raw planes a maintainer runs once per yearly file, anywhere netCDF4 exists, is
 
     python -c "import netCDF4, sys; f, v = sys.argv[1:]; netCDF4.Dataset(f)[v][:].astype('<f4').tofile(f[:-3] + '.f32')" tas_1990.nc tas
 
@@ -135,9 +136,62 @@ class RawPlaneFiles:
         return m[k]
 
 
+class ClassicNetCDFFiles:
+    """`<dir>/<shortname>_<year>.nc` in the NetCDF CLASSIC format (CDF-1/2/5 — what `nccopy -k classic` or `-k cdf5` writes
+    from the distributed NetCDF-4 files), read with scipy.io.netcdf_file (memory-mapped; this image has no HDF5 library, so
+    NetCDF-4 itself stays out of reach).  The variable is looked up by shortname, falling back to the file's only
+    3-D variable; `scale_factor` / `add_offset` are applied, the fill value is passed through.  Same `plane()` contract
+    as RawPlaneFiles: Float32 [320, 640]."""
+
+    def __init__(self, directory, shortnames=JRA55_SHORTNAMES, shape=(NY, NX)):
+        self.dir, self.shape = directory, tuple(shape)
+        self.shortnames = tuple(shortnames)
+        self._vars = {}
+
+    def path(self, shortname, year):
+        return os.path.join(self.dir, f"{shortname}_{year}.nc")
+
+    def _variable(self, shortname, year):
+        key = (shortname, year)
+        v = self._vars.get(key)
+        if v is None:
+            from scipy.io import netcdf_file
+            p = self.path(shortname, year)
+            if not os.path.exists(p):
+                raise FileNotFoundError(f"{p}: JRA55 NetCDF (classic) file missing")
+            f = netcdf_file(p, "r", mmap=True)
+            var = f.variables.get(shortname)
+            if var is None:
+                cubes = [x for x in f.variables.values() if len(x.shape) == 3]
+                if len(cubes) != 1:
+                    raise KeyError(f"{p}: no variable '{shortname}' and {len(cubes)} three-dimensional variables to choose from")
+                var = cubes[0]
+            if tuple(var.shape[1:]) != self.shape:
+                raise ValueError(f"{p}: variable of shape {var.shape}, expected [time, {self.shape[0]}, {self.shape[1]}]")
+            v = self._vars[key] = (f, var, float(getattr(var, "scale_factor", 1.0)), float(getattr(var, "add_offset", 0.0)))
+        return v
+
+    def plane(self, shortname, year, k):
+        _, var, scale, offset = self._variable(shortname, year)
+        if not 0 <= k < var.shape[0]:
+            raise IndexError(f"{self.path(shortname, year)} holds {var.shape[0]} snapshots, asked for {k}")
+        a = np.asarray(var[k], dtype=np.float32)   # big-endian on disk → native Float32
+        if scale != 1.0 or offset != 0.0:
+            a = (a * np.float32(scale) + np.float32(offset)).astype(np.float32)
+        return a
+
+
+def plane_files(directory):
+    """RawPlaneFiles or ClassicNetCDFFiles, by what the directory holds (`*.f32` wins)."""
+    names = os.listdir(directory) if os.path.isdir(directory) else []
+    if any(n.endswith(".f32") for n in names) or not any(n.endswith(".nc") for n in names):
+        return RawPlaneFiles(directory)
+    return ClassicNetCDFFiles(directory)
+
+
 def atmosphere_provider(directory, calendar, files=None):
     """provider(n) for models.JRA55PrescribedAtmosphere: snapshot counter → {cf_atmos_source variable: float32[320, 640]}."""
-    files = files or RawPlaneFiles(directory)
+    files = files or plane_files(directory)
 
     def provider(n):
         year, k = calendar.record_of(n)
@@ -147,7 +201,7 @@ def atmosphere_provider(directory, calendar, files=None):
 
 def land_snapshots(directory, calendar, first=0, count=2, files=None):
     """{friver, licalvf}: float32[count, 320, 640] for JRA55PrescribedLand's in-memory window."""
-    files = files or RawPlaneFiles(directory)
+    files = files or plane_files(directory)
     out = {}
     for var in LAND_VARIABLES:
         out[var] = np.stack([files.plane(var, *calendar.record_of(first + n)) for n in range(count)]).astype(np.float32)

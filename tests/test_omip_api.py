@@ -20,7 +20,8 @@ from coflux import synthetic as syn
 def test_api_surface_of_the_omip_configurations():
     for name in ("TripolarGrid", "build_coupled_model", "omip_forcing", "JRA55PrescribedLand", "NormalizeSalinity"):
         assert hasattr(cm, name), name
-    for name in ("RepeatYearJRA55", "MultiYearJRA55", "SnapshotCalendar", "RawPlaneFiles", "atmosphere_provider", "JRA55_SHORTNAMES"):
+    for name in ("RepeatYearJRA55", "MultiYearJRA55", "SnapshotCalendar", "RawPlaneFiles", "ClassicNetCDFFiles", "plane_files",
+                 "atmosphere_provider", "JRA55_SHORTNAMES"):
         assert hasattr(jra55, name), name
     assert jra55.JRA55_SHORTNAMES == ("tas", "huss", "psl", "uas", "vas", "rlds", "rsds", "prra", "prsn", "friver", "licalvf")  # jra55_data_staging.jl:8
 
@@ -62,6 +63,39 @@ def test_raw_plane_files_round_trip(tmp_path):
         jra55.RawPlaneFiles(str(tmp_path)).plane("tas", 1991, 0)
     with pytest.raises(IndexError):
         jra55.RawPlaneFiles(str(tmp_path)).plane("tas", 1990, 5)
+
+
+def test_classic_netcdf_files_feed_the_same_planes(tmp_path):
+    """NetCDF classic files (what `nccopy -k classic` makes of the distributed NetCDF-4 ones) through scipy: the same planes
+    as the raw-plane reader, scale_factor / add_offset applied, the variable found by shortname or as the only 3-D one."""
+    from scipy.io import netcdf_file
+    snaps = syn.jra55_snapshots(3)
+    for var in abi.JRA55_VARIABLES:
+        f = netcdf_file(str(tmp_path / f"{var}_1990.nc"), "w")
+        f.createDimension("time", None); f.createDimension("lat", 320); f.createDimension("lon", 640)
+        name = var if var != "psl" else "sea_level_pressure"       # one file names its variable differently
+        v = f.createVariable(name, "f4", ("time", "lat", "lon"))
+        if var == "tas":                                            # packed: value = stored * scale + offset
+            v[:] = ((snaps[var] - 250.0) / 0.5).astype("f4"); v.scale_factor = 0.5; v.add_offset = 250.0
+        else:
+            v[:] = snaps[var]
+        f.close()
+    cal = jra55.SnapshotCalendar(jra55.RepeatYearJRA55(year=1990))
+    cal.records, cal.total = [(1990, k) for k in range(3)], 3
+    assert isinstance(jra55.plane_files(str(tmp_path)), jra55.ClassicNetCDFFiles)
+    provider = jra55.atmosphere_provider(str(tmp_path), cal)
+    for n in (0, 2, 4):
+        got = provider(n)
+        for var in abi.JRA55_VARIABLES:
+            assert got[var].dtype == np.float32 and got[var].shape == (320, 640)
+            if var == "tas":
+                np.testing.assert_allclose(got[var], snaps[var][n % 3], rtol=1e-6)
+            else:
+                np.testing.assert_array_equal(got[var], snaps[var][n % 3])
+    with pytest.raises(IndexError):
+        jra55.ClassicNetCDFFiles(str(tmp_path)).plane("tas", 1990, 3)
+    with pytest.raises(FileNotFoundError, match="classic"):
+        jra55.ClassicNetCDFFiles(str(tmp_path)).plane("tas", 1991, 0)
 
 
 def test_build_coupled_model_rejects_unknown_options_with_the_reference_strings():
