@@ -65,6 +65,7 @@ def test_raw_plane_files_round_trip(tmp_path):
         jra55.RawPlaneFiles(str(tmp_path)).plane("tas", 1990, 5)
 
 
+@pytest.mark.filterwarnings("ignore:Cannot close a netcdf_file")
 def test_classic_netcdf_files_feed_the_same_planes(tmp_path):
     """NetCDF classic files (what `nccopy -k classic` makes of the distributed NetCDF-4 ones) through scipy: the same planes
     as the raw-plane reader, scale_factor / add_offset applied, the variable found by shortname or as the only 3-D one."""
