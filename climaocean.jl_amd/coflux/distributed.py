@@ -81,17 +81,31 @@ class SlabHaloExchanger:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.backend = backend if self.world > 1 else "none"
+        if self.backend == "peer":
+            # cf_peer_halo_export fails (CF_ERR_COMM) on a rank whose device cannot give it fine-grained memory.  Every
+            # rank reaches the collectives below whatever happened locally: the ranks agree on the outcome first, and a
+            # failure anywhere moves ALL of them to the RCCL exchange together (a rank that raised before the gather
+            # would leave the others blocked in it — ADVICE r3).
+            mine, failure = None, None
+            try:
+                mine = ctx.peer_halo_export(max_fields=4, max_rows=self.rows)
+            except Exception as exc:  # noqa: BLE001 — reported below, on every rank
+                failure = f"rank {self.rank}: {exc}"
+            handles = [None] * self.world
+            dist.all_gather_object(handles, (mine, failure))
+            failures = [f for _, f in handles if f is not None]
+            if failures:
+                self.peer_fallback_reason = "; ".join(failures)
+                self.backend = "rccl"
+            else:
+                handles = [h for h, _ in handles]
+                ctx.peer_halo_connect(handles[self.rank - 1] if self.rank > 0 else None,
+                                      handles[self.rank + 1] if self.rank < self.world - 1 else None, self.rank, self.world)
         if self.backend == "rccl":
             from .runtime import comm_unique_id
             ident = [comm_unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(ident, src=0)
             ctx.comm_init(ident[0], self.rank, self.world)
-        elif self.backend == "peer":
-            mine = ctx.peer_halo_export(max_fields=4, max_rows=self.rows)
-            handles = [None] * self.world
-            dist.all_gather_object(handles, mine)
-            ctx.peer_halo_connect(handles[self.rank - 1] if self.rank > 0 else None,
-                                  handles[self.rank + 1] if self.rank < self.world - 1 else None, self.rank, self.world)
 
     def __call__(self, tensors):
         if self.backend == "rccl":

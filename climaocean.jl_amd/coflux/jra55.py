@@ -199,6 +199,16 @@ def atmosphere_provider(directory, calendar, files=None):
     return provider
 
 
+def land_provider(directory, calendar, files=None):
+    """provider(n) for models.JRA55PrescribedLand's sliding window: snapshot counter → {friver, licalvf: float32[320, 640]}."""
+    files = files or plane_files(directory)
+
+    def provider(n):
+        year, k = calendar.record_of(n)
+        return {var: files.plane(var, year, k) for var in LAND_VARIABLES}
+    return provider
+
+
 def land_snapshots(directory, calendar, first=0, count=2, files=None):
     """{friver, licalvf}: float32[count, 320, 640] for JRA55PrescribedLand's in-memory window."""
     files = files or plane_files(directory)

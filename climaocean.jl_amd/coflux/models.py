@@ -477,8 +477,10 @@ def omip_forcing(arch, sea_ice, *, forcing_dir, start_date, end_date, repeat_yea
     sea_ice_albedo = ic.SeaIceAlbedo() if sea_ice is not None else None   # SeaIceAlbedo(hi, hs, Ts): reads the live ice fields
     radiation = Radiation(ocean_surface=ic.SurfaceRadiationProperties(0.06, 1.00),
                           sea_ice_surface=ic.SurfaceRadiationProperties(sea_ice_albedo, 1.0) if sea_ice is not None else None)
-    land = JRA55PrescribedLand(jra55.land_snapshots(forcing_dir, calendar, 0, min(backend_size, calendar.total), files),
-                               time_indices_in_memory=min(backend_size, calendar.total), device=device)
+    # JRA55PrescribedLand(arch; …) streams the whole record like the atmosphere: same calendar, same window length
+    land = JRA55PrescribedLand(provider=jra55.land_provider(forcing_dir, calendar, files), total_snapshots=calendar.total,
+                               time_indices_in_memory=max(2, backend_size), cyclic=dataset.cyclic, device=device)
+    land.dataset, land.calendar = dataset, calendar
     return atmosphere, radiation, land
 
 
@@ -535,10 +537,9 @@ def update_state(model):
         land = model.land
         if not hasattr(itf, "land_freshwater"):
             itf.land_freshwater = itf.context.zeros()
-        x = model.clock.time / land.time_interval
-        l1 = int(np.floor(x)) % land.n_levels
+        l1, l2, lfrac = land.levels(model.clock.time)   # (the record's calendar: cyclic repeat year / clamped multi-year)
         itf.context.interpolate_land_freshwater(land.data["friver"], land.data.get("licalvf"), itf.weights, itf.land_freshwater,
-                                                level1=l1, level2=(l1 + 1) % land.n_levels, time_fraction=x - np.floor(x))
+                                                level1=l1, level2=l2, time_fraction=lfrac)
         itf.context.set_land_freshwater(itf.land_freshwater)
     if model.sea_ice is not None and itf.sea_ice_ocean_heat_flux is not None:
         # compute_sea_ice_ocean_fluxes!: the three-equation exchange and frazil from the current ocean surface and the
@@ -592,15 +593,66 @@ def run(simulation):
 class JRA55PrescribedLand:
     """JRA55PrescribedLand(arch; …) — atmosphere.jl:46: river discharge and calving (friver, licalvf of
     jra55_data_staging.jl:8) as 3-hourly Float32 windows on the JRA55 grid; OceanSeaIceModel(…; land) interpolates them
-    each step and the freshwater reaches the salinity flux."""
+    each step and the freshwater reaches the salinity flux.
 
-    def __init__(self, snapshots=None, *, time_indices_in_memory=2, time_interval=3 * hours, device=0):
-        dev = torch.device("cuda", device)
+    Two backends, like the atmosphere: the whole record in memory (`snapshots` = {friver, licalvf}: [n, 320, 640]), or a
+    sliding window of `time_indices_in_memory` device slots fed by `provider(n) -> {friver, licalvf}: [320, 640]`
+    (`total_snapshots` records; `cyclic` = RepeatYearJRA55, clamped = MultiYearJRA55).  The window follows the monotone
+    snapshot COUNTER (slot = counter mod slots), so a repeat year whose length is no multiple of the slot count never
+    puts two consecutive snapshots in one slot.  Two 0.8 MB planes per 3 h: read synchronously, no prefetch thread."""
+
+    def __init__(self, snapshots=None, *, provider=None, total_snapshots=None, time_indices_in_memory=2, time_interval=3 * hours,
+                 device=0, cyclic=True, source_size=(synthetic.JRA55_NX, synthetic.JRA55_NY)):
+        dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.time_interval = time_interval
+        self.cyclic = cyclic
+        self.provider = provider
+        if provider is not None:
+            if total_snapshots is None:
+                raise ValueError("a snapshot provider needs total_snapshots")
+            if time_indices_in_memory < 2:
+                raise ValueError("time_indices_in_memory must be >= 2")
+            self.n_levels = total_snapshots
+            self.n_slots = time_indices_in_memory
+            shape = (self.n_slots, source_size[1], source_size[0])
+            self.data = {k: torch.zeros(shape, dtype=torch.float32, device=dev) for k in ("friver", "licalvf")}
+            self._slot_counter = [None] * self.n_slots   # which snapshot counter each slot holds
+            return
         if snapshots is None:
             snapshots = synthetic.jra55_land_snapshots(time_indices_in_memory)
         self.data = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in snapshots.items()}
         self.n_levels = self.data["friver"].shape[0]
-        self.time_interval = time_interval
+
+    def _wrap(self, n):
+        return n % self.n_levels if self.cyclic else min(max(n, 0), self.n_levels - 1)
+
+    def levels(self, t):
+        """(level1, level2, ñ) into `self.data` for model time t — the bracketing snapshots made resident first on the
+        sliding-window backend.  Cyclic (repeat year) or clamped (multi-year record ends) like the atmosphere."""
+        x = t / self.time_interval
+        base = int(np.floor(x))
+        frac = x - base
+        if self.cyclic:
+            k1, k2 = base, base + 1
+        else:
+            k1 = min(max(base, 0), self.n_levels - 1)
+            k2 = min(max(base + 1, 0), self.n_levels - 1)
+            if not (0 <= base < self.n_levels - 1):
+                frac = 0.0
+        if self.provider is None:
+            return self._wrap(k1), self._wrap(k2), frac
+        for k in (k1, k2):
+            slot = k % self.n_slots
+            if self._slot_counter[slot] != k:
+                snap = self.provider(self._wrap(k))
+                for v, dst in self.data.items():
+                    plane = snap.get(v)
+                    if plane is None:
+                        dst[slot].zero_()
+                    else:
+                        dst[slot].copy_(torch.as_tensor(np.ascontiguousarray(plane, dtype=np.float32)))
+                self._slot_counter[slot] = k
+        return k1 % self.n_slots, k2 % self.n_slots, frac
 
 
 class NormalizeSalinity:

@@ -397,11 +397,11 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
     if ((long long)(grid->nx + 2 * grid->ring) * (grid->ny + 2 * grid->ring) >= (1LL << 24))
         return fail(nullptr, CF_ERR_INVALID, "surface of %d x %d cells: the kernels index a surface with fewer than 2^24 cells per context "
                     "(shard it by latitude slabs)", grid->nx, grid->ny);
-    cf_ctx* ctx = new cf_ctx();
-    ctx->device = device;
     if ((long long)(grid->nx + 2 * grid->hx) * (grid->ny + 2 * grid->hy) >= (1LL << 29))
         return fail(nullptr, CF_ERR_INVALID, "fields of %d x %d doubles with halos (%d, %d): the kernels address a field with 32-bit byte "
                     "offsets (fewer than 2^29 doubles)", grid->nx, grid->ny, grid->hx, grid->hy);
+    cf_ctx* ctx = new cf_ctx();   // (every validation of the grid is above: nothing below returns without deleting it)
+    ctx->device = device;
     ctx->grid = GridDesc{grid->nx, grid->ny, grid->hx, grid->hy, grid->ring, grid->nx + 2 * grid->hx};
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;

@@ -293,7 +293,11 @@ hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc
     // 600 → 17.3, 560 → 17.5 µs; no effect below 2 workgroups per CU, slightly negative above 4: left alone there)
     const int cus = L.cu_count > 0 ? L.cu_count : 256;
     if (blocks > 2 * cus && blocks <= 4 * cus) blocks = std::max(2 * cus, blocks * 25 / 32);
-    if (const char* cap = std::getenv("COFLUX_INTERP_BLOCKS")) blocks = std::min(blocks, std::max(1, std::atoi(cap)));  // (experiments)
+    static const int blocks_cap = [] {  // (experiments: COFLUX_EXPERIMENTS=1 COFLUX_INTERP_BLOCKS=n, read once)
+        const char* cap = experiment_knob("COFLUX_INTERP_BLOCKS");
+        return cap ? std::max(1, std::atoi(cap)) : 0;
+    }();
+    if (blocks_cap > 0) blocks = std::min(blocks, blocks_cap);
     const size_t lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double);
 #define CF_LAUNCH_INTERP(ROWS_)                                                                                        \
     hipLaunchKernelGGL(interpolate_kernel<ROWS_>, dim3(blocks), dim3(64 * IT_WAVES), lds, st, make_source(s),          \

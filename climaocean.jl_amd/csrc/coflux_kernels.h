@@ -3,9 +3,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "coflux_device.hpp"
 
 namespace coflux {
+
+// Experiment knobs (COFLUX_LAYERS, COFLUX_SORT_WINDOWS, COFLUX_INTERP_BLOCKS: scheduling only, never results) are honoured
+// only in a process started with COFLUX_EXPERIMENTS=1, and each is read once per process — a stray variable in a
+// production environment cannot silently change what a run measures.
+inline const char* experiment_knob(const char* name) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("COFLUX_EXPERIMENTS");
+        return e != nullptr && e[0] == '1';
+    }();
+    return enabled ? std::getenv(name) : nullptr;
+}
+
 
 struct LoopParams;
 struct IceParams;

@@ -33,10 +33,11 @@ struct Geom {
     static constexpr int LDS_BYTES = PARAMS_OFFSET + (int)sizeof(DevParams);
 };
 static_assert(Geom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
-constexpr int AO_LAYER_1 = 1024, AO_LAYER_2 = 768, AO_LAYER_3 = 512;  // wet cells per chunk of the last three arrival layers (plan_chunk_rounds)
+constexpr int AO_LAYER_1 = AO_CHUNK < 1024 ? AO_CHUNK : 1024, AO_LAYER_2 = AO_CHUNK < 768 ? AO_CHUNK : 768, AO_LAYER_3 = 512;  // wet cells per chunk of the last three arrival layers (plan_chunk_rounds)
 static_assert(AO_LAYER_1 <= AO_CHUNK && AO_LAYER_1 >= AO_LAYER_2 && AO_LAYER_2 >= AO_LAYER_3, "layer sizes");
 static_assert(AO_BINS == 64, "Geom<>::PARAMS_OFFSET spells the bin count out");
 static_assert(Geom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow solver workgroups must fit the CU's 160 KB of LDS");
+
 
 // ---------------------------------------------------------------------------------------------
 // Chunk table.  Two quantisation effects cost ≈ 25 % each when every workgroup simply takes 512 surface
@@ -203,7 +204,7 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
         // 1024s for everything before the last two layers (none on a surface that fits three layers), then as
         // many 768s as still needed, then 512s
         int W1 = AO_LAYER_1, W2 = AO_LAYER_2, W3 = AO_LAYER_3;
-        if (const char* env = std::getenv("COFLUX_LAYERS")) {  // experiments only: "w1,w2,w3" (multiples of 64, w1 ≥ w2 ≥ w3, w1 ≤ AO_CHUNK)
+        if (const char* env = experiment_knob("COFLUX_LAYERS")) {  // experiments only (with COFLUX_EXPERIMENTS=1): "w1,w2,w3" (multiples of 64, w1 ≥ w2 ≥ w3, w1 ≤ AO_CHUNK)
             int a = 0, b = 0, c = 0;
             if (std::sscanf(env, "%d,%d,%d", &a, &b, &c) == 3 && a <= AO_CHUNK && a >= b && b >= c && c >= 64 && a % 64 == 0 && b % 64 == 0 && c % 64 == 0) {
                 W1 = a;

@@ -31,6 +31,9 @@
 #include "coflux_lean.hpp"
 #include "coflux_solver_shared.hpp"
 
+#ifndef CF_LEAN_WAVES
+#define CF_LEAN_WAVES 3  // waves per SIMD the narrow lean kernel is compiled for (4: ≤ 128 VGPRs; needs ≤ 40 960 B of LDS per workgroup)
+#endif
 #ifndef CF_LEAN_PREFETCH
 #define CF_LEAN_PREFETCH 0  // 1: the next batch's inputs are requested before the current batch iterates (measured: 23 more live registers cost more than the wait, 70.3 vs 68.3 us)
 #endif
@@ -108,6 +111,9 @@ struct LeanGeom {
 };
 static_assert(LeanGeom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow lean solver workgroups must fit the CU's 160 KB of LDS");
 static_assert(LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
+#ifndef CF_SKIP_LDS_ASSERT
+static_assert(CF_LEAN_WAVES == 3 || LeanGeom<AO_BLOCK>::LDS_BYTES <= 40960, "four narrow lean workgroups per CU: 160 KB / 4 in 1280-byte granules");
+#endif
 
 // zero_interface_state of a land cell: all fluxes 0, T = 0 K (and, in the fused form, zero net fluxes inside the interior)
 template <bool FUSE, bool FUSE_INTERP = false>
@@ -139,7 +145,7 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 // solver leaves idle), writes them (the API's outputs) and keeps what it needs in registers; land cells get theirs with
 // their zeros.  update_state! is then two launches: this kernel and the face stresses.
 template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false>
-__global__ __launch_bounds__(BLOCK, 3) void ao_lean_kernel(LeanArgs unused_by_name) {
+__global__ __launch_bounds__(BLOCK, BLOCK == AO_BLOCK ? CF_LEAN_WAVES : 3) void ao_lean_kernel(LeanArgs unused_by_name) {
     using Geo = LeanGeom<BLOCK>;
     constexpr int CHUNK = Geo::CHUNK;
     LeanArgsPtr K = opaque((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
@@ -595,8 +601,13 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
     A.T_offset = P.T_offset;
     A.wx_reciprocal = row_reciprocal(G.nx + 2 * G.ring);
     A.sort_enabled = L.lean_hints;
-    if (L.lean_hints > 1)
-        if (const char* e = std::getenv("COFLUX_SORT_WINDOWS")) A.sort_enabled = std::max(1, std::min(8, std::atoi(e)));  // (experiments: 1, 2, 4, 8)
+    if (L.lean_hints > 1) {
+        static const int windows = [] {  // (experiments: COFLUX_EXPERIMENTS=1 COFLUX_SORT_WINDOWS=1|2|4|8, read once)
+            const char* e = experiment_knob("COFLUX_SORT_WINDOWS");
+            return e ? std::max(1, std::min(8, std::atoi(e))) : 0;
+        }();
+        if (windows > 0) A.sort_enabled = windows;
+    }
     if (net) {  // the fused form: the epilogue also writes the cell-local net ocean fluxes (constant ocean albedo only)
         if (ice) A.I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress, nullptr};
         A.I.land = land;

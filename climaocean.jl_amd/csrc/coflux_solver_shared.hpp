@@ -12,7 +12,10 @@ namespace coflux {
 
 constexpr int TABLE_BYTES = TABLE_DOUBLES * 8;
 constexpr int AO_BLOCK = 256;
-constexpr int AO_CHUNK = 1280;  // capacity of a narrow workgroup's wet-cell list = the most wet cells a chunk can hold
+#ifndef CF_AO_CHUNK
+#define CF_AO_CHUNK 1280
+#endif
+constexpr int AO_CHUNK = CF_AO_CHUNK;  // capacity of a narrow workgroup's wet-cell list = the most wet cells a chunk can hold
 constexpr int AO_BLOCK_WIDE = 768;
 constexpr int AO_CHUNK_WIDE = 3072;
 constexpr int AO_BINS = 64;    // trip-count bins of the per-chunk counting sort (one wave scans them)

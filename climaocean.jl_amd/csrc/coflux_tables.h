@@ -19,7 +19,10 @@ constexpr int PSI_FINE_BINADES = 14;  // x < 16384
 constexpr int PSI_SUB_BITS = 3;
 constexpr int PSI_SUB = 1 << PSI_SUB_BITS;  // pieces per fine binade
 constexpr int PSI_FINE_SEG = PSI_FINE_BINADES * PSI_SUB;
-constexpr int PSI_COARSE_SUB_BITS = 2;
+#ifndef CF_PSI_COARSE_SUB_BITS
+#define CF_PSI_COARSE_SUB_BITS 2  // (experiments: 0 = one piece per coarse binade, 39 → 32 KB of tables)
+#endif
+constexpr int PSI_COARSE_SUB_BITS = CF_PSI_COARSE_SUB_BITS;
 constexpr int PSI_COARSE_SUB = 1 << PSI_COARSE_SUB_BITS;  // pieces per coarse binade
 constexpr int PSI_SEG = PSI_FINE_SEG + (PSI_BINADES - PSI_FINE_BINADES) * PSI_COARSE_SUB;
 constexpr int PSI_DEG = 6;       // polynomial degree per segment, in u = x − (segment start)

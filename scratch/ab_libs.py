@@ -47,7 +47,7 @@ best = {}
 for rnd in range(2):
     for spec in tags:
         tag, _, opts = spec.partition(":")
-        env = dict(os.environ, AB_ROOT=ROOT)
+        env = dict(os.environ, AB_ROOT=ROOT, COFLUX_EXPERIMENTS="1")
         if tag != "prod": env["LIBCOFLUX"] = os.path.join(ROOT, "scratch", f"libcoflux_{tag}.so")
         opts, _, layers = opts.partition("@")
         if opts: env["AB_OPTS"] = json.dumps(dict(kv.split("=") for kv in opts.split(",")))

@@ -24,7 +24,7 @@ print(json.dumps(dict(interp_us=round(t * 1e3, 2))))
 ctx.close()
 '''
 for spec in sys.argv[1:] or ["default"]:
-    env = dict(os.environ, AB_ROOT=ROOT)
+    env = dict(os.environ, AB_ROOT=ROOT, COFLUX_EXPERIMENTS="1")
     for kv in spec.split(","):
         if "=" in kv:
             k, v = kv.split("="); env[k] = v

@@ -107,3 +107,54 @@ def test_two_rank_slabs_reproduce_the_global_fluxes_gloo():
             lo = 1 if rank == 0 else 0  # the outermost ring rows read un-exchanged outer halos: skip
             hi = v.shape[0] - (1 if rank == 1 else 0)
             np.testing.assert_array_equal(v[lo:hi], ref[k][H - 1 + j0 + lo:H - 1 + j0 + hi], err_msg=f"{rank} {k}")
+
+
+class _FakeContext:
+    """What SlabHaloExchanger touches of a FluxContext; rank `fail_rank`'s device has no fine-grained memory."""
+
+    def __init__(self, rank, fail_rank):
+        from types import SimpleNamespace
+        self.grid = SimpleNamespace(ring=1)
+        self.rank, self.fail_rank, self.calls = rank, fail_rank, []
+
+    def peer_halo_export(self, max_fields, max_rows):
+        self.calls.append("export")
+        if self.rank == self.fail_rank:
+            raise RuntimeError("cf_peer_halo_export: CF_ERR_COMM (no fine-grained device memory)")
+        return b"handle-%d" % self.rank
+
+    def peer_halo_connect(self, south, north, rank, world):
+        self.calls.append("connect")
+
+    def comm_init(self, ident, rank, world):
+        self.calls.append(("comm_init", ident, rank, world))
+
+
+def _fallback_worker(rank, world, port, fail_rank, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from coflux import distributed, runtime
+        runtime.comm_unique_id = lambda: b"unique-id"      # (the real one needs the HIP library)
+        ctx = _FakeContext(rank, fail_rank)
+        ex = distributed.SlabHaloExchanger(ctx, 10, 3, backend="peer")
+        out[rank] = (ex.backend, list(ctx.calls), getattr(ex, "peer_fallback_reason", None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_backend_falls_back_to_rccl_on_every_rank_together_gloo():
+    """a rank whose cf_peer_halo_export fails must not leave the others blocked in the handle gather — the
+    ranks agree on the outcome and switch to the RCCL exchange together; without a failure they connect the mailboxes."""
+    for fail_rank, want in ((1, "rccl"), (-1, "peer")):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_fallback_worker, args=(2, _free_port(), fail_rank, out), nprocs=2, join=True)
+        for rank in (0, 1):
+            backend, calls, reason = out[rank]
+            assert backend == want, (fail_rank, rank, backend)
+            if want == "rccl":
+                assert ("comm_init", b"unique-id", rank, 2) in calls and "connect" not in calls
+                assert "rank 1" in reason and "CF_ERR_COMM" in reason
+            else:
+                assert calls == ["export", "connect"] and reason is None

@@ -168,24 +168,59 @@ def test_omip_forcing_from_raw_planes_wraps_the_repeat_year(tmp_path):
     assert radiation.ocean_surface.albedo == 0.06 and radiation.ocean_surface.emissivity == 1.0      # atmosphere.jl:43
     assert isinstance(atmosphere.dataset, jra55.RepeatYearJRA55) and atmosphere.calendar.total == 2920
     atmosphere.calendar.records, atmosphere.calendar.total = [(1990, k) for k in range(5)], 5   # the files hold five planes
-    atmosphere.n_levels = 5
+    atmosphere.n_levels = land_c.n_levels = 5
+    assert land_c.provider is not None and land_c.n_slots == 3 and land_c.calendar is atmosphere.calendar
     nx, ny, nz, h = 90, 40, 10, 3
     grid = cm.LatitudeLongitudeGrid(size=(nx, ny, nz), halo=(h, h, h))
     state = syn.ocean_state(nx, ny, h, h)
     results = []
-    for atm in (atmosphere, cm.JRA55PrescribedAtmosphere(snaps)):
+    for atm, lnd in ((atmosphere, land_c), (cm.JRA55PrescribedAtmosphere(snaps), cm.JRA55PrescribedLand(land))):
         ocean = cm.ocean_simulation(grid)
         cm.set_surface(ocean, T=state["T"], S=state["S"], u=state["u"], v=state["v"], mask=state["mask"])
-        coupled = cm.OceanSeaIceModel(ocean, atmosphere=atm, radiation=radiation)
+        coupled = cm.OceanSeaIceModel(ocean, atmosphere=atm, radiation=radiation, land=lnd)
         out = []
-        for _ in range(6):
-            cm.time_step(coupled, 150 * cm.minutes)    # 2.5 h per step: crosses the wrap (5 × 3 h) at step 6
+        for _ in range(8):
+            # 2.5 h per step: leaves the land's three-slot window after step 3 (it used to replay the first
+            # `backend_size` snapshots for ever) and crosses the repeat-year wrap (5 × 3 h) at step 6
+            cm.time_step(coupled, 150 * cm.minutes)
             out.append(ocean.model.top_boundary_conditions.T.clone())
+            out.append(ocean.model.top_boundary_conditions.S.clone())
         results.append(out)
         coupled.interfaces.context.close()
     for a, b in zip(*results):
         assert torch_equal(a, b)
     atmosphere.close()
+
+
+def test_land_window_streams_the_whole_record_past_its_slots():
+    """JRA55PrescribedLand on the provider backend: a record longer than the window is streamed through the
+    slots by snapshot counter — cyclic for a repeat year, clamped at the ends of a multi-year record — and the two
+    bracketing snapshots never share a slot, also across the wrap of a record whose length is no multiple of the slots."""
+    total, slots, ny, nx = 7, 3, 4, 6
+    planes = {v: np.arange(total, dtype=np.float32)[:, None, None] * (1.0 if v == "friver" else -2.0) + np.zeros((total, ny, nx), np.float32)
+              for v in ("friver", "licalvf")}
+    reads = []
+
+    def provider(n):
+        reads.append(n)
+        return {v: planes[v][n] for v in planes}
+    for cyclic in (True, False):
+        land = cm.JRA55PrescribedLand(provider=provider, total_snapshots=total, time_indices_in_memory=slots, cyclic=cyclic,
+                                      device="cpu", source_size=(nx, ny))
+        in_memory = cm.JRA55PrescribedLand(planes, cyclic=cyclic, device="cpu")
+        for step in range(-2, 40):
+            t = (step * 0.7 + 0.1) * land.time_interval
+            l1, l2, frac = land.levels(t)
+            m1, m2, mfrac = in_memory.levels(t)
+            assert l1 != l2 or m1 == m2
+            assert frac == mfrac
+            for v in planes:
+                assert np.array_equal(land.data[v][l1].numpy(), in_memory.data[v][m1].numpy()), (cyclic, step, v)
+                assert np.array_equal(land.data[v][l2].numpy(), in_memory.data[v][m2].numpy()), (cyclic, step, v)
+        if not cyclic:   # beyond the record's last snapshot: held there, no blending
+            l1, l2, frac = land.levels(100 * land.time_interval)
+            assert frac == 0.0 and float(land.data["friver"][l1][0, 0]) == total - 1 == float(land.data["friver"][l2][0, 0])
+    assert max(reads) == total - 1 and min(reads) == 0
 
 
 def torch_equal(a, b):
