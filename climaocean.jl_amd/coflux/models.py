@@ -650,7 +650,7 @@ class JRA55PrescribedLand:
                     if plane is None:
                         dst[slot].zero_()
                     else:
-                        dst[slot].copy_(torch.as_tensor(np.ascontiguousarray(plane, dtype=np.float32)))
+                        dst[slot].copy_(torch.from_numpy(np.array(plane, dtype=np.float32)))  # (a copy: memory-mapped planes are read-only)
                 self._slot_counter[slot] = k
         return k1 % self.n_slots, k2 % self.n_slots, frac
 

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "climaocean.jl_amd"))
 import numpy as np, torch
 from coflux import abi, synthetic as syn, interface_computations as ic
 from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, NET_NAMES, FluxContext
-nx, ny, h = 1440, 560, 7
+nx, ny, h = 1440, int(os.environ.get("NY", 560)), 7
 ocean_np = syn.ocean_state(nx, ny, h, h); src_np = syn.jra55_snapshots(2)
 fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h)
 for name, mk in (("default", lambda: ic.SimilarityTheoryFluxes()), ("corrected", ic.corrected_atmosphere_ocean_fluxes)):

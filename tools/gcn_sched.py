@@ -1,0 +1,474 @@
+#!/usr/bin/env python3
+"""gcn_sched.py — a post-register-allocation instruction scheduler for straight-line pieces of gfx950 (CDNA4) assembly.
+
+Why: LLVM's scheduling model for gfx940/gfx950 prices an FP64 VALU instruction at its ISSUE cost (one quad cycle), so it
+sees no reason to interleave independent chains; the hardware issues a wave's instructions in order and a dependent
+FP64 instruction waits ≈ 8+ cycles for its operand (scratch/ubench_lat.hip).  A wave that has its SIMD to itself (a
+latitude slab of a strongly scaled run) therefore runs the Monin–Obukhov iteration at ≈ 1750 cycles although it issues
+in ≈ 580.  This tool re-orders the instructions of the hot loop's basic blocks of the compiler's own output — same
+instructions, same registers, same results bit for bit — with the measured latencies, recomputes the s_waitcnt
+lgkmcnt() counts for the new order of the LDS reads and re-inserts the hazard no-ops of the gfx940 family.
+
+Scope (deliberately narrow): blocks without stores / global memory / LDS writes / exec writes / scalar memory;
+anything it does not understand makes it leave the block alone.
+
+  gcn_sched.py in.s out.s --function <substring> [--blocks-with ds_read_b128] [--report]
+"""
+import re
+import sys
+import argparse
+from collections import defaultdict
+
+# ---------------------------------------------------------------------------------------------
+# machine model (cycles; scratch/ubench_lat.hip, scratch/ubench_valu.hip on MI355X)
+# ---------------------------------------------------------------------------------------------
+# issue: cycles the wave's issue port is busy; latency: issue → a dependent instruction may issue
+MODEL = dict(
+    f64=(4, 8), f64_trans=(16, 24), f32=(2, 5), f32_trans=(8, 12), int32=(2, 5), int_vop3=(4, 8), cvt=(4, 8),
+    mov64=(4, 8), cmp64=(4, 8), cmp32=(2, 5), salu=(1, 2), lds=(2, 110), nop=(1, 1), other=(4, 8))
+
+
+class Inst:
+    __slots__ = ("text", "op", "defs", "uses", "kind", "is_lds", "is_valu", "is_trans", "index", "comment_only", "raw_lines")
+
+    def __init__(self, text):
+        self.text = text
+        self.raw_lines = [text]
+
+
+REG_RANGE = re.compile(r"\b([vsa])\[(\d+):(\d+)\]")
+REG_ONE = re.compile(r"\b([vs])(\d+)\b")
+
+
+def regs_of(tok):
+    """registers named in one operand token → set of 'v12', 's3', 'vcc_lo', 'vcc_hi', 'exec_lo', …"""
+    out = set()
+    t = tok
+    for m in REG_RANGE.finditer(t):
+        for n in range(int(m.group(2)), int(m.group(3)) + 1):
+            out.add(f"{m.group(1)}{n}")
+    t2 = REG_RANGE.sub(" ", t)
+    for m in REG_ONE.finditer(t2):
+        out.add(f"{m.group(1)}{m.group(2)}")
+    if re.search(r"\bvcc\b", t2):
+        out |= {"vcc_lo", "vcc_hi"}
+    for h in ("vcc_lo", "vcc_hi", "exec_lo", "exec_hi", "m0", "scc"):
+        if re.search(rf"\b{h}\b", t2):
+            out.add(h)
+    if re.search(r"\bexec\b", t2):
+        out |= {"exec_lo", "exec_hi"}
+    return out
+
+
+def split_operands(s):
+    """top-level comma split (brackets protect v[1:2])"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "[(":
+            depth += 1
+        elif ch in "])":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+FMAC = re.compile(r"^v_(fmac|mac|pk_fmac)_")
+TRANS = re.compile(r"^v_(rcp|rsq|sqrt|log|exp|sin|cos)_")
+
+
+def classify(op):
+    if op.startswith("ds_read") or op.startswith("ds_load"):
+        return "lds"
+    if op in ("s_nop",):
+        return "nop"
+    if op.startswith("s_"):
+        return "salu"
+    if TRANS.match(op):
+        return "f64_trans" if "f64" in op else "f32_trans"
+    if op.startswith("v_cmp"):
+        return "cmp64" if ("f64" in op or "64" in op.split("_")[-2:][0]) else "cmp32"
+    if op.startswith("v_cvt"):
+        return "cvt"
+    if op.startswith("v_mov_b64") or op.startswith("v_lshl_add_u64") or op.startswith("v_lshlrev_b64"):
+        return "mov64"
+    if "f64" in op:
+        return "f64"
+    if op.startswith(("v_lshl_add_u32", "v_add3_u32", "v_bfe", "v_and_or", "v_mul_lo", "v_mul_hi", "v_mad_", "v_lshl_or", "v_cndmask_b32_e64")):
+        return "int_vop3"
+    if re.search(r"_f32|_f16", op):
+        return "f32"
+    if op.startswith("v_"):
+        return "int32"
+    return "other"
+
+
+UNSAFE = re.compile(r"^(ds_write|ds_store|ds_add|ds_|global_|flat_|buffer_|scratch_|s_load|s_store|s_buffer|s_barrier|s_setprio|s_sleep|s_sendmsg|s_endpgm|"
+                    r"s_cbranch|s_branch|s_setpc|s_swappc|s_getpc|v_readfirstlane|v_writelane|v_permlane|ds_bpermute|ds_permute|s_memtime|s_getreg|s_setreg|"
+                    r"v_mfma|v_smfma|s_set_gpr_idx|v_movrel|v_div_scale|v_div_fmas|v_mbcnt)")
+
+
+def parse_inst(line):
+    """one assembly line → Inst (defs / uses as register-name sets), or None for something that pins the block"""
+    code = line.split(";")[0].strip()
+    ins = Inst(line)
+    if not code:
+        ins.comment_only = True
+        ins.op = ""
+        ins.defs, ins.uses, ins.kind = set(), set(), "nop"
+        ins.is_lds = ins.is_valu = ins.is_trans = False
+        return ins
+    ins.comment_only = False
+    m = re.match(r"(\S+)\s*(.*)", code)
+    op, rest = m.group(1), m.group(2)
+    ins.op = op
+    if UNSAFE.match(op) and not op.startswith("ds_read"):
+        return None
+    ops = split_operands(rest)
+    ins.kind = classify(op)
+    ins.is_lds = ins.kind == "lds"
+    ins.is_valu = op.startswith("v_")
+    ins.is_trans = bool(TRANS.match(op))
+    defs, uses = set(), set()
+    if op == "s_waitcnt" or op == "s_nop":
+        ins.defs, ins.uses = set(), set()
+        return ins
+    if op.startswith("ds_read"):
+        # ds_read_b128 vdst, vaddr [offset:…]; ds_read2… vdst, vaddr offset0:… offset1:…
+        toks = split_operands(rest)
+        defs |= regs_of(toks[0])
+        addr = toks[1].split()[0]
+        uses |= regs_of(addr)
+        uses |= {"exec_lo", "exec_hi"}
+        ins.defs, ins.uses = defs, uses
+        return ins
+    if not ops:
+        return None
+    if op.startswith("s_"):
+        if op.startswith("s_cmp") or op.startswith("s_bitcmp"):
+            defs.add("scc")
+            for o in ops:
+                uses |= regs_of(o)
+        else:
+            defs |= regs_of(ops[0])
+            for o in ops[1:]:
+                uses |= regs_of(o)
+            if re.match(r"s_(and|or|xor|andn2|orn2|nand|nor|xnor|add|sub|addc|subb|lshl|lshr|ashr|min|max|mul|bfe|not|abs|bcnt|ff|flbit|absdiff|lshl\d_add)_", op) or "saveexec" in op:
+                defs.add("scc")
+            if op.startswith(("s_addc", "s_subb", "s_cselect", "s_cmov")):
+                uses.add("scc")
+            if "saveexec" in op:
+                defs |= {"exec_lo", "exec_hi"}
+                uses |= {"exec_lo", "exec_hi"}
+        ins.defs, ins.uses = defs, uses
+        return ins
+    if not op.startswith("v_"):
+        return None
+    # VALU
+    uses |= {"exec_lo", "exec_hi"}
+    if op.startswith("v_cmpx"):
+        return None
+    if op.startswith("v_cmp"):
+        defs |= regs_of(ops[0])          # vcc or an SGPR pair, spelled out in both encodings
+        for o in ops[1:]:
+            uses |= regs_of(o)
+    elif op.startswith("v_readlane"):
+        defs |= regs_of(ops[0])
+        for o in ops[1:]:
+            uses |= regs_of(o)
+    else:
+        defs |= regs_of(ops[0])
+        for o in ops[1:]:
+            uses |= regs_of(o)
+        if FMAC.match(op):
+            uses |= regs_of(ops[0])
+        if op.startswith("v_cndmask_b32") and op.endswith(("_e32", "_dpp", "_sdwa")) and len(ops) == 4:
+            pass  # the mask (vcc) is spelled as the fourth operand: already in uses
+        if op.startswith(("v_addc", "v_subb", "v_subbrev", "v_add_co", "v_sub_co", "v_subrev_co", "v_mad_u64", "v_mad_i64")):
+            return None  # carries: not modelled
+    ins.defs, ins.uses = defs, uses
+    return ins
+
+
+# ---------------------------------------------------------------------------------------------
+# blocks, dependence graph
+# ---------------------------------------------------------------------------------------------
+LABEL = re.compile(r"^[.\w$]+:")
+
+
+def find_function(lines, sub):
+    start = end = None
+    for i, l in enumerate(lines):
+        if start is None and re.match(r"^_Z\w+:", l) and sub in l:
+            start = i
+        elif start is not None and l.startswith(".Lfunc_end"):
+            end = i
+            break
+    if start is None or end is None:
+        raise SystemExit(f"function containing {sub!r} not found")
+    return start, end
+
+
+def straight_pieces(lines, lo, hi):
+    """maximal runs of lines [a, b) inside [lo, hi) without labels, branches or anything parse_inst refuses"""
+    pieces, cur = [], []
+    a = None
+    for i in range(lo, hi):
+        l = lines[i]
+        s = l.strip()
+        is_break = False
+        ins = None
+        if LABEL.match(l) or s.startswith(".") or s.startswith(";;#ASM"):
+            is_break = True
+        else:
+            ins = parse_inst(l)
+            if ins is None:
+                is_break = True
+            elif not ins.comment_only and ({"exec_lo", "exec_hi"} & ins.defs):
+                is_break = True
+        if is_break:
+            if cur:
+                pieces.append((a, i, cur))
+            cur, a = [], None
+        else:
+            if a is None:
+                a = i
+            cur.append(ins)
+    if cur:
+        pieces.append((a, hi, cur))
+    return pieces
+
+
+def build_dag(insts):
+    """edges (pred → succ, kind) for RAW / WAR / WAW over registers; LDS reads keep no mutual order (no LDS write in a piece)"""
+    n = len(insts)
+    preds = [dict() for _ in range(n)]   # pred index → 'raw' | 'war' | 'waw'
+    last_def = {}
+    last_uses = defaultdict(list)
+    for i, ins in enumerate(insts):
+        for r in ins.uses:
+            if r in last_def:
+                preds[i][last_def[r]] = "raw"
+        for r in ins.defs:
+            if r in last_def and preds[i].get(last_def[r]) != "raw":
+                preds[i].setdefault(last_def[r], "waw")
+            for u in last_uses[r]:
+                if u != i and preds[i].get(u) is None:
+                    preds[i][u] = "war"
+        for r in ins.defs:
+            last_def[r] = i
+            last_uses[r] = []
+        for r in ins.uses:
+            last_uses[r].append(i)
+    return preds
+
+
+# ---------------------------------------------------------------------------------------------
+# in-order issue simulation of one wave (no other wave on the SIMD)
+# ---------------------------------------------------------------------------------------------
+def hazard_gap(prod, cons):
+    """wait states the gfx940 family needs between producer and consumer (0 = none): GCNHazardRecognizer's rules that can
+    occur in the pieces this tool touches"""
+    need = 0
+    if prod.is_valu:
+        sg = {r for r in prod.defs if r[0] == "s" or r.startswith("vcc")}
+        if sg and cons.is_valu and (sg & cons.uses):
+            need = max(need, 2)          # VALU writes SGPR / VCC → VALU reads it (mask or constant)
+        if sg and cons.op.startswith("v_readlane") and (sg & cons.uses):
+            need = max(need, 4)
+        if prod.is_trans and cons.is_valu and not cons.is_trans and (prod.defs & cons.uses):
+            need = max(need, 1)          # trans result forwarded to a non-trans VALU
+        if cons.op.startswith("v_readlane") and ({r for r in prod.defs if r[0] == "v"} & cons.uses):
+            need = max(need, 1)
+    if prod.op.startswith("s_") and ("m0" in prod.defs) and ("m0" in cons.uses):
+        need = max(need, 1)
+    return need
+
+
+def simulate(order, insts, preds, lds_latency=None):
+    """cycles until the last result of the piece is available, issuing `order` in order on an otherwise idle SIMD"""
+    ready = {}
+    t = 0
+    finish = 0
+    lat_lds = lds_latency or MODEL["lds"][1]
+    for pos, i in enumerate(order):
+        ins = insts[i]
+        if ins.comment_only or ins.op == "s_waitcnt":
+            continue
+        if ins.op == "s_nop":
+            continue
+        issue, lat = MODEL[ins.kind]
+        if ins.is_lds:
+            lat = lat_lds
+        start = t
+        for p, kind in preds[i].items():
+            if kind == "raw":
+                start = max(start, ready.get(p, 0))
+        ready[i] = start + lat
+        t = start + issue
+        finish = max(finish, ready[i])
+    return finish
+
+
+def list_schedule(insts, preds):
+    """critical-path list scheduling with the measured latencies, in-order issue: at every step take, among the
+    instructions whose predecessors have been scheduled, the one that can start earliest; ties by longest path to the end"""
+    n = len(insts)
+    succs = [[] for _ in range(n)]
+    for i in range(n):
+        for p, k in preds[i].items():
+            succs[p].append((i, k))
+    # priority: longest latency-weighted path to the end of the piece
+    height = [0] * n
+    for i in range(n - 1, -1, -1):
+        ins = insts[i]
+        issue, lat = MODEL[ins.kind] if not (ins.comment_only or ins.op in ("s_waitcnt", "s_nop")) else (0, 0)
+        h = lat
+        for s, k in succs[i]:
+            h = max(h, (lat if k == "raw" else issue) + height[s])
+        height[i] = h
+    indeg = [len(preds[i]) for i in range(n)]
+    avail = [i for i in range(n) if indeg[i] == 0]
+    ready = {}
+    t = 0
+    order = []
+    while avail:
+        best, best_key = None, None
+        for i in avail:
+            ins = insts[i]
+            st = t
+            for p, kind in preds[i].items():
+                if kind == "raw":
+                    st = max(st, ready.get(p, 0))
+            key = (max(st, t), -height[i], i)
+            if best_key is None or key < best_key:
+                best, best_key = i, key
+        i = best
+        avail.remove(i)
+        ins = insts[i]
+        if ins.comment_only or ins.op in ("s_waitcnt", "s_nop"):
+            issue, lat = 0, 0
+        else:
+            issue, lat = MODEL[ins.kind]
+        st = best_key[0]
+        ready[i] = st + lat
+        t = st + issue
+        order.append(i)
+        for s, k in succs[i]:
+            indeg[s] -= 1
+            if indeg[s] == 0:
+                avail.append(s)
+    return order
+
+
+# ---------------------------------------------------------------------------------------------
+# emission: waitcnts for the LDS reads in their new order, hazard no-ops
+# ---------------------------------------------------------------------------------------------
+def emit(order, insts, preds, entry_waitcnt):
+    """`entry_waitcnt`: lgkmcnt(0) is emitted ahead of the piece's first LDS-dependent use only as the reads require;
+    reads issued BEFORE the piece are not known here, so a piece that had a waitcnt at its head keeps it (entry_waitcnt)."""
+    out = []
+    lds_issued = []       # instruction indices of the LDS reads issued so far in the piece, in order
+    waited_upto = 0       # reads [0, waited_upto) are known to have landed
+    emitted = []          # Inst objects in emission order (for hazard distances)
+    if entry_waitcnt:
+        out.append(entry_waitcnt)
+    for i in order:
+        ins = insts[i]
+        if ins.comment_only:
+            out.append(ins.text)
+            continue
+        if ins.op in ("s_waitcnt", "s_nop"):
+            continue      # recomputed
+        # LDS results this instruction needs (RAW) — or overwrites / re-reads as WAR/WAW on an in-flight destination
+        need = -1
+        for p, kind in preds[i].items():
+            if insts[p].is_lds and p in lds_issued:
+                need = max(need, lds_issued.index(p))
+        if need >= waited_upto:
+            outstanding_allowed = len(lds_issued) - 1 - need
+            out.append(f"\ts_waitcnt lgkmcnt({outstanding_allowed})")
+            emitted.append(None)
+            waited_upto = need + 1
+        # hazards against the previous few emitted instructions
+        gap_needed = 0
+        dist = 0
+        for prev in reversed(emitted[-6:]):
+            if prev is None:      # a waitcnt counts as a wait state
+                dist += 1
+                continue
+            g = hazard_gap(prev, ins)
+            if g > dist:
+                gap_needed = max(gap_needed, g - dist)
+            dist += 1
+        if gap_needed > 0:
+            out.append(f"\ts_nop {gap_needed - 1}")
+            for _ in range(gap_needed):
+                emitted.append(None)
+        out.append(ins.text)
+        emitted.append(ins)
+        if ins.is_lds:
+            lds_issued.append(i)
+    # everything this piece started must be assumed pending by whoever follows: the following code's own waitcnts were
+    # computed by the compiler for ITS order of reads — a piece that ends with reads in flight ends with a full wait
+    if waited_upto < len(lds_issued):
+        out.append("\ts_waitcnt lgkmcnt(0)")
+    return out
+
+
+def process(lines, fn_sub, must_contain, report, min_len=12):
+    lo, hi = find_function(lines, fn_sub)
+    pieces = straight_pieces(lines, lo, hi)
+    new_lines = list(lines)
+    edits = []
+    for a, b, insts in pieces:
+        real = [x for x in insts if not x.comment_only and x.op not in ("s_waitcnt", "s_nop")]
+        if len(real) < min_len:
+            continue
+        if must_contain and not any(must_contain in x.op for x in real):
+            continue
+        # a waitcnt that is not lgkmcnt-only (vmcnt / expcnt) pins the piece: leave it alone
+        if any(x.op == "s_waitcnt" and not re.fullmatch(r"\s*s_waitcnt lgkmcnt\(\d+\)\s*", x.text.split(";")[0]) for x in insts):
+            continue
+        # reads in flight at the head of the piece: the compiler's first waitcnt tells; keep a full wait at the head if the
+        # original piece waited before its first own read was issued
+        first_lds = next((k for k, x in enumerate(insts) if x.is_lds), len(insts))
+        head_wait = next((x for x in insts[:first_lds] if x.op == "s_waitcnt"), None)
+        # (conservative: any waitcnt anywhere in a piece that also USES registers loaded before the piece → wait at the head)
+        any_wait = any(x.op == "s_waitcnt" for x in insts)
+        entry = "\ts_waitcnt lgkmcnt(0)" if (head_wait is not None or (any_wait and first_lds > 0)) else None
+        preds = build_dag(insts)
+        base_order = list(range(len(insts)))
+        before = simulate(base_order, insts, preds)
+        order = list_schedule(insts, preds)
+        after = simulate(order, insts, preds)
+        if after >= before:
+            continue
+        text = emit(order, insts, preds, entry)
+        edits.append((a, b, text, before, after, len(real)))
+    for a, b, text, before, after, nreal in sorted(edits, reverse=True):
+        new_lines[a:b] = text
+        if report:
+            print(f"  lines {a}-{b}: {nreal} instructions, modelled lone-wave cycles {before} -> {after}", file=sys.stderr)
+    return new_lines, edits
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("dst")
+    ap.add_argument("--function", action="append", required=True)
+    ap.add_argument("--blocks-with", default="")
+    ap.add_argument("--report", action="store_true")
+    a = ap.parse_args()
+    lines = open(a.src).read().split("\n")
+    for fn in a.function:
+        if a.report:
+            print(fn, file=sys.stderr)
+        lines, _ = process(lines, fn, a.blocks_with, a.report)
+    open(a.dst, "w").write("\n".join(lines))
