@@ -443,7 +443,7 @@ def main():
             return base
         traffic, traffic_source, sq, sq_source = {}, None, {}, None
         canonical = (nx, ny, a.flux_configuration, world, a.config) == (1440, 560, "default", 1, "ocean")
-        for tag in ("r03", "r02", "r01"):
+        for tag in ("r04", "r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
                 if canonical:
@@ -453,13 +453,15 @@ def main():
                 break
             except Exception:
                 continue
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq.json")))
-            if canonical:
-                sq = {variant_key(k): v for k, v in pmc["kernels"].items()}
-                sq_source = f"committed: profiles/r03_pmc_sq.json (rocprofv3 --pmc SQ_INSTS_VALU …, tree {pmc.get('commit')})"
-        except Exception:
-            pass
+        for tag in ("r04", "r03"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json")))
+                if canonical:
+                    sq = {variant_key(k): v for k, v in pmc["kernels"].items()}
+                    sq_source = f"committed: profiles/{tag}_pmc_sq.json (rocprofv3 --pmc SQ_INSTS_VALU …, tree {pmc.get('commit')})"
+                break
+            except Exception:
+                continue
         ao_kernel = "ao_lean_kernel" if lean else "ao_flux_fast_kernel"
         ao_key = (ao_kernel + (":fused" if fused else ":plain")) if lean else ao_kernel
         ao_what = "compute_atmosphere_ocean_fluxes!" + (" + the cell-local part of compute_net_ocean_fluxes! in its epilogue" if fused else "")

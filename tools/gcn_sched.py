@@ -23,9 +23,12 @@ from collections import defaultdict
 # machine model (cycles; scratch/ubench_lat.hip, scratch/ubench_valu.hip on MI355X)
 # ---------------------------------------------------------------------------------------------
 # issue: cycles the wave's issue port is busy; latency: issue → a dependent instruction may issue
+# One wave alone on its SIMD (scratch/ubench_lat.hip, in s_memtime ticks): it issues at most one instruction per ≈ 4
+# ticks whatever the type; a dependent VALU instruction of ANY type follows its producer after ≈ 9; v_rcp/v_rsq_f64 ≈ 20.5;
+# f32 transcendentals ≈ 13 (+ the mandatory wait state); an LDS read's data ≈ 64 after its issue.
 MODEL = dict(
-    f64=(4, 8), f64_trans=(16, 24), f32=(2, 5), f32_trans=(8, 12), int32=(2, 5), int_vop3=(4, 8), cvt=(4, 8),
-    mov64=(4, 8), cmp64=(4, 8), cmp32=(2, 5), salu=(1, 2), lds=(2, 110), nop=(1, 1), other=(4, 8))
+    f64=(4, 9), f64_trans=(16, 21), f32=(4, 9), f32_trans=(8, 13), int32=(4, 9), int_vop3=(4, 9), cvt=(4, 9),
+    mov64=(4, 9), cmp64=(4, 9), cmp32=(4, 9), salu=(4, 6), lds=(4, 64), nop=(4, 4), other=(4, 9))
 
 
 class Inst:
@@ -223,7 +226,16 @@ def straight_pieces(lines, lo, hi):
         s = l.strip()
         is_break = False
         ins = None
-        if LABEL.match(l) or s.startswith(".") or s.startswith(";;#ASM"):
+        if s.startswith(";;#ASM"):
+            # inline-asm markers: either an empty fence the sources use against the COMPILER's scheduler, or a wrapper
+            # around one ordinary instruction (v_max_f64 / v_min_f64 with an SGPR operand): no machine effect — dropped
+            if a is None:
+                a = i
+            ins = parse_inst("")
+            ins.text = None
+            cur.append(ins)
+            continue
+        if LABEL.match(l) or s.startswith("."):
             is_break = True
         else:
             ins = parse_inst(l)
@@ -381,7 +393,8 @@ def emit(order, insts, preds, entry_waitcnt):
     for i in order:
         ins = insts[i]
         if ins.comment_only:
-            out.append(ins.text)
+            if ins.text is not None:
+                out.append(ins.text)
             continue
         if ins.op in ("s_waitcnt", "s_nop"):
             continue      # recomputed
