@@ -132,6 +132,8 @@ def parse_inst(line):
     ins.op = op
     if UNSAFE.match(op) and not op.startswith("ds_read"):
         return None
+    if "_dpp" in op or "_sdwa" in op or re.search(r"\b(row_|quad_perm|wave_|bank_mask|dst_sel|src0_sel)", rest):
+        return None   # DPP / SDWA carry their own hazards (VALU → DPP read: 2 wait states): such pieces are left alone
     ops = split_operands(rest)
     ins.kind = classify(op)
     ins.is_lds = ins.kind == "lds"
@@ -450,11 +452,11 @@ def process(lines, fn_sub, must_contain, report, min_len=12):
             continue
         # reads in flight at the head of the piece: the compiler's first waitcnt tells; keep a full wait at the head if the
         # original piece waited before its first own read was issued
-        first_lds = next((k for k, x in enumerate(insts) if x.is_lds), len(insts))
-        head_wait = next((x for x in insts[:first_lds] if x.op == "s_waitcnt"), None)
-        # (conservative: any waitcnt anywhere in a piece that also USES registers loaded before the piece → wait at the head)
-        any_wait = any(x.op == "s_waitcnt" for x in insts)
-        entry = "\ts_waitcnt lgkmcnt(0)" if (head_wait is not None or (any_wait and first_lds > 0)) else None
+        # Loads issued BEFORE the piece (LDS reads, scalar loads — both count in lgkmcnt, scalar ones return out of order) that
+        # the piece consumes are covered by waitcnts somewhere inside the original piece; the recomputed waitcnts only know the
+        # piece's own LDS reads.  So: a piece that waited at all starts with a full wait.  (A piece that never waited consumes
+        # nothing that was still in flight at its head.)
+        entry = "\ts_waitcnt lgkmcnt(0)" if any(x.op == "s_waitcnt" for x in insts) else None
         preds = build_dag(insts)
         base_order = list(range(len(insts)))
         before = simulate(base_order, insts, preds)
