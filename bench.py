@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--trip-hints", type=int, choices=(0, 1, 2, 3), default=2,
                     help="CF_OPT_TRIP_HINTS for the timed region: 2 = the library's default (index-ordered batches in the round-3 ocean "
                          "kernel), 1 = batches sorted by last call's trip counts over the whole chunk, 3 = within quarter-chunk windows")
+    ap.add_argument("--fused-interp", type=int, choices=(0, 1), default=None,
+                    help="CF_OPT_FUSED_INTERP: interpolate_atmosphere_state! inside the solver's prologue (two launches per step); "
+                         "default: the library's choice")
     ap.add_argument("--no-sorted-pass", action="store_true",
                     help="skip the informational pass with CF_OPT_TRIP_HINTS = 1 (profiling runs: only the default configuration's launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample: passes that fit this wall time")
@@ -240,6 +243,8 @@ def main():
     ctx = FluxContext(nx, ny, h, h, params, ring=1, device=local_rank)
     if a.trip_hints != 2:
         ctx.set_option(abi.OPT_TRIP_HINTS, a.trip_hints)
+    if a.fused_interp is not None:
+        ctx.set_option(abi.OPT_FUSED_INTERP, a.fused_interp)
     ring_rows = ctx.grid.ring + 1
     states = [{k: ctx.to_device(o[k]) for k in ("T", "S", "u", "v", "mask")} for o in ocean_np]
     states[1]["mask"] = states[0]["mask"]   # one static wet mask (the solver's chunk table is keyed on it)
@@ -528,13 +533,15 @@ def main():
                 bound="fp64_valu_issue", kernel=ao_kernel, achieved=rate / 1e9, peak=FP64_ISSUE_PEAK / 1e9, unit="G wave-instr/s",
                 frac=rate / FP64_ISSUE_PEAK, valu_instructions_per_launch=insts, instructions_source=sq_source,
                 valu_busy_of_wave_lifetime=k_sq.get("valu_busy"),
-                note=("peak = 1024 SIMDs x 2.4 GHz / 4 cycles per FP64 wave-instruction; under this load the device clocks at "
-                      "about 1.9-2.0 GHz (scratch/ubench_valu.hip: 480 G wave-instr/s of v_fma_f64 sustained), so frac <= 0.80 is the "
-                      "practical ceiling; every VALU instruction is counted at the FP64 rate"))
+                note=("peak = 1024 SIMDs x 2.4 GHz / 4 cycles per FP64 wave-instruction; during this loop rocm-smi reads sclk "
+                      "2.36 GHz at 1160 of 1400 W (profiles/r04_clock_watch.log) — a pure v_fma_f64 stream on every SIMD is "
+                      "power-limited to about 1.9 GHz = 480 G wave-instr/s (scratch/ubench_valu.hip), the solver is not; every "
+                      "VALU instruction is counted at the FP64 rate (the SQ counters book an integer VALU instruction at one "
+                      "quad cycle as well: 28.5 M active quads for 27.0 M instructions)"))
         # strong-scaling projection from single-GPU measurements of one rank's slab (scratch/slab_curve.py): a PROJECTION,
         # labelled as such — the driver computes the real curve from its own N-GPU runs
         try:
-            sc = json.load(open(os.path.join(ROOT, "profiles", "r03_slab_curve.json")))
+            sc = json.load(open(os.path.join(ROOT, "profiles", "r04a_slab_curve.json")))
             if canonical and world == 1:
                 out["projected_scaling"] = dict(
                     kind="projection from one GPU, not a multi-GPU measurement",
