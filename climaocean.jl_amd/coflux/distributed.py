@@ -102,10 +102,20 @@ class SlabHaloExchanger:
                 ctx.peer_halo_connect(handles[self.rank - 1] if self.rank > 0 else None,
                                       handles[self.rank + 1] if self.rank < self.world - 1 else None, self.rank, self.world)
         if self.backend == "rccl":
-            from .runtime import comm_unique_id
-            ident = [comm_unique_id() if self.rank == 0 else None]
+            from . import runtime
+            # rank 0 always reaches the broadcast — with the id or with the reason it has none — so that no rank is left
+            # waiting in it; every rank then raises the same error
+            ident = [None]
+            if self.rank == 0:
+                try:
+                    ident = [(runtime.comm_unique_id(), None)]
+                except Exception as exc:  # noqa: BLE001
+                    ident = [(None, f"rank 0: {exc}")]
             dist.broadcast_object_list(ident, src=0)
-            ctx.comm_init(ident[0], self.rank, self.world)
+            uid, failure = ident[0]
+            if failure is not None:
+                raise RuntimeError(f"no RCCL unique id ({failure})")
+            ctx.comm_init(uid, self.rank, self.world)
 
     def __call__(self, tensors):
         if self.backend == "rccl":
