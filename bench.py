@@ -54,12 +54,13 @@ def parse():
     ap.add_argument("--flux-configuration", choices=("default", "corrected", "ncar"), default="default")
     ap.add_argument("--config", choices=("ocean", "sea_ice"), default="ocean",
                     help="ocean: BASELINE configs[1]; sea_ice: configs[2] (atmosphere–sea-ice interface + partition)")
-    ap.add_argument("--pipeline", choices=("auto", "on", "off"), default="auto",
+    ap.add_argument("--pipeline", choices=("auto", "on", "off", "merged"), default="auto",
                     help="interpolate the next step's atmosphere on the auxiliary stream during the solver; auto = off: "
                          "measured slower at every slab size since the tiled kernel picks its rows per tile by size "
                          "(1440x70: 0.0453 vs 0.0396 ms/step; 1440x560: 0.151 vs 0.121), and so is the same kernel gated "
                          "behind the solver to run beside the net fluxes (0.133 / 0.060): a cross-stream dependency costs "
-                         "more than either kernel hides")
+                         "more than either kernel hides; merged = CF_OPT_MERGED_PREFETCH: the next step's interpolation inside this "
+                         "step's face-stress launch (two launches per step)")
     ap.add_argument("--net-diagnostics", action="store_true",
                     help="also write the three optional radiation diagnostics of cf_net_ocean_fluxes (24 B/cell beyond "
                          "the 88 + 40 B/cell contract of compute_net_ocean_fluxes!, SURVEY.md §8d)")
@@ -250,7 +251,9 @@ def main():
     states[1]["mask"] = states[0]["mask"]   # one static wet mask (the solver's chunk table is keyed on it)
     src = {k: ctx.to_device(v) for k, v in src_np.items()}
     w = {k: (ctx.to_device(v) if isinstance(v, np.ndarray) else v) for k, v in w_np.items()}
-    pipeline = a.pipeline == "on"
+    pipeline = a.pipeline in ("on", "merged")
+    if a.pipeline == "merged":
+        ctx.set_option(abi.OPT_MERGED_PREFETCH, 1)
     atmos_sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2 if pipeline else 1)]
     fl = ctx.field_set(FLUX_NAMES)
     # compute_net_ocean_fluxes! writes five fields (τx, τy, Jᵀ, Jˢ, penetrating shortwave: the 40 B/cell of the contract);

@@ -25,7 +25,7 @@ VELOCITY_RELATIVE, VELOCITY_WIND = 0, 1
 MASK_NONE, MASK_U8, MASK_BOTTOM_HEIGHT = 0, 1, 2
 ALBEDO_CONSTANT, ALBEDO_LATITUDE_DEPENDENT = 0, 1
 OPT_SOLVER, OPT_INTERP_TILE_CAP, OPT_MAX_BLOCKS, OPT_TRIP_HINTS, OPT_AO_CHUNK, OPT_PROFILE_STRIDE, OPT_FUSED_NET = 0, 1, 2, 3, 4, 5, 6
-OPT_ICE_ORBIT_SHORTCUT, OPT_FUSED_INTERP = 7, 8
+OPT_ICE_ORBIT_SHORTCUT, OPT_FUSED_INTERP, OPT_MERGED_PREFETCH = 7, 8, 9
 SOLVER_TABLES, SOLVER_LIBM, SOLVER_TABLES_R2, SOLVER_TABLES_R2_OUTER = 0, 1, 2, 3   # 2, 3: A/B diagnostics (include/coflux.h)
 STAGE_INTERPOLATE, STAGE_AO_FLUXES, STAGE_NET_FLUXES, STAGE_UPDATE_STATE = 0, 1, 2, 3
 

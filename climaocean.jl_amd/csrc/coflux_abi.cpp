@@ -514,6 +514,10 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             if (value < 0 || value > 1) return fail(ctx, CF_ERR_INVALID, "fused interpolation %d: 0 (off), 1 (when possible)", value);
             ctx->fused_interp = value;
             return CF_OK;
+        case CF_OPT_MERGED_PREFETCH:
+            if (value < 0 || value > 1) return fail(ctx, CF_ERR_INVALID, "merged prefetch %d: 0 (auxiliary stream), 1 (in the face-stress launch)", value);
+            ctx->merged_prefetch = value;
+            return CF_OK;
         case CF_OPT_ICE_ORBIT_SHORTCUT:
             ctx->ice_orbit_shortcut = value != 0;
             ctx->ice_kernel.orbit_shortcut = value != 0 ? 1.0 : 0.0;
@@ -739,7 +743,7 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     if (ctx->deferred.valid && ctx->deferred.out.u == atmos->u) CHECK(cf_flush_deferred_prefetch(ctx));  // asked for THIS step
     for (auto& p : ctx->prefetch) {
         if (!p.valid || p.key != atmos->u) continue;
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p.done, 0));  // also orders a mismatched prefetch before our writes
+        if (!p.on_main) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p.done, 0));  // also orders a mismatched prefetch before our writes
         prefetched = p.level1 == src->level1 && p.level2 == src->level2 && p.tf == src->time_fraction;
         p.valid = false;
     }
@@ -757,11 +761,32 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes,
                                   fuse ? ice : nullptr, fuse ? net : nullptr, ctx->d_land_freshwater,
                                   fuse_interp ? src : nullptr, fuse_interp ? w : nullptr));
-    // the next step's interpolation goes out behind the solver: its workgroups are dispatched first, the gather kernel
-    // takes the registers and issue slots they leave free
-    CHECK(cf_flush_deferred_prefetch(ctx));
+    // A requested next-step interpolation (cf_prefetch_atmosphere_state).  CF_OPT_MERGED_PREFETCH: it rides in THIS step's
+    // face-stress launch on the main stream — two independent memory-bound kernels, one launch boundary fewer (on a
+    // latitude slab a boundary is a tenth of the step).  Otherwise it goes out on the auxiliary stream right behind the
+    // solver: the solver's workgroups are dispatched first, the gather kernel takes what they leave free.
+    const bool merge = fuse && ctx->merged_prefetch != 0 && ctx->deferred.valid && ctx->launch.interp_cap != 0 &&
+                       ctx->deferred.out.u != atmos->u;
+    if (!merge) CHECK(cf_flush_deferred_prefetch(ctx));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
-    if (fuse)
+    if (merge) {
+        cf_ctx::Prefetch* slot = nullptr;
+        for (auto& p : ctx->prefetch)
+            if (p.valid && p.key == ctx->deferred.out.u) slot = &p;
+        if (!slot)
+            for (auto& p : ctx->prefetch)
+                if (!p.valid) slot = &p;
+        if (!slot) return fail(ctx, CF_ERR_INVALID, "two prefetched atmosphere states are already pending");
+        HIP_TRY(ctx, launch_interpolate_and_stress(ctx->stream, ctx->launch, ctx->dev, ctx->grid, &ctx->deferred.src, &ctx->deferred.w,
+                                                   &ctx->deferred.out, ocean, fluxes, ice, net));
+        slot->key = ctx->deferred.out.u;
+        slot->level1 = ctx->deferred.src.level1;
+        slot->level2 = ctx->deferred.src.level2;
+        slot->tf = ctx->deferred.src.time_fraction;
+        slot->valid = true;
+        slot->on_main = true;
+        ctx->deferred.valid = false;
+    } else if (fuse)
         HIP_TRY(ctx, launch_net_stress(ctx->stream, ctx->dev, ctx->grid, ocean, fluxes, ice, net));
     else
         HIP_TRY(ctx, launch_net_fluxes(ctx->stream, ctx->dev, ctx->grid, ocean, atmos, fluxes, ice, w, net, ctx->d_land_freshwater));

@@ -53,6 +53,7 @@ struct cf_ctx {
     int* d_lean_info = nullptr;         // per chunk: listed wet cells + fingerprint (4 ints)
     bool trip_hints = true;
     bool lean_hints = false;         // the lean ocean kernel sorts its lists by trip count only when CF_OPT_TRIP_HINTS = 1
+    int merged_prefetch = 0;         // CF_OPT_MERGED_PREFETCH: a requested next-step interpolation rides in the face-stress launch
     int fused_interp = 0;            // cf_update_state: the interpolation in the lean ocean kernel's prologue (0 off: measured slower; 1 when possible)
     int fused_net = 2;               // cf_update_state: net fluxes in the solver's epilogue + a stress kernel: 0 never, 1 when possible, 2 with the lean ocean kernel
     // cost-balanced chunk table of the solver, rebuilt when the wet mask (pointer / kind / surface z) changes
@@ -100,6 +101,7 @@ struct cf_ctx {
         double tf = 0.0;
         hipEvent_t done = nullptr;
         bool valid = false;
+        bool on_main = false;         // launched on the main stream (merged with the face stresses): stream order, no event
     } prefetch[2];
     // a prefetch that has been requested but not launched yet: it goes out right AFTER the next solver launch, so
     // that the solver's workgroups are dispatched first and the interpolation only fills what they leave free

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "coflux_interp_cell.hpp"
+#include "coflux_kernel_types.hpp"
 #include "coflux_kernels.h"
 
 namespace coflux {
@@ -46,9 +47,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// the tiles of workgroup `block` of `nblocks` (the kernel below; the merged stress + interpolation launch)
 template <int ROWS>
-__global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S, WeightDesc Wt, GridDesc G,
-                                                                     Exchange E, int cap) {
+__device__ __forceinline__ void interpolate_tiles(const SourceDesc& S, const WeightDesc& Wt, const GridDesc& G, const Exchange& E, int cap,
+                                                  int block, int nblocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* tile = reinterpret_cast<double*>(smem) + (size_t)wave * CF_JRA55_NVARS * cap;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S
     const int half = S.ns_x / 2;
     const bool rotate = Wt.cos_rot != nullptr && Wt.sin_rot != nullptr;
 
-    for (int t = (int)blockIdx.x * IT_WAVES + wave; t < ntiles; t += (int)gridDim.x * IT_WAVES) {
+    for (int t = block * IT_WAVES + wave; t < ntiles; t += nblocks * IT_WAVES) {
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
         const int i = tx * 64 + lane - G.ring;
         const int ic = min(i, G.nx + G.ring - 1);  // out-of-window lanes shadow the last column
@@ -163,6 +165,50 @@ __global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S
         }
         wave_lds_sync();  // the tile is rewritten by this wave's next iteration
     }
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(64 * IT_WAVES) void interpolate_kernel(SourceDesc S, WeightDesc Wt, GridDesc G,
+                                                                     Exchange E, int cap) {
+    interpolate_tiles<ROWS>(S, Wt, G, E, cap, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two independent memory-bound pieces of consecutive steps in ONE launch (cf_time_steps with pipelining on a surface
+// that does not fill the device): the face stresses of step n (they need every cell's ρτ of step n: a launch of their own
+// behind the solver) and the interpolation of step n + 1's atmosphere state into the OTHER set of exchange fields
+// (nothing of step n reads it).  On a latitude slab every launch boundary is ≈ 3 µs of a ≈ 30 µs step; the two kernels'
+// workgroups are all resident at once either way.  Workgroups [0, n_interp) interpolate, the rest take 256 stress
+// cells each; the arithmetic is the two kernels' own (interpolate_tiles, net_face_stress): same bits.
+// ---------------------------------------------------------------------------------------------
+struct StressArgs {
+    const void* mask;
+    const double* rtx;
+    const double* rty;
+    IceIn I;
+    double* tau_x;
+    double* tau_y;
+};
+
+template <int ROWS>
+__global__ __launch_bounds__(64 * IT_WAVES) void interpolate_and_stress_kernel(SourceDesc S, WeightDesc Wt, GridDesc G, Exchange E, int cap,
+                                                                                int n_interp, DevParams P, StressArgs A) {
+    static_assert(64 * IT_WAVES == 256, "a stress workgroup takes 256 cells");
+    if ((int)blockIdx.x < n_interp) {
+        interpolate_tiles<ROWS>(S, Wt, G, E, cap, (int)blockIdx.x, n_interp);
+        return;
+    }
+    const int idx = ((int)blockIdx.x - n_interp) * 256 + (int)threadIdx.x;
+    if (idx >= G.nx * G.ny) return;
+    const int j = idx / G.nx;
+    const size_t k = cell_index(G, idx - j * G.nx, j);
+    const size_t kw = k - 1, ks = k - (size_t)G.sj;
+    const bool wet = cell_is_wet(P, A.mask, k);
+    const double aice = A.I.conc ? A.I.conc[k] : 0.0;
+    const double tx = net_face_stress(P, A.rtx[kw], A.rtx[k], A.I.conc ? A.I.conc[kw] : 0.0, aice, A.I.txio ? A.I.txio[k] : 0.0);
+    const double ty = net_face_stress(P, A.rty[ks], A.rty[k], A.I.conc ? A.I.conc[ks] : 0.0, aice, A.I.tyio ? A.I.tyio[k] : 0.0);
+    A.tau_x[k] = wet ? tx : 0.0;
+    A.tau_y[k] = wet ? ty : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -274,9 +320,8 @@ hipError_t launch_interpolate_background(hipStream_t st, const GridDesc& G, cons
     return hipGetLastError();
 }
 
-hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
-                              const cf_interp_weights* w, const cf_exchange_fields* e) {
-    if (L.interp_cap == 0) return launch_interpolate_background(st, G, s, w, e);  // CF_OPT_INTERP_TILE_CAP = 0
+// rows per tile and workgroups of the tiled interpolation on this surface
+static void interpolate_grid(const LaunchCfg& L, const GridDesc& G, int* rows_out, int* blocks_out) {
     // Rows of 64 cells per wave tile.  A tile is one dependent chain (indices → footprint → LDS → 8 stores per row),
     // and on a surface that does not fill the device's wave slots the kernel's time IS that chain: fewer rows per
     // tile then mean more waves and a shorter chain (1440×70: 7.8 → 5.4 µs with one row), while on the full surface
@@ -298,6 +343,15 @@ hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc
         return cap ? std::max(1, std::atoi(cap)) : 0;
     }();
     if (blocks_cap > 0) blocks = std::min(blocks, blocks_cap);
+    *rows_out = rows;
+    *blocks_out = blocks;
+}
+
+hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
+                              const cf_interp_weights* w, const cf_exchange_fields* e) {
+    if (L.interp_cap == 0) return launch_interpolate_background(st, G, s, w, e);  // CF_OPT_INTERP_TILE_CAP = 0
+    int rows = 4, blocks = 1;
+    interpolate_grid(L, G, &rows, &blocks);
     const size_t lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double);
 #define CF_LAUNCH_INTERP(ROWS_)                                                                                        \
     hipLaunchKernelGGL(interpolate_kernel<ROWS_>, dim3(blocks), dim3(64 * IT_WAVES), lds, st, make_source(s),          \
@@ -306,6 +360,33 @@ hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc
     else if (rows == 2) CF_LAUNCH_INTERP(2);
     else CF_LAUNCH_INTERP(1);
 #undef CF_LAUNCH_INTERP
+    return hipGetLastError();
+}
+
+// the face stresses of one step and the interpolation of the next step's atmosphere state in one launch (see the kernel)
+hipError_t launch_interpolate_and_stress(hipStream_t st, const LaunchCfg& L, const DevParams& P, const GridDesc& G,
+                                         const cf_atmos_source* s, const cf_interp_weights* w, const cf_exchange_fields* e,
+                                         const cf_ocean_surface* o, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
+                                         const cf_net_ocean_fluxes* n) {
+    if (L.interp_cap == 0) return hipErrorInvalidValue;
+    int rows = 4, blocks = 1;
+    interpolate_grid(L, G, &rows, &blocks);
+    const size_t lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double);
+    StressArgs A{};
+    A.mask = o->mask;
+    A.rtx = f->x_momentum;
+    A.rty = f->y_momentum;
+    if (ice) A.I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress, nullptr};
+    A.tau_x = n->u;
+    A.tau_y = n->v;
+    const int stress_blocks = (G.nx * G.ny + 255) / 256;
+#define CF_LAUNCH_BOTH(ROWS_)                                                                                              \
+    hipLaunchKernelGGL(interpolate_and_stress_kernel<ROWS_>, dim3(blocks + stress_blocks), dim3(64 * IT_WAVES), lds, st, \
+                       make_source(s), make_weights(w), G, make_exchange(e), L.interp_cap, blocks, P, A)
+    if (rows == 4) CF_LAUNCH_BOTH(4);
+    else if (rows == 2) CF_LAUNCH_BOTH(2);
+    else CF_LAUNCH_BOTH(1);
+#undef CF_LAUNCH_BOTH
     return hipGetLastError();
 }
 

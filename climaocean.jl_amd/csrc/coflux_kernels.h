@@ -68,6 +68,10 @@ hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc&
 hipError_t launch_interpolate_land(hipStream_t st, const GridDesc& G, const cf_land_source* s, const cf_interp_weights* w, double* out);
 hipError_t launch_salinity_restoring(hipStream_t st, const DevParams& P, const GridDesc& G, const void* mask, double vp,
                                      const double* target, const double* S, double* out);
+hipError_t launch_interpolate_and_stress(hipStream_t st, const LaunchCfg& L, const DevParams& P, const GridDesc& G,
+                                         const cf_atmos_source* s, const cf_interp_weights* w, const cf_exchange_fields* e,
+                                         const cf_ocean_surface* o, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
+                                         const cf_net_ocean_fluxes* n);
 hipError_t launch_interpolate_background(hipStream_t st, const GridDesc& G, const cf_atmos_source* s,
                                          const cf_interp_weights* w, const cf_exchange_fields* e);
 hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const IceParams& I,

@@ -43,6 +43,7 @@ int cf_launch_prefetch(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_
     rec->level2 = src->level2;
     rec->tf = src->time_fraction;
     rec->valid = true;
+    rec->on_main = false;
     return CF_OK;
 }
 

@@ -351,6 +351,12 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * on MI355X, 0.1007 vs 0.0956 ms per step: the 72 corner gathers per cell cost the solver's
                                    * vector-memory address path more than the tiled kernel's 18 µs (which stages them in LDS the
                                    * solver has no room for) and push 19 registers to scratch.                                 */
+#define CF_OPT_MERGED_PREFETCH 9   /* 1: an interpolation requested ahead (cf_prefetch_atmosphere_state, cf_time_steps with pipelining) is
+                                   * launched TOGETHER with the current step's face stresses — one kernel on the context's stream whose
+                                   * workgroups do one or the other (same arithmetic, same bits) — instead of on the auxiliary stream: a
+                                   * step is then two launches (solver; stresses + next interpolation).  Pays where launch boundaries
+                                   * dominate (a latitude slab of a strongly scaled run); needs the fused net fluxes and the tiled
+                                   * interpolation.  0 (default): auxiliary stream.                                                  */
 #define CF_OPT_ICE_ORBIT_SHORTCUT 7 /* 1 (default): the atmosphere–sea-ice iteration stops as soon as its state repeats the state of two
                                      iterations ago bit for bit — an exact period-2 orbit, where the skin-temperature balance does not
                                      contract — and returns the iterate the remaining steps up to maxiter would end on (the same
