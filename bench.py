@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--flux-configuration", choices=("default", "corrected", "ncar"), default="default")
     ap.add_argument("--config", choices=("ocean", "sea_ice"), default="ocean",
                     help="ocean: BASELINE configs[1]; sea_ice: configs[2] (atmosphere–sea-ice interface + partition)")
-    ap.add_argument("--pipeline", choices=("auto", "on", "off", "merged"), default="auto",
+    ap.add_argument("--pipeline", choices=("auto", "on", "off", "merged", "tail"), default="auto",
                     help="interpolate the next step's atmosphere on the auxiliary stream during the solver; auto = off: "
                          "measured slower at every slab size since the tiled kernel picks its rows per tile by size "
                          "(1440x70: 0.0453 vs 0.0396 ms/step; 1440x560: 0.151 vs 0.121), and so is the same kernel gated "
@@ -251,9 +251,17 @@ def main():
     states[1]["mask"] = states[0]["mask"]   # one static wet mask (the solver's chunk table is keyed on it)
     src = {k: ctx.to_device(v) for k, v in src_np.items()}
     w = {k: (ctx.to_device(v) if isinstance(v, np.ndarray) else v) for k, v in w_np.items()}
-    pipeline = a.pipeline in ("on", "merged")
-    if a.pipeline == "merged":
-        ctx.set_option(abi.OPT_MERGED_PREFETCH, 1)
+    # --pipeline auto: the next step's interpolation as tail workgroups of the solver launch (CF_OPT_MERGED_PREFETCH = 2) wherever
+    # the round-3 ocean kernel runs with its fused epilogue — measured −3 % per step on the 1/4-degree surface, −9 … −16 % on
+    # slabs and on the 1/6-degree surface (profiles/r04_experiments.md §6); the other solver kernels keep the three launches
+    lean0, fused0 = ctx.solver_path()
+    mode = a.pipeline
+    if mode == "auto":
+        mode = "tail" if (a.config == "ocean" and lean0 and fused0 == 1) else "off"
+    pipeline = mode in ("on", "merged", "tail")
+    if mode in ("merged", "tail"):
+        ctx.set_option(abi.OPT_MERGED_PREFETCH, 1 if mode == "merged" else 2)
+    tail_mode = mode == "tail" and lean0 and fused0 == 1
     atmos_sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2 if pipeline else 1)]
     fl = ctx.field_set(FLUX_NAMES)
     # compute_net_ocean_fluxes! writes five fields (τx, τy, Jᵀ, Jˢ, penetrating shortwave: the 40 B/cell of the contract);
@@ -430,7 +438,7 @@ def main():
     if rank == 0:
         kw = dict(src=src, weights=w, ocean=states[0], atmos=atmos_sets[0], fluxes=fl, net=net, time_fraction=0.37)
         interp_ms = min(ctx.time_stage(abi.STAGE_INTERPOLATE, 50, **kw) for _ in range(3))
-        if pipeline:   # the kernel the pipelined step actually runs on the auxiliary stream
+        if mode == "on":   # the kernel the pipelined step actually runs on the auxiliary stream
             ctx.set_option(abi.OPT_INTERP_TILE_CAP, 0)
             interp_bg_ms = min(ctx.time_stage(abi.STAGE_INTERPOLATE, 50, **kw) for _ in range(3))
             ctx.set_option(abi.OPT_INTERP_TILE_CAP, 128)
@@ -480,9 +488,12 @@ def main():
             except Exception:
                 continue
         ao_kernel = "ao_lean_kernel" if lean else "ao_flux_fast_kernel"
-        ao_key = (ao_kernel + (":fused" if fused else ":plain")) if lean else ao_kernel
+        ao_key = (ao_kernel + (":fused" if fused else ":plain") + (":piped" if tail_mode else "")) if lean else ao_kernel
         ao_what = "compute_atmosphere_ocean_fluxes!" + (" + the cell-local part of compute_net_ocean_fluxes! in its epilogue" if fused else "")
         ao_bytes = BYTES_AO_FUSED if fused else BYTES_AO
+        if tail_mode:   # the launch also interpolates the NEXT step's atmosphere state in its tail workgroups
+            ao_what += " + interpolate_atmosphere_state! of the next step in its tail workgroups"
+            ao_bytes += BYTES_INTERP
 
         def roof(name, nbytes, ncells, ms, **extra):
             achieved = nbytes * ncells / (ms * 1e-3) / 1e9
@@ -505,6 +516,7 @@ def main():
                    config=dict(workload=workload, global_cells=cells_total, parallelism=f"latitude-slab x{world}",
                                rows_per_rank=ny, halo_backend=best, halo_verified=(sorted(exchangers) if world > 1 else None),
                                halo_rows=ring_rows if world > 1 else 0, pipelined_interpolation=pipeline,
+                               pipeline_mode=mode,
                                step_loop="cf_time_steps (C)" if (a.config == "ocean" and best != "torch") else "host"),
                    settle_steps=settle.get(best), repetitions=reps, ms_per_step_samples=[s / steps * 1e3 for s in samples],
                    halo_paths_ms_per_step={k: v[0] / steps * 1e3 for k, v in results.items()} if world > 1 else None,
@@ -513,7 +525,11 @@ def main():
                                  launches_timed=nrec,
                                  bytes_per_cell_note=("80 B read + 48 B written (SURVEY §8d, the contract figure of the solver) + Qs, Ql, Mp read "
                                                       "and JT, JS, SW written by the fused net-flux epilogue" if fused else
-                                                      "80 B read + 48 B written (SURVEY §8d)"),
+                                                      "80 B read + 48 B written (SURVEY §8d)") +
+                                                     (" + 18.3 B of the JRA55 window read and 64 B of exchange fields written by the tail "
+                                                      "workgroups (interpolate_atmosphere_state! of the next step, SURVEY §8d)" if tail_mode else ""),
+                                 frac_solver_and_net_only_176_B_per_cell=(BYTES_AO_FUSED * cells_rank / (ao_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                                          if tail_mode else None),
                                  frac_at_contract_128_B_per_cell=BYTES_AO * cells_rank / (ao_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  measured="HIP events around the kernel inside a separate event-bracketed pass over the timed schedule",
                                  avg_launch_ms_batches_sorted_by_trip_hints=prof_sorted[1][0] if prof_sorted else None,
@@ -522,7 +538,7 @@ def main():
                    roofline_net_fluxes=(roof("net_stress_kernel (compute_net_ocean_fluxes!: the two face stresses)", BYTES_STRESS, nx * ny, net_ms)
                                         if fused else roof("net_flux_kernel (compute_net_ocean_fluxes!)", BYTES_NET, nx * ny, net_ms)),
                    stages_ms=dict(interpolate_tiled_standalone=interp_ms,
-                                  interpolate_background_standalone=interp_bg_ms if pipeline else None,
+                                  interpolate_background_standalone=interp_bg_ms if mode == "on" else None,
                                   ao_fluxes=ao_ms, net_fluxes=net_ms, ao_fluxes_standalone=ao_ms_alone,
                                   net_fluxes_standalone=net_ms_alone),
                    device_copy_GBs=2 * copy_bytes / (copy_ms * 1e-3) / 1e9,

@@ -515,7 +515,8 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->fused_interp = value;
             return CF_OK;
         case CF_OPT_MERGED_PREFETCH:
-            if (value < 0 || value > 1) return fail(ctx, CF_ERR_INVALID, "merged prefetch %d: 0 (auxiliary stream), 1 (in the face-stress launch)", value);
+            if (value < 0 || value > 2)
+                return fail(ctx, CF_ERR_INVALID, "merged prefetch %d: 0 (auxiliary stream), 1 (in the face-stress launch), 2 (tail workgroups of the solver launch)", value);
             ctx->merged_prefetch = value;
             return CF_OK;
         case CF_OPT_ICE_ORBIT_SHORTCUT:
@@ -719,6 +720,26 @@ int cf_compute_net_ocean_fluxes(cf_ctx* ctx, const cf_ocean_surface* ocean, cons
     return CF_OK;
 }
 
+// A deferred next-step interpolation (cf_prefetch_atmosphere_state) that has just been launched on the MAIN stream — as the
+// solver launch's tail workgroups, inside the face-stress launch, or as a plain launch: stream order replaces the event.
+int deferred_went_out_on_main(cf_ctx* ctx) {
+    cf_ctx::Prefetch* slot = nullptr;
+    for (auto& p : ctx->prefetch)
+        if (p.valid && p.key == ctx->deferred.out.u) slot = &p;
+    if (!slot)
+        for (auto& p : ctx->prefetch)
+            if (!p.valid) slot = &p;
+    if (!slot) return fail(ctx, CF_ERR_INVALID, "two prefetched atmosphere states are already pending");
+    slot->key = ctx->deferred.out.u;
+    slot->level1 = ctx->deferred.src.level1;
+    slot->level2 = ctx->deferred.src.level2;
+    slot->tf = ctx->deferred.src.time_fraction;
+    slot->valid = true;
+    slot->on_main = true;
+    ctx->deferred.valid = false;
+    return CF_OK;
+}
+
 int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
                     const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
                     const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net) {
@@ -758,6 +779,26 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     if (!prefetched && !fuse_interp) HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     CHECK(wait_for_halos(ctx));  // the interpolation above overlapped the halo rows
+    // CF_OPT_MERGED_PREFETCH = 2: a requested next-step interpolation becomes the TAIL workgroups of this solver launch
+    const bool tail = fuse && !fuse_interp && ctx->merged_prefetch == 2 && ctx->deferred.valid && ctx->launch.interp_cap != 0 &&
+                      ctx->deferred.out.u != atmos->u && !ctx->launch.ao_wide && ctx->launch.d_lean_info &&
+                      ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
+    if (tail) {
+        int rows = 4, blocks = 1;
+        interpolate_grid(ctx->launch, ctx->grid, &rows, &blocks);
+        static const int tail_cap = [] {  // (experiments: COFLUX_EXPERIMENTS=1 COFLUX_TAIL_BLOCKS=n, read once)
+            const char* e = experiment_knob("COFLUX_TAIL_BLOCKS");
+            return e ? std::max(1, std::atoi(e)) : 0;
+        }();
+        if (tail_cap > 0) blocks = std::min(blocks, tail_cap);
+        static const int tail_pos = [] {  // (experiments: COFLUX_TAIL_POS = dispatch index of the first interpolation workgroup; default: behind the solver)
+            const char* e = experiment_knob("COFLUX_TAIL_POS");
+            return e ? std::atoi(e) : -1;
+        }();
+        HIP_TRY(ctx, launch_ao_fluxes_lean(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes, ice, net,
+                                           ctx->d_land_freshwater, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out, rows, blocks, tail_pos));
+        CHECK(deferred_went_out_on_main(ctx));
+    } else
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes,
                                   fuse ? ice : nullptr, fuse ? net : nullptr, ctx->d_land_freshwater,
                                   fuse_interp ? src : nullptr, fuse_interp ? w : nullptr));
@@ -765,27 +806,14 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     // face-stress launch on the main stream — two independent memory-bound kernels, one launch boundary fewer (on a
     // latitude slab a boundary is a tenth of the step).  Otherwise it goes out on the auxiliary stream right behind the
     // solver: the solver's workgroups are dispatched first, the gather kernel takes what they leave free.
-    const bool merge = fuse && ctx->merged_prefetch != 0 && ctx->deferred.valid && ctx->launch.interp_cap != 0 &&
+    const bool merge = fuse && ctx->merged_prefetch == 1 && ctx->deferred.valid && ctx->launch.interp_cap != 0 &&
                        ctx->deferred.out.u != atmos->u;
-    if (!merge) CHECK(cf_flush_deferred_prefetch(ctx));
+    if (ctx->merged_prefetch == 0) CHECK(cf_flush_deferred_prefetch(ctx));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     if (merge) {
-        cf_ctx::Prefetch* slot = nullptr;
-        for (auto& p : ctx->prefetch)
-            if (p.valid && p.key == ctx->deferred.out.u) slot = &p;
-        if (!slot)
-            for (auto& p : ctx->prefetch)
-                if (!p.valid) slot = &p;
-        if (!slot) return fail(ctx, CF_ERR_INVALID, "two prefetched atmosphere states are already pending");
         HIP_TRY(ctx, launch_interpolate_and_stress(ctx->stream, ctx->launch, ctx->dev, ctx->grid, &ctx->deferred.src, &ctx->deferred.w,
                                                    &ctx->deferred.out, ocean, fluxes, ice, net));
-        slot->key = ctx->deferred.out.u;
-        slot->level1 = ctx->deferred.src.level1;
-        slot->level2 = ctx->deferred.src.level2;
-        slot->tf = ctx->deferred.src.time_fraction;
-        slot->valid = true;
-        slot->on_main = true;
-        ctx->deferred.valid = false;
+        CHECK(deferred_went_out_on_main(ctx));
     } else if (fuse)
         HIP_TRY(ctx, launch_net_stress(ctx->stream, ctx->dev, ctx->grid, ocean, fluxes, ice, net));
     else
@@ -793,6 +821,12 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     if (rec) {
         HIP_TRY(ctx, hipEventRecord(ev[3], ctx->stream));
         ++ctx->prof_count;
+    }
+    if (ctx->merged_prefetch != 0 && ctx->deferred.valid && ctx->deferred.out.u != atmos->u) {
+        // neither merged form applies to this step (another solver kernel, un-fused net fluxes …): the requested interpolation
+        // goes out as a launch of its own on the same stream — the sequence of an un-pipelined step, one step early
+        HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out));
+        CHECK(deferred_went_out_on_main(ctx));
     }
     return CF_OK;
 }

@@ -143,3 +143,6 @@ int cf_fail(cf_ctx* ctx, int code, const char* fmt, ...);
         int rc_ = (call);      \
         if (rc_ != CF_OK) return rc_; \
     } while (0)
+
+// coflux_abi.cpp: books ctx->deferred as launched on the main stream (see cf_update_state)
+extern "C" int deferred_went_out_on_main(cf_ctx* ctx);

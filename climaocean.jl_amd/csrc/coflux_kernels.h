@@ -57,7 +57,8 @@ hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32
 hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
                                  const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
                                  const cf_sea_ice_fields* ice = nullptr, const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr,
-                                 const cf_atmos_source* src = nullptr, const cf_interp_weights* w = nullptr);
+                                 const cf_atmos_source* src = nullptr, const cf_interp_weights* w = nullptr,
+                                 const cf_exchange_fields* next_out = nullptr, int tail_rows = 0, int tail_blocks = 0, int tail_pos = -1);
 size_t wet_list_capacity(int ncells);
 int wet_list_stride(bool wide);
 hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
@@ -68,6 +69,7 @@ hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc&
 hipError_t launch_interpolate_land(hipStream_t st, const GridDesc& G, const cf_land_source* s, const cf_interp_weights* w, double* out);
 hipError_t launch_salinity_restoring(hipStream_t st, const DevParams& P, const GridDesc& G, const void* mask, double vp,
                                      const double* target, const double* S, double* out);
+void interpolate_grid(const LaunchCfg& L, const GridDesc& G, int* rows_out, int* blocks_out);
 hipError_t launch_interpolate_and_stress(hipStream_t st, const LaunchCfg& L, const DevParams& P, const GridDesc& G,
                                          const cf_atmos_source* s, const cf_interp_weights* w, const cf_exchange_fields* e,
                                          const cf_ocean_surface* o, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,

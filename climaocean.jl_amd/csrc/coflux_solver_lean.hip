@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "coflux_interp_cell.hpp"
+#include "coflux_interp_tiles.hpp"
 #include "coflux_lean.hpp"
 #include "coflux_solver_shared.hpp"
 
@@ -75,8 +76,12 @@ struct LeanArgs {
     long long sort_enabled;   // CF_OPT_TRIP_HINTS
     IceIn I;                  // fused net fluxes only
     NetOut N;
-    SourceDesc S;             // fused interpolation only: the JRA55 window and the weights of interpolate_atmosphere_state!
+    SourceDesc S;             // fused interpolation / tail workgroups: the JRA55 window and the weights of interpolate_atmosphere_state!
     WeightDesc Wt;
+    Exchange E_next;          // TAIL: the exchange fields of the NEXT step (another set than E)
+    long long n_chunks;       // TAIL: workgroups [0, n_chunks) solve, the tail_blocks behind them interpolate
+    long long tail_blocks, tail_rows, tail_cap;
+    long long tail_pos;       // TAIL: index of the first interpolation workgroup in dispatch order (n_chunks: behind every solver workgroup)
 };
 typedef const LeanArgs __attribute__((address_space(4)))* LeanArgsPtr;
 
@@ -144,11 +149,32 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 // from the JRA55 window in its prologue (72 gathers per cell that hit L2 and ride the vector-memory pipe the FP64-bound
 // solver leaves idle), writes them (the API's outputs) and keeps what it needs in registers; land cells get theirs with
 // their zeros.  update_state! is then two launches: this kernel and the face stresses.
-template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false>
+// TAIL: the launch carries tail_blocks more workgroups BEHIND the solver's (dispatch follows the workgroup index, so they
+// take the slots the solver's workgroups free as they retire): they interpolate the NEXT step's atmosphere state into the
+// other set of exchange fields with the tiled routine of interpolate_kernel — memory-bound work under the solver's
+// FP64-bound tail instead of a launch of its own in front of the next solver (cf_time_steps with two exchange sets).
+template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false>
 __global__ __launch_bounds__(BLOCK, BLOCK == AO_BLOCK ? CF_LEAN_WAVES : 3) void ao_lean_kernel(LeanArgs unused_by_name) {
     using Geo = LeanGeom<BLOCK>;
     constexpr int CHUNK = Geo::CHUNK;
     LeanArgsPtr K = opaque((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
+    int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
+    if constexpr (TAIL) {
+        static_assert(BLOCK == 64 * IT_WAVES, "a tail workgroup is an interpolation workgroup");
+        const int nb = (int)K->tail_blocks, ipos = (int)K->tail_pos;
+        if (chunk >= ipos && chunk < ipos + nb) {
+            const SourceDesc S = kread(&K->S);
+            const WeightDesc Wt = kread(&K->Wt);
+            const GridDesc Gt = kread(&K->G);
+            const Exchange En = kread(&K->E_next);
+            const int b = chunk - ipos, cap = (int)K->tail_cap, rows = (int)K->tail_rows;
+            if (rows == 4) interpolate_tiles<4>(S, Wt, Gt, En, cap, b, nb);
+            else if (rows == 2) interpolate_tiles<2>(S, Wt, Gt, En, cap, b, nb);
+            else interpolate_tiles<1>(S, Wt, Gt, En, cap, b, nb);
+            return;
+        }
+        if (chunk >= ipos) chunk -= nb;
+    }
     const LoopParams L = kread(&K->L);
     const GridDesc G = kread(&K->G);
     const double* __restrict__ g_tab = K->g_tab;
@@ -166,7 +192,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK == AO_BLOCK ? CF_LEAN_WAVES : 3) void 
     LEAN_STAMP(0);
     const int wx = G.nx + 2 * G.ring;
     const unsigned wx_rcp = (unsigned)K->wx_reciprocal;
-    const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
     const bool use_static = K->sorted != nullptr;
     unsigned long long stamp_iter = 0, stamp_batches = 0, stamp_trips = 0;
     // ---- start phase: everything is REQUESTED before anything is looked at, in straight-line code ----------------
@@ -583,7 +608,8 @@ hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32
 hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
                                  const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
                                  const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land,
-                                 const cf_atmos_source* src, const cf_interp_weights* w) {
+                                 const cf_atmos_source* src, const cf_interp_weights* w, const cf_exchange_fields* next_out,
+                                 int tail_rows, int tail_blocks, int tail_pos) {
     if (!L.d_chunk_begins || L.n_chunks <= 0 || !L.d_lean_info) return hipErrorInvalidValue;
     LeanArgs A{};
     A.L = C;
@@ -615,6 +641,23 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
                      net->downwelling_shortwave};
     }
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
+    if (next_out) {
+        // tail workgroups: `src`, `w` describe the NEXT step's interpolation into `next_out` (narrow geometry, fused net fluxes)
+        if (!net || !src || !w || L.ao_wide || L.interp_cap <= 0 || tail_blocks <= 0) return hipErrorInvalidValue;
+        const size_t tile_lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double);
+        if (tile_lds > (size_t)LeanGeom<AO_BLOCK>::LDS_BYTES) return hipErrorInvalidValue;
+        A.S = make_source(src);
+        A.Wt = make_weights(w);
+        A.E_next = make_exchange(next_out);
+        A.n_chunks = L.n_chunks;
+        A.tail_blocks = tail_blocks;
+        A.tail_rows = tail_rows;
+        A.tail_cap = L.interp_cap;
+        A.tail_pos = tail_pos < 0 || tail_pos > L.n_chunks ? L.n_chunks : tail_pos;
+        if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK, true, false, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK, true, false, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        return hipGetLastError();
+    }
 #define CF_LEAN_LAUNCH(COARE_, BLOCK_, FUSE_) \
     hipLaunchKernelGGL((ao_lean_kernel<COARE_, BLOCK_, FUSE_>), dim3(L.n_chunks), dim3(BLOCK_), LeanGeom<BLOCK_>::LDS_BYTES, st, A)
     if (src) {  // interpolation fused too (narrow geometry, with the fused net fluxes: launch_ao_fluxes checks)

@@ -289,7 +289,19 @@ int cf_time_steps(cf_ctx* ctx, int64_t first_step, int nsteps, const cf_run_sche
                       ctx->deferred.src.time_fraction == s0.time_fraction;
             if (pending) CHECK(cf_flush_deferred_prefetch(ctx));
         }
-        if (!pending) CHECK(request_prefetch(ctx, &s0, w, a0, false));
+        if (!pending) {
+            if (ctx->merged_prefetch != 0) {
+                // the merged forms keep everything on the context's stream: so does the first step's interpolation
+                CHECK(cf_flush_deferred_prefetch(ctx));
+                HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, &s0, w, a0));
+                ctx->deferred.src = s0;
+                ctx->deferred.w = *w;
+                ctx->deferred.out = *a0;
+                CHECK(deferred_went_out_on_main(ctx));
+            } else {
+                CHECK(request_prefetch(ctx, &s0, w, a0, false));
+            }
+        }
     }
     for (int64_t step = first_step; step < first_step + nsteps; ++step) {
         const cf_ocean_surface* o = &S->ocean_states[step % S->n_ocean_states];

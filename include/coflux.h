@@ -356,7 +356,9 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * workgroups do one or the other (same arithmetic, same bits) — instead of on the auxiliary stream: a
                                    * step is then two launches (solver; stresses + next interpolation).  Pays where launch boundaries
                                    * dominate (a latitude slab of a strongly scaled run); needs the fused net fluxes and the tiled
-                                   * interpolation.  0 (default): auxiliary stream.                                                  */
+                                   * interpolation.  0 (default): auxiliary stream.
+                                   * 2: the requested interpolation becomes extra workgroups BEHIND the solver's in the solver launch
+                                   * (round-3 ocean kernel): they take the slots the solver's workgroups free as they retire.       */
 #define CF_OPT_ICE_ORBIT_SHORTCUT 7 /* 1 (default): the atmosphere–sea-ice iteration stops as soon as its state repeats the state of two
                                      iterations ago bit for bit — an exact period-2 orbit, where the skin-temperature balance does not
                                      contract — and returns the iterate the remaining steps up to maxiter would end on (the same

@@ -48,7 +48,7 @@ def _host_steps(ctx, states, src, w, n, n_levels=4):
     return atmos, fl, net
 
 
-@pytest.mark.parametrize("pipeline", [False, True, "merged"])
+@pytest.mark.parametrize("pipeline", [False, True, "merged", "tail"])
 def test_time_steps_reproduces_host_loop_bitwise(pipeline):
     """cf_time_steps (C loop, advancing clock through a 4-snapshot window, alternating ocean states, optionally
     with the next step's interpolation on the auxiliary stream, or — CF_OPT_MERGED_PREFETCH — inside the current step's
@@ -56,8 +56,8 @@ def test_time_steps_reproduces_host_loop_bitwise(pipeline):
     n = 21   # crosses two snapshot boundaries (9 steps per snapshot interval)
     ctx, states, src, w, _ = _setup()
     ref_atmos, ref_fl, ref_net = _host_steps(ctx, states, src, w, n)
-    if pipeline == "merged":
-        ctx.set_option(abi.OPT_MERGED_PREFETCH, 1)
+    if pipeline in ("merged", "tail"):
+        ctx.set_option(abi.OPT_MERGED_PREFETCH, 1 if pipeline == "merged" else 2)
     sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2 if pipeline else 1)]
     fl, net = ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
     sched = ctx.make_schedule(states, sets, first_level=0, time_fraction=0.0, time_fraction_increment=INC, pipeline=bool(pipeline))
