@@ -257,7 +257,7 @@ def main():
     lean0, fused0 = ctx.solver_path()
     mode = a.pipeline
     if mode == "auto":
-        mode = "tail" if (a.config == "ocean" and lean0 and fused0 == 1) else "off"
+        mode = "tail" if (lean0 and fused0 == 1) else "off"
     pipeline = mode in ("on", "merged", "tail")
     if mode in ("merged", "tail"):
         ctx.set_option(abi.OPT_MERGED_PREFETCH, 1 if mode == "merged" else 2)
@@ -355,10 +355,18 @@ def main():
                 tot = s * inc
                 l1 = int(tot) % n_levels
                 kw = dict(level1=l1, level2=(l1 + 1) % n_levels, time_fraction=tot - int(tot))
+                cur = atmos_sets[s % len(atmos_sets)]
+                if tail_mode and len(atmos_sets) == 2:
+                    # the host-driven loop asks for the next step's atmosphere itself (cf_time_steps does the same in C): it
+                    # becomes the tail workgroups of this step's ocean-solver launch
+                    nxt = (s + 1) * inc
+                    l1n = int(nxt) % n_levels
+                    ctx.prefetch_atmosphere_state(src, w, atmos_sets[(s + 1) % 2], level1=l1n, level2=(l1n + 1) % n_levels,
+                                                  time_fraction=nxt - int(nxt))
                 if a.config == "sea_ice":
-                    ctx.update_state_sea_ice(src, w, st, atmos_sets[0], fl, net, ice, ice_state, ai, net_ice, **kw)
+                    ctx.update_state_sea_ice(src, w, st, cur, fl, net, ice, ice_state, ai, net_ice, **kw)
                 else:
-                    ctx.update_state(src, w, st, atmos_sets[0], fl, net, **kw)
+                    ctx.update_state(src, w, st, cur, fl, net, **kw)
         else:
             ctx.time_steps(first, n, sched, src, w, fl, net)
 
@@ -560,13 +568,13 @@ def main():
         # strong-scaling projection from single-GPU measurements of one rank's slab (scratch/slab_curve.py): a PROJECTION,
         # labelled as such — the driver computes the real curve from its own N-GPU runs
         try:
-            sc = json.load(open(os.path.join(ROOT, "profiles", "r04a_slab_curve.json")))
+            sc = json.load(open(os.path.join(ROOT, "profiles", "r04b_slab_curve.json")))
             if canonical and world == 1:
                 out["projected_scaling"] = dict(
                     kind="projection from one GPU, not a multi-GPU measurement",
                     speedup_before_halo_rows={k: round(v, 3) for k, v in sc["projected_speedup_before_halos"].items()},
                     slab_ms_per_step={k: round(v["ms_per_step"], 5) for k, v in sc["slabs"].items()},
-                    source="committed: profiles/r03_slab_curve.json (python bench.py --ny 560/280/140/70 on one MI355X)",
+                    source="committed: profiles/r04b_slab_curve.json (python bench.py --ny 560/280/140/70 on one MI355X)",
                     note=sc["note"])
         except Exception:
             pass
