@@ -29,6 +29,8 @@ for n in range(ncases):
             l1 = int(tot) % n_levels
             ctx.update_state(src, w, states[s % 2], ra, rf, rn, level1=l1, level2=(l1 + 1) % n_levels, time_fraction=tot - int(tot))
         ctx.sync()
+        merged = int(rng.integers(0, 3)) if pipeline else 0   # CF_OPT_MERGED_PREFETCH: aux stream / stress launch / solver tail
+        ctx.set_option(abi.OPT_MERGED_PREFETCH, merged)
         sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2 if pipeline else 1)]
         fl, net = ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
         sched = ctx.make_schedule(states, sets, first_level=0, time_fraction=tf0, time_fraction_increment=inc, pipeline=pipeline)
@@ -43,5 +45,5 @@ for n in range(ncases):
         ctx.close()
     except Exception as exc:
         bad += 1
-        print("FAIL", n, dict(nx=nx, ny=ny, h=h, n_levels=n_levels, inc=inc, nsteps=nsteps, pipeline=pipeline, cfg=cfg.__name__), repr(exc)[:300], flush=True)
+        print("FAIL", n, dict(nx=nx, ny=ny, h=h, n_levels=n_levels, inc=inc, nsteps=nsteps, pipeline=pipeline, merged=merged if pipeline else None, cfg=cfg.__name__), repr(exc)[:300], flush=True)
 print(f"{ncases - bad} of {ncases} cases passed", flush=True)
