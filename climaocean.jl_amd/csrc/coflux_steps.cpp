@@ -314,7 +314,9 @@ int cf_time_steps(cf_ctx* ctx, int64_t first_step, int nsteps, const cf_run_sche
         if (S->fold_north) CHECK(cf_fold_north_halo(ctx, rows, fold_loc, fold_sign, 4, ctx->grid.ring + 1));
         const cf_atmos_source s = source_at(step);
         const cf_exchange_fields* a = &S->atmos[S->n_atmos_sets == 2 ? step % 2 : 0];
-        if (S->pipeline && step + 1 < first_step + nsteps) {
+        if (S->pipeline) {
+            // (also on the last step of this call: the loop goes on in the next call, which finds the state pending; a
+            // caller that stops here has one unused interpolation in the other exchange set)
             // queued BEFORE this step's kernels: the set it overwrites was last read by the previous step's net fluxes
             const cf_atmos_source sn = source_at(step + 1);
             CHECK(cf_prefetch_atmosphere_state(ctx, &sn, w, &S->atmos[(step + 1) % 2]));
