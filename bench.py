@@ -257,11 +257,11 @@ def main():
     lean0, fused0 = ctx.solver_path()
     mode = a.pipeline
     if mode == "auto":
-        mode = "tail" if (lean0 and fused0 == 1) else "off"
+        mode = "tail" if (fused0 == 1 and (lean0 or a.flux_configuration == "ncar")) else "off"
     pipeline = mode in ("on", "merged", "tail")
     if mode in ("merged", "tail"):
         ctx.set_option(abi.OPT_MERGED_PREFETCH, 1 if mode == "merged" else 2)
-    tail_mode = mode == "tail" and lean0 and fused0 == 1
+    tail_mode = mode == "tail" and fused0 == 1 and (lean0 or a.flux_configuration == "ncar")
     atmos_sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2 if pipeline else 1)]
     fl = ctx.field_set(FLUX_NAMES)
     # compute_net_ocean_fluxes! writes five fields (τx, τy, Jᵀ, Jˢ, penetrating shortwave: the 40 B/cell of the contract);

@@ -780,9 +780,10 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     CHECK(wait_for_halos(ctx));  // the interpolation above overlapped the halo rows
     // CF_OPT_MERGED_PREFETCH = 2: a requested next-step interpolation becomes the TAIL workgroups of this solver launch
+    const bool tail_lean = ctx->launch.d_lean_info && ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
+    const bool tail_ly = ctx->fast.specialization == SOLVER_LY && ctx->launch.solver == CF_SOLVER_TABLES;
     const bool tail = fuse && !fuse_interp && ctx->merged_prefetch == 2 && ctx->deferred.valid && ctx->launch.interp_cap != 0 &&
-                      ctx->deferred.out.u != atmos->u && !ctx->launch.ao_wide && ctx->launch.d_lean_info &&
-                      ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
+                      ctx->deferred.out.u != atmos->u && !ctx->launch.ao_wide && (tail_lean || tail_ly);
     if (tail) {
         int rows = 4, blocks = 1;
         interpolate_grid(ctx->launch, ctx->grid, &rows, &blocks);
@@ -795,8 +796,12 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
             const char* e = experiment_knob("COFLUX_TAIL_POS");
             return e ? std::atoi(e) : -1;
         }();
-        HIP_TRY(ctx, launch_ao_fluxes_lean(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes, ice, net,
-                                           ctx->d_land_freshwater, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out, rows, blocks, tail_pos));
+        if (tail_lean)
+            HIP_TRY(ctx, launch_ao_fluxes_lean(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes, ice, net,
+                                               ctx->d_land_freshwater, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out, rows, blocks, tail_pos));
+        else
+            HIP_TRY(ctx, launch_ly_fluxes_with_tail(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes, ice, net,
+                                                    ctx->d_land_freshwater, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out, rows, blocks));
         CHECK(deferred_went_out_on_main(ctx));
     } else
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes,

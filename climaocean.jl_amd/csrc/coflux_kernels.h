@@ -54,6 +54,11 @@ hipError_t launch_net_stress(hipStream_t st, const DevParams& P, const GridDesc&
 hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks, bool wide,
                            const int* d_begins, uint32_t* d_wet_pos, uint8_t* d_trip, int* d_scratch, int* overflow_out);
 hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32_t* d_wet_pos, const int* d_begins, uint32_t* d_sorted, int* d_info);
+hipError_t launch_ly_fluxes_with_tail(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
+                                      const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
+                                      const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land,
+                                      const cf_atmos_source* next_src, const cf_interp_weights* w, const cf_exchange_fields* next_out,
+                                      int tail_rows, int tail_blocks);
 hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
                                  const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
                                  const cf_sea_ice_fields* ice = nullptr, const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr,

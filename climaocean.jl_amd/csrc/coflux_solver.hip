@@ -320,10 +320,27 @@ size_t wet_list_capacity(int ncells) { return (size_t)chunk_table_capacity(ncell
 
 // (second launch bound = waves per SIMD: the lean ocean iteration fits 128 VGPRs — four narrow workgroups per CU, whose
 // LDS, tables included, is 39 KB each; everything else keeps three)
-template <bool COARE, int SPEC, bool FUSE_NET, int BLOCK>
+// TAIL: workgroups behind the chunk table's interpolate the NEXT step's atmosphere state (see ao_lean_kernel; instantiated for
+// CoefficientBasedFluxes with the fused net fluxes, the OMIP-2 standard configuration)
+template <bool COARE, int SPEC, bool FUSE_NET, int BLOCK, bool TAIL = false>
 __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BLOCK) ? CF_LEAN_WAVES : 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
     constexpr int CHUNK = Geom<BLOCK>::CHUNK;
     SolverArgsPtr K = opaque((SolverArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
+    if constexpr (TAIL) {
+        static_assert(BLOCK == 64 * IT_WAVES, "a tail workgroup is an interpolation workgroup");
+        const int nch = (int)K->n_chunks;
+        if ((int)blockIdx.x >= nch) {
+            const SourceDesc S = kread(&K->Si);
+            const WeightDesc Wt = kread(&K->Wi);
+            const GridDesc Gt = kread(&K->G);
+            const Exchange En = kread(&K->E_next);
+            const int b = (int)blockIdx.x - nch, nb = (int)K->tail_blocks, cap = (int)K->tail_cap, rows = (int)K->tail_rows;
+            if (rows == 4) interpolate_tiles<4>(S, Wt, Gt, En, cap, b, nb);
+            else if (rows == 2) interpolate_tiles<2>(S, Wt, Gt, En, cap, b, nb);
+            else interpolate_tiles<1>(S, Wt, Gt, En, cap, b, nb);
+            return;
+        }
+    }
     const LoopParams L = kread(&K->L);
     const GridDesc G = kread(&K->G);
     const WetLists W = kread(&K->W);
@@ -845,6 +862,35 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
         default: CF_LAUNCH(COARE, SOLVER_GENERIC);
     }
 #undef CF_LAUNCH
+}
+
+// CoefficientBasedFluxes with the fused net fluxes AND the next step's interpolation in tail workgroups (narrow geometry)
+hipError_t launch_ly_fluxes_with_tail(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
+                                      const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
+                                      const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land,
+                                      const cf_atmos_source* next_src, const cf_interp_weights* w, const cf_exchange_fields* next_out,
+                                      int tail_rows, int tail_blocks) {
+    if (!L.d_chunk_begins || L.n_chunks <= 0 || L.ao_wide || !net || !next_src || !w || !next_out || L.interp_cap <= 0 || tail_blocks <= 0 ||
+        C.specialization != SOLVER_LY)
+        return hipErrorInvalidValue;
+    if ((size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double) > (size_t)Geom<AO_BLOCK>::LDS_BYTES) return hipErrorInvalidValue;
+    IceIn I{};
+    if (ice) I = IceIn{ice->concentration, ice->interface_heat, ice->salt_flux, ice->x_stress, ice->y_stress, nullptr};
+    I.land = land;
+    const NetOut N{net->u, net->v, net->T, net->S, net->shortwave_surface_flux, net->upwelling_longwave, net->downwelling_longwave,
+                   net->downwelling_shortwave};
+    SolverArgs A{C, G, make_ocean(o), make_exchange(e), make_fluxes(f), L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip},
+                 L.d_chunk_begins, I, N, IceStateIn{}, IceParams{}, P.z_surface, P.mask_kind, P.T_offset, row_reciprocal(G.nx + 2 * G.ring)};
+    A.Si = make_source(next_src);
+    A.Wi = make_weights(w);
+    A.E_next = make_exchange(next_out);
+    A.n_chunks = L.n_chunks;
+    A.tail_blocks = tail_blocks;
+    A.tail_rows = tail_rows;
+    A.tail_cap = L.interp_cap;
+    hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_LY, true, AO_BLOCK, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK),
+                       Geom<AO_BLOCK>::LDS_BYTES, st, A);
+    return hipGetLastError();
 }
 
 // `net` != nullptr: the fused form — the solver's epilogue also writes the cell-local net ocean fluxes (JT, JS,

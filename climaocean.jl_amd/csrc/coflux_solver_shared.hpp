@@ -7,6 +7,7 @@
 #include "coflux_fast.hpp"
 #include "coflux_kernel_types.hpp"
 #include "coflux_kernels.h"
+#include "coflux_interp_tiles.hpp"
 
 namespace coflux {
 
@@ -70,6 +71,11 @@ struct SolverArgs {
     long long mask_kind;
     double T_offset;     // (zero_interface_state writes −T_offset; same reason)
     unsigned long long wx_reciprocal;  // floor(2³² / (nx + 2·ring)), see row_of
+    // TAIL launches only (CF_OPT_MERGED_PREFETCH = 2): the next step's interpolation in the workgroups behind the chunks'
+    SourceDesc Si;
+    WeightDesc Wi;
+    Exchange E_next;
+    long long n_chunks, tail_blocks, tail_rows, tail_cap;
 };
 typedef const SolverArgs __attribute__((address_space(4)))* SolverArgsPtr;
 
