@@ -740,9 +740,13 @@ int deferred_went_out_on_main(cf_ctx* ctx) {
     return CF_OK;
 }
 
-int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
-                    const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
-                    const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net) {
+// hold_tail_work (cf_update_state_sea_ice with CF_OPT_MERGED_PREFETCH = 2): the face stresses and a requested next-step
+// interpolation are NOT launched here — they ride in the tail of the sea-ice interface launch that follows, whose workgroups
+// retire over a much longer span than the ocean solver's; *stress_held tells the caller whether the stresses are still due.
+static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
+                             const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
+                             const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net,
+                             bool hold_tail_work, bool* stress_held) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     CHECK(check_source(ctx, src));
@@ -782,8 +786,8 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     // CF_OPT_MERGED_PREFETCH = 2: a requested next-step interpolation becomes the TAIL workgroups of this solver launch
     const bool tail_lean = ctx->launch.d_lean_info && ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
     const bool tail_ly = ctx->fast.specialization == SOLVER_LY && ctx->launch.solver == CF_SOLVER_TABLES;
-    const bool tail = fuse && !fuse_interp && ctx->merged_prefetch == 2 && ctx->deferred.valid && ctx->launch.interp_cap != 0 &&
-                      ctx->deferred.out.u != atmos->u && !ctx->launch.ao_wide && (tail_lean || tail_ly);
+    const bool tail = fuse && !fuse_interp && !hold_tail_work && ctx->merged_prefetch == 2 && ctx->deferred.valid &&
+                      ctx->launch.interp_cap != 0 && ctx->deferred.out.u != atmos->u && !ctx->launch.ao_wide && (tail_lean || tail_ly);
     if (tail) {
         int rows = 4, blocks = 1;
         interpolate_grid(ctx->launch, ctx->grid, &rows, &blocks);
@@ -811,7 +815,7 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
     // face-stress launch on the main stream — two independent memory-bound kernels, one launch boundary fewer (on a
     // latitude slab a boundary is a tenth of the step).  Otherwise it goes out on the auxiliary stream right behind the
     // solver: the solver's workgroups are dispatched first, the gather kernel takes what they leave free.
-    const bool merge = fuse && ctx->merged_prefetch == 1 && ctx->deferred.valid && ctx->launch.interp_cap != 0 &&
+    const bool merge = fuse && !hold_tail_work && ctx->merged_prefetch == 1 && ctx->deferred.valid && ctx->launch.interp_cap != 0 &&
                        ctx->deferred.out.u != atmos->u;
     if (ctx->merged_prefetch == 0) CHECK(cf_flush_deferred_prefetch(ctx));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
@@ -819,6 +823,8 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
         HIP_TRY(ctx, launch_interpolate_and_stress(ctx->stream, ctx->launch, ctx->dev, ctx->grid, &ctx->deferred.src, &ctx->deferred.w,
                                                    &ctx->deferred.out, ocean, fluxes, ice, net));
         CHECK(deferred_went_out_on_main(ctx));
+    } else if (fuse && hold_tail_work) {
+        if (stress_held) *stress_held = true;   // (the caller's next launch carries them)
     } else if (fuse)
         HIP_TRY(ctx, launch_net_stress(ctx->stream, ctx->dev, ctx->grid, ocean, fluxes, ice, net));
     else
@@ -827,13 +833,19 @@ int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_wei
         HIP_TRY(ctx, hipEventRecord(ev[3], ctx->stream));
         ++ctx->prof_count;
     }
-    if (ctx->merged_prefetch != 0 && ctx->deferred.valid && ctx->deferred.out.u != atmos->u) {
+    if (!hold_tail_work && ctx->merged_prefetch != 0 && ctx->deferred.valid && ctx->deferred.out.u != atmos->u) {
         // neither merged form applies to this step (another solver kernel, un-fused net fluxes …): the requested interpolation
         // goes out as a launch of its own on the same stream — the sequence of an un-pipelined step, one step early
         HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out));
         CHECK(deferred_went_out_on_main(ctx));
     }
     return CF_OK;
+}
+
+int cf_update_state(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
+                    const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
+                    const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net) {
+    return update_state_impl(ctx, src, w, ocean, atmos, fluxes, ice, net, false, nullptr);
 }
 
 int cf_profile_enable(cf_ctx* ctx, int max_records) {
@@ -1139,8 +1151,8 @@ int cf_compute_sea_ice_ocean_fluxes(cf_ctx* ctx, const cf_ice_ocean_params* para
     return CF_OK;
 }
 
-int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice_in, const cf_ocean_surface* ocean,
-                                         const cf_exchange_fields* atmos, const cf_interface_fluxes* out) {
+static int atmosphere_sea_ice_fluxes_impl(cf_ctx* ctx, const cf_sea_ice_state* ice_in, const cf_ocean_surface* ocean,
+                                          const cf_exchange_fields* atmos, const cf_interface_fluxes* out, const AiTail* tail) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
@@ -1156,8 +1168,13 @@ int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ic
     CHECK(wait_for_halos(ctx));
     CHECK(ensure_chunk_table(ctx, ocean->mask));
     HIP_TRY(ctx, launch_ai_fluxes(ctx->stream, ctx->launch, ctx->ice_dev, ctx->ice_loop, ctx->ice_kernel, ctx->grid, ice, ocean,
-                                  atmos, out, ctx->d_ice_tables, ctx->d_ice_params, ctx->trip_hints ? ctx->d_trip_ice : nullptr));
+                                  atmos, out, ctx->d_ice_tables, ctx->d_ice_params, ctx->trip_hints ? ctx->d_trip_ice : nullptr, tail));
     return CF_OK;
+}
+
+int cf_compute_atmosphere_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice_in, const cf_ocean_surface* ocean,
+                                         const cf_exchange_fields* atmos, const cf_interface_fluxes* out) {
+    return atmosphere_sea_ice_fluxes_impl(ctx, ice_in, ocean, atmos, out, nullptr);
 }
 
 int cf_compute_net_sea_ice_fluxes(cf_ctx* ctx, const cf_sea_ice_state* ice_in, const cf_ocean_surface* ocean,
@@ -1191,8 +1208,37 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
                             const double* interface_heat, const cf_net_sea_ice_fluxes* net_ice) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
-    CHECK(cf_update_state(ctx, src, w, ocean, atmos, ao_fluxes, ice_partition, net));
-    CHECK(cf_compute_atmosphere_sea_ice_fluxes(ctx, ice_state, ocean, atmos, ai_fluxes));
+    // CF_OPT_MERGED_PREFETCH = 2: the face stresses of this step and a requested next-step interpolation ride in the tail
+    // workgroups of the interface solve — the longest launch of the step, whose workgroups retire over tens of microseconds
+    const bool ice_tail = ctx->merged_prefetch == 2 && ctx->ice_loop.specialization == SOLVER_ICE &&
+                          ctx->launch.solver == CF_SOLVER_TABLES && !ctx->launch.ao_wide;
+    bool stress_held = false;
+    CHECK(update_state_impl(ctx, src, w, ocean, atmos, ao_fluxes, ice_partition, net, ice_tail, &stress_held));
+    AiTail T{};
+    bool interp_rides = false;
+    if (ice_tail) {
+        if (stress_held) {
+            T.d_ocean_params = ctx->launch.d_params;
+            T.stress_ocean = ocean;
+            T.stress_fluxes = ao_fluxes;
+            T.stress_ice = ice_partition;
+            T.stress_net = net;
+        }
+        if (ctx->deferred.valid && ctx->deferred.out.u != atmos->u && ctx->launch.interp_cap != 0) {
+            interpolate_grid(ctx->launch, ctx->grid, &T.interp_rows, &T.interp_blocks);
+            T.next_src = &ctx->deferred.src;
+            T.w = &ctx->deferred.w;
+            T.next_out = &ctx->deferred.out;
+            interp_rides = true;
+        }
+    }
+    const bool any_tail = stress_held || interp_rides;
+    CHECK(atmosphere_sea_ice_fluxes_impl(ctx, ice_state, ocean, atmos, ai_fluxes, any_tail ? &T : nullptr));
+    if (interp_rides) CHECK(deferred_went_out_on_main(ctx));
+    if (ice_tail && ctx->deferred.valid && ctx->deferred.out.u != atmos->u) {   // (no tiled interpolation configured: a launch of its own)
+        HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out));
+        CHECK(deferred_went_out_on_main(ctx));
+    }
     return cf_compute_net_sea_ice_fluxes(ctx, ice_state, ocean, atmos, ai_fluxes, frazil_heat, interface_heat, net_ice);
 }
 

@@ -81,10 +81,22 @@ hipError_t launch_interpolate_and_stress(hipStream_t st, const LaunchCfg& L, con
                                          const cf_net_ocean_fluxes* n);
 hipError_t launch_interpolate_background(hipStream_t st, const GridDesc& G, const cf_atmos_source* s,
                                          const cf_interp_weights* w, const cf_exchange_fields* e);
+// what may ride in the tail workgroups of the sea-ice interface launch (launch_ai_fluxes)
+struct AiTail {
+    const cf_atmos_source* next_src = nullptr;      // the next step's interpolation …
+    const cf_interp_weights* w = nullptr;
+    const cf_exchange_fields* next_out = nullptr;
+    int interp_rows = 0, interp_blocks = 0;
+    const DevParams* d_ocean_params = nullptr;      // … and this step's face stresses (compute_net_ocean_fluxes!)
+    const cf_ocean_surface* stress_ocean = nullptr;
+    const cf_interface_fluxes* stress_fluxes = nullptr;
+    const cf_sea_ice_fields* stress_ice = nullptr;
+    const cf_net_ocean_fluxes* stress_net = nullptr;
+};
 hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const IceParams& I,
                             const GridDesc& G, const cf_sea_ice_state* ice, const cf_ocean_surface* o,
                             const cf_exchange_fields* e, const cf_interface_fluxes* f, const double* d_tables,
-                            const DevParams* d_params, uint8_t* d_trip);
+                            const DevParams* d_params, uint8_t* d_trip, const AiTail* tail = nullptr);
 hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
                              int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
                              int* nchunks_out, int* wide_out);

@@ -330,14 +330,37 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
         static_assert(BLOCK == 64 * IT_WAVES, "a tail workgroup is an interpolation workgroup");
         const int nch = (int)K->n_chunks;
         if ((int)blockIdx.x >= nch) {
-            const SourceDesc S = kread(&K->Si);
-            const WeightDesc Wt = kread(&K->Wi);
+            int b = (int)blockIdx.x - nch;
+            const int nb = (int)K->tail_blocks;
             const GridDesc Gt = kread(&K->G);
-            const Exchange En = kread(&K->E_next);
-            const int b = (int)blockIdx.x - nch, nb = (int)K->tail_blocks, cap = (int)K->tail_cap, rows = (int)K->tail_rows;
-            if (rows == 4) interpolate_tiles<4>(S, Wt, Gt, En, cap, b, nb);
-            else if (rows == 2) interpolate_tiles<2>(S, Wt, Gt, En, cap, b, nb);
-            else interpolate_tiles<1>(S, Wt, Gt, En, cap, b, nb);
+            if (b < nb) {
+                const SourceDesc S = kread(&K->Si);
+                const WeightDesc Wt = kread(&K->Wi);
+                const Exchange En = kread(&K->E_next);
+                const int cap = (int)K->tail_cap, rows = (int)K->tail_rows;
+                if (rows == 4) interpolate_tiles<4>(S, Wt, Gt, En, cap, b, nb);
+                else if (rows == 2) interpolate_tiles<2>(S, Wt, Gt, En, cap, b, nb);
+                else interpolate_tiles<1>(S, Wt, Gt, En, cap, b, nb);
+                return;
+            }
+            // face stresses (net_stress_kernel's arithmetic: net_face_stress, contraction off — the same bits)
+            b -= nb;
+            const int idx = b * 256 + (int)threadIdx.x;
+            if (idx >= Gt.nx * Gt.ny) return;
+            const DevParams& Po = *K->stress_params;
+            const IceIn I = kread(&K->stress_ice);
+            const void* smask = K->stress_mask;
+            const double* __restrict__ rtx = K->rtx;
+            const double* __restrict__ rty = K->rty;
+            const int j = idx / Gt.nx;
+            const size_t k = cell_index(Gt, idx - j * Gt.nx, j);
+            const size_t kw = k - 1, ks = k - (size_t)Gt.sj;
+            const bool wet = cell_is_wet(Po, smask, k);
+            const double aice = I.conc ? I.conc[k] : 0.0;
+            const double tx = net_face_stress(Po, rtx[kw], rtx[k], I.conc ? I.conc[kw] : 0.0, aice, I.txio ? I.txio[k] : 0.0);
+            const double ty = net_face_stress(Po, rty[ks], rty[k], I.conc ? I.conc[ks] : 0.0, aice, I.tyio ? I.tyio[k] : 0.0);
+            K->tau_x[k] = wet ? tx : 0.0;
+            K->tau_y[k] = wet ? ty : 0.0;
             return;
         }
     }
@@ -934,7 +957,7 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
 hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const IceParams& Ice,
                             const GridDesc& G, const cf_sea_ice_state* ice, const cf_ocean_surface* o,
                             const cf_exchange_fields* e, const cf_interface_fluxes* f, const double* d_tables,
-                            const DevParams* d_params, uint8_t* d_trip) {
+                            const DevParams* d_params, uint8_t* d_trip, const AiTail* tail) {
     if (!L.d_chunk_begins || L.n_chunks <= 0) return hipErrorInvalidValue;
     SolverArgs A{};
     A.L = C;
@@ -956,6 +979,40 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
     // constant roughness lengths and a gustiness floor (both production presets): the lean iteration body
     const bool lean = C.specialization == SOLVER_ICE && L.solver == CF_SOLVER_TABLES;
+    if (tail) {
+        // tail workgroups behind the interface solve's (lean iteration, narrow geometry): the next step's interpolation and / or
+        // this step's face stresses
+        if (!lean || L.ao_wide) return hipErrorInvalidValue;
+        A.n_chunks = L.n_chunks;
+        if (tail->next_out) {
+            if (!tail->next_src || !tail->w || L.interp_cap <= 0 || tail->interp_blocks <= 0 ||
+                (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double) > (size_t)Geom<AO_BLOCK>::LDS_BYTES)
+                return hipErrorInvalidValue;
+            A.Si = make_source(tail->next_src);
+            A.Wi = make_weights(tail->w);
+            A.E_next = make_exchange(tail->next_out);
+            A.tail_blocks = tail->interp_blocks;
+            A.tail_rows = tail->interp_rows;
+            A.tail_cap = L.interp_cap;
+        }
+        if (tail->stress_net) {
+            if (!tail->d_ocean_params || !tail->stress_ocean || !tail->stress_fluxes) return hipErrorInvalidValue;
+            A.stress_blocks = (G.nx * G.ny + 255) / 256;
+            A.stress_params = tail->d_ocean_params;
+            A.stress_mask = tail->stress_ocean->mask;
+            A.rtx = tail->stress_fluxes->x_momentum;
+            A.rty = tail->stress_fluxes->y_momentum;
+            if (tail->stress_ice)
+                A.stress_ice = IceIn{tail->stress_ice->concentration, tail->stress_ice->interface_heat, tail->stress_ice->salt_flux,
+                                     tail->stress_ice->x_stress, tail->stress_ice->y_stress, nullptr};
+            A.tau_x = tail->stress_net->u;
+            A.tau_y = tail->stress_net->v;
+        }
+        const dim3 tgrid((unsigned)(L.n_chunks + A.tail_blocks + A.stress_blocks));
+        if (coare) hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE_LEAN, false, AO_BLOCK, true>), tgrid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, st, A);
+        else hipLaunchKernelGGL((ao_flux_fast_kernel<false, SOLVER_SEAICE_LEAN, false, AO_BLOCK, true>), tgrid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, st, A);
+        return hipGetLastError();
+    }
 #define CF_AI_LAUNCH(COARE_, SPEC_, BLOCK_) \
     hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, false, BLOCK_>), grid, dim3(BLOCK_), Geom<BLOCK_>::LDS_BYTES, st, A)
     if (L.ao_wide) {

@@ -76,6 +76,16 @@ struct SolverArgs {
     WeightDesc Wi;
     Exchange E_next;
     long long n_chunks, tail_blocks, tail_rows, tail_cap;
+    // … and / or the face stresses of the CURRENT step (the sea-ice interface launch: they need the ocean solver's ρτ, which
+    // the previous launch wrote): workgroups behind the interpolation's, 256 cells each
+    long long stress_blocks;
+    const DevParams* stress_params;   // the OCEAN formulation's parameter block (ρₒ, mask kind)
+    const void* stress_mask;
+    const double* rtx;
+    const double* rty;
+    IceIn stress_ice;
+    double* tau_x;
+    double* tau_y;
 };
 typedef const SolverArgs __attribute__((address_space(4)))* SolverArgsPtr;
 

@@ -341,3 +341,43 @@ def test_bench_n_rank_code_path_rehearsal():
     assert line["n_gpus"] == 2 and line["steps"] == 40 and "rehearsal" in line
     assert line["config"]["halo_verified"] == ["peer"] and line["config"]["rows_per_rank"] == 60
     assert line["value"] > 0 and line["config"]["step_loop"].startswith("cf_time_steps")
+
+
+def test_sea_ice_step_with_tail_workgroups_is_bitwise_the_plain_step():
+    """cf_update_state_sea_ice with CF_OPT_MERGED_PREFETCH = 2: this step's face stresses and the requested next-step
+    interpolation ride in the tail workgroups of the sea-ice interface launch.  Same bits as the plain sequence in every
+    output — exchange fields, ocean interface and net fluxes (incl. the stresses), sea-ice interface fluxes and skin
+    temperature, top / bottom heat — over a host loop that crosses a snapshot boundary."""
+    n, n_levels = 12, 4
+    results = []
+    for tail in (False, True):
+        ctx, states, src, w, (o0, _) = _setup(n_levels=n_levels)
+        ctx.set_sea_ice_formulation(ic.flux_params(ic.corrected_atmosphere_sea_ice_fluxes()))
+        si = syn.sea_ice_state(NX, NY, H, H)
+        ice = {k: ctx.to_device(o0["ice_" + k]) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")}
+        ice_state = dict(concentration=ice["concentration"], **{k: ctx.to_device(si[k]) for k in ("thickness", "top_temperature", "u", "v", "albedo")})
+        sets = [ctx.field_set(EXCHANGE_NAMES) for _ in range(2)]
+        fl, net, ai = ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES), ctx.field_set(FLUX_NAMES)
+        net_ice = ctx.field_set(("top_heat", "bottom_heat"))
+        ai["temperature"].copy_(ice_state["top_temperature"])
+        ice_state["top_temperature"] = ai["temperature"]      # the skin temperature is carried from step to step
+        if tail:
+            ctx.set_option(abi.OPT_MERGED_PREFETCH, 2)
+        for s in range(n):
+            tot = s * INC
+            l1 = int(tot) % n_levels
+            if tail:
+                nxt = (s + 1) * INC
+                l1n = int(nxt) % n_levels
+                ctx.prefetch_atmosphere_state(src, w, sets[(s + 1) % 2], level1=l1n, level2=(l1n + 1) % n_levels, time_fraction=nxt - int(nxt))
+            ctx.update_state_sea_ice(src, w, states[s % 2], sets[s % 2], fl, net, ice, ice_state, ai, net_ice,
+                                     level1=l1, level2=(l1 + 1) % n_levels, time_fraction=tot - int(tot))
+        ctx.sync()
+        out = {}
+        for name, d in (("atmos", sets[(n - 1) % 2]), ("fl", fl), ("net", net), ("ai", ai), ("net_ice", net_ice)):
+            for k, v in d.items():
+                out[f"{name}.{k}"] = v.clone()
+        results.append(out)
+        ctx.close()
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k
