@@ -97,6 +97,9 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
                             const GridDesc& G, const cf_sea_ice_state* ice, const cf_ocean_surface* o,
                             const cf_exchange_fields* e, const cf_interface_fluxes* f, const double* d_tables,
                             const DevParams* d_params, uint8_t* d_trip, const AiTail* tail = nullptr);
+// build_chunk_table / cf_debug_chunk_plan: `wet_per_chunk` = AO_PLAN_TAIL asks for the automatic plan of a launch that carries
+// tail workgroups (CF_OPT_MERGED_PREFETCH = 2)
+constexpr int AO_PLAN_TAIL = -2;
 hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
                              int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
                              int* nchunks_out, int* wide_out);

@@ -182,6 +182,8 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
         return cost_units <= 0 ? 0L : (cost_units + (long)w * AO_WET_COST - 1) / ((long)w * AO_WET_COST);
     };
     const long need = total > 0 ? total : 1;
+    const bool tail_plan = forced_wet_per_chunk == AO_PLAN_TAIL;
+    if (tail_plan) forced_wet_per_chunk = 0;
     if (forced_wet_per_chunk == AO_PLAN_WIDE) {
         // one workgroup per CU and round: chunks of equal cost, whole batches, as few rounds as the list capacity allows
         const long per_round = cap(AO_CHUNK_WIDE);
@@ -204,6 +206,15 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
         // 1024s for everything before the last two layers (none on a surface that fits three layers), then as
         // many 768s as still needed, then 512s
         int W1 = AO_LAYER_1, W2 = AO_LAYER_2, W3 = AO_LAYER_3;
+        // A launch with tail workgroups WANTS its solver workgroups to retire at different times — every slot freed early is
+        // taken by the memory-bound riders — so on a surface that fits one dispatch generation the three arrivals get EQUAL
+        // chunks (the first retires at ≈ 60 % of the kernel, see above): same box, step with the tail, 1024/768/512 vs
+        // 768/768/768: `:corrected` 80.0–80.7 → 75.8–77.1 µs, `:ncar` 60.7–64.6 → 60.8–60.9, `:default` 86.3–87.9 → 85.8–87.9
+        // (profiles/r04_tail_layers*.log).  Only where the surface needs all three layers: larger surfaces stagger themselves,
+        // smaller ones want the smaller workgroups of the plan below (a 3/4 surface: 80.9 µs per step with equal chunks,
+        // 72.4 with the layers; a half surface 64.8 vs 55.4).
+        if (tail_plan && need > cap(AO_LAYER_1) + cap(AO_LAYER_2) && need <= cap(AO_LAYER_1) + cap(AO_LAYER_2) + cap(AO_LAYER_3))
+            W1 = W2 = W3 = AO_LAYER_2;
         if (const char* env = experiment_knob("COFLUX_LAYERS")) {  // experiments only (with COFLUX_EXPERIMENTS=1): "w1,w2,w3" (multiples of 64, w1 ≥ w2 ≥ w3, w1 ≤ AO_CHUNK)
             int a = 0, b = 0, c = 0;
             if (std::sscanf(env, "%d,%d,%d", &a, &b, &c) == 3 && a <= AO_CHUNK && a >= b && b >= c && c >= 64 && a % 64 == 0 && b % 64 == 0 && c % 64 == 0) {
@@ -243,7 +254,7 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
     // workgroups of different age on a CU stagger themselves — the oldest iterates while the youngest loads — and
     // twelve waves of one age do not.  It stays as an option because it leaves ≈ 100 KB of the CU's LDS unused.
     const bool wide = wet_per_chunk == AO_CHUNK_WIDE;
-    const int largest = plan_chunk_rounds(total, cu_count, wide ? AO_PLAN_WIDE : wet_per_chunk, &R);
+    const int largest = plan_chunk_rounds(total, cu_count, wide ? AO_PLAN_WIDE : wet_per_chunk, &R);  // (AO_PLAN_TAIL passes through)
     wet_per_chunk = largest;
     *wide_out = wide ? 1 : 0;
     hipLaunchKernelGGL(chunk_begins_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums, R, d_begins,
