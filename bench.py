@@ -568,13 +568,13 @@ def main():
         # strong-scaling projection from single-GPU measurements of one rank's slab (scratch/slab_curve.py): a PROJECTION,
         # labelled as such — the driver computes the real curve from its own N-GPU runs
         try:
-            sc = json.load(open(os.path.join(ROOT, "profiles", "r04b_slab_curve.json")))
+            sc = json.load(open(os.path.join(ROOT, "profiles", "r04d_slab_curve.json")))
             if canonical and world == 1:
                 out["projected_scaling"] = dict(
                     kind="projection from one GPU, not a multi-GPU measurement",
                     speedup_before_halo_rows={k: round(v, 3) for k, v in sc["projected_speedup_before_halos"].items()},
                     slab_ms_per_step={k: round(v["ms_per_step"], 5) for k, v in sc["slabs"].items()},
-                    source="committed: profiles/r04b_slab_curve.json (python bench.py --ny 560/280/140/70 on one MI355X)",
+                    source="committed: profiles/r04d_slab_curve.json (python bench.py --ny 560/280/140/70 on one MI355X)",
                     note=sc["note"])
         except Exception:
             pass
