@@ -358,7 +358,13 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * dominate (a latitude slab of a strongly scaled run); needs the fused net fluxes and the tiled
                                    * interpolation.  0 (default): auxiliary stream.
                                    * 2: the requested interpolation becomes extra workgroups BEHIND the solver's in the solver launch
-                                   * (round-3 ocean kernel): they take the slots the solver's workgroups free as they retire.       */
+                                   * (round-3 ocean kernel and the CoefficientBasedFluxes kernel): they take the slots the solver's
+                                   * workgroups free as they retire; with a sea-ice formulation (cf_update_state_sea_ice) the riders —
+                                   * the interpolation and the current step's face stresses — sit in the interface solve's launch.
+                                   * A context in this mode cuts its solver chunks for it (equal chunks per CU where the surface fills
+                                   * one dispatch generation, so that workgroups retire staggered): meant for stepping loops that
+                                   * request every next state; a lone cf_update_state without a request runs ≈ 5 µs slower on that
+                                   * plan than on the default one.  Results are the same bits in every mode.                          */
 #define CF_OPT_ICE_ORBIT_SHORTCUT 7 /* 1 (default): the atmosphere–sea-ice iteration stops as soon as its state repeats the state of two
                                      iterations ago bit for bit — an exact period-2 orbit, where the skin-temperature balance does not
                                      contract — and returns the iterate the remaining steps up to maxiter would end on (the same
