@@ -411,6 +411,7 @@ class ComponentInterfaces:
         self.weights = grid.interpolation_weights(ctx.to_device)
         self.fold_north = bool(getattr(grid, "fold_north", False))
         self.exchange_atmosphere_state = ctx.field_set(EXCHANGE_NAMES)
+        self._exchange_other = None   # second set of exchange fields: run!(simulation) requests every next state into it
         fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL if store_similarity_scales else ())
         self.atmosphere_ocean_interface = SimpleNamespace(fluxes=SimpleNamespace(**fluxes), _fields=fluxes)
         bc = ocean.model.top_boundary_conditions
@@ -549,6 +550,21 @@ def update_state(model):
                                                  si.x_stress, si.y_stress, f)
         si.interface_heat, si.salt_flux, si.frazil_heat = f["interface_heat"], f["salt_flux"], f["frazil_heat"]
     ice = model.sea_ice.fields() if model.sea_ice is not None else None
+    # Inside run!(simulation) the clock is known one step ahead: the NEXT step's atmosphere state is requested into the other
+    # set of exchange fields and rides in this step's solver launch (CF_OPT_MERGED_PREFETCH = 2: tail workgroups; the same
+    # bits as interpolating it when its step comes).  A sliding window needs a third slot for that: the request makes the
+    # next bracketing snapshots resident while this step may still read the current ones.
+    if getattr(itf, "_next_state_in_other", False):   # requested by the previous step: this step's state is in the other set
+        itf.exchange_atmosphere_state, itf._exchange_other = itf._exchange_other, itf.exchange_atmosphere_state
+        itf._next_state_in_other = False
+    dt_next = getattr(model, "_pipeline_dt", None)
+    pipelined = dt_next is not None and (atm.provider is None or atm.n_slots >= 3)
+    if pipelined:
+        if itf._exchange_other is None:
+            itf._exchange_other = itf.context.field_set(EXCHANGE_NAMES)
+            itf.context.set_option(abi.OPT_MERGED_PREFETCH, 2)
+        src_n, n1n, n2n, frac_n = atm.source(itf.context, model.clock.time + dt_next)
+        itf.context.prefetch_atmosphere_state(src_n, itf.weights, itf._exchange_other, level1=n1n, level2=n2n, time_fraction=frac_n)
     if itf.atmosphere_sea_ice_interface is not None:
         # the ocean path, then compute_atmosphere_sea_ice_fluxes! + compute_net_sea_ice_fluxes! in one ABI call; the
         # skin temperature found by the iteration becomes the sea ice's top surface temperature (and the next step's
@@ -560,10 +576,12 @@ def update_state(model):
                                          frazil_heat=si.frazil_heat, interface_heat=si.interface_heat,
                                          level1=n1, level2=n2, time_fraction=frac)
         si.top_surface_temperature.copy_(ai["temperature"])
-        return
-    itf.context.update_state(src, itf.weights, model.ocean.surface_state(), itf.exchange_atmosphere_state,
-                             itf.atmosphere_ocean_interface._fields, itf.net_fluxes._ocean_fields, ice=ice,
-                             level1=n1, level2=n2, time_fraction=frac)
+    else:
+        itf.context.update_state(src, itf.weights, model.ocean.surface_state(), itf.exchange_atmosphere_state,
+                                 itf.atmosphere_ocean_interface._fields, itf.net_fluxes._ocean_fields, ice=ice,
+                                 level1=n1, level2=n2, time_fraction=frac)
+    itf._next_state_in_other = pipelined   # (the next update_state! swaps the sets first: until then
+                                           #  `exchange_atmosphere_state` is the state at the model's clock)
 
 
 def time_step(model, dt):
@@ -585,8 +603,12 @@ class Simulation:
 def run(simulation):
     """run!(simulation) — README.md:77."""
     m = simulation.model
-    while m.clock.time < simulation.stop_time and m.clock.iteration < simulation.stop_iteration:
-        time_step(m, simulation.dt)
+    m._pipeline_dt = simulation.dt   # (update_state requests every next atmosphere state: see there)
+    try:
+        while m.clock.time < simulation.stop_time and m.clock.iteration < simulation.stop_iteration:
+            time_step(m, simulation.dt)
+    finally:
+        m._pipeline_dt = None
     m.interfaces.context.sync()
 
 

@@ -64,6 +64,39 @@ def test_readme_recipe_config1_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_run_requests_every_next_state_and_gives_the_bits_of_the_plain_loop():
+    """run!(simulation) knows the clock one step ahead: update_state! requests the next atmosphere state with every step
+    (it rides in the solver launch's tail workgroups, CF_OPT_MERGED_PREFETCH = 2, through a second set of exchange fields).
+    Same bits as time_step! called in a plain loop — net fluxes, interface fluxes and the exchange state itself —
+    across a snapshot boundary."""
+    import torch
+    nx, ny, nz, h = 90, 40, 10, 3
+    grid = cm.LatitudeLongitudeGrid(size=(nx, ny, nz), halo=(h, h, h), latitude=(-70, 70), z=(-3000, 0))
+    state = syn.ocean_state(nx, ny, h, h)
+    snaps = syn.jra55_snapshots(4)
+    got = []
+    for piped in (True, False):
+        ocean = cm.ocean_simulation(grid)
+        cm.set_surface(ocean, T=state["T"], S=state["S"], u=state["u"], v=state["v"], mask=state["mask"])
+        coupled = cm.OceanSeaIceModel(ocean, atmosphere=cm.JRA55PrescribedAtmosphere(snaps))
+        if piped:
+            cm.run(cm.Simulation(coupled, dt=50 * cm.minutes, stop_iteration=9))
+            assert coupled.interfaces._exchange_other is not None
+        else:
+            for _ in range(9):
+                cm.time_step(coupled, 50 * cm.minutes)
+            coupled.interfaces.context.sync()
+            assert coupled.interfaces._exchange_other is None
+        bc = ocean.model.top_boundary_conditions
+        fields = dict(u=bc.u, v=bc.v, T=bc.T, S=bc.S, Qc=coupled.interfaces.atmosphere_ocean_interface.fluxes.sensible_heat,
+                      **{"atmos_" + k: v for k, v in coupled.interfaces.exchange_atmosphere_state.items()})
+        got.append({k: v.clone() for k, v in fields.items()})
+        coupled.interfaces.context.close()
+    for k in got[0]:
+        assert torch.equal(got[0][k], got[1][k]), k
+
+
+@pytest.mark.gpu
 def test_config3_sea_ice_coupling_through_the_model_api():
     """BASELINE config 3: OceanSeaIceModel(ocean, sea_ice; atmosphere) with the :corrected interfaces
     (omip_simulation.jl:139-147).  Ocean partition with the ice-concentration mask, atmosphere–sea-ice interface
