@@ -1158,7 +1158,8 @@ int cf_compute_sea_ice_ocean_fluxes(cf_ctx* ctx, const cf_ice_ocean_params* para
 }
 
 static int atmosphere_sea_ice_fluxes_impl(cf_ctx* ctx, const cf_sea_ice_state* ice_in, const cf_ocean_surface* ocean,
-                                          const cf_exchange_fields* atmos, const cf_interface_fluxes* out, const AiTail* tail) {
+                                          const cf_exchange_fields* atmos, const cf_interface_fluxes* out, const AiTail* tail,
+                                          const NetIceOut* net_ice = nullptr) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
@@ -1174,7 +1175,7 @@ static int atmosphere_sea_ice_fluxes_impl(cf_ctx* ctx, const cf_sea_ice_state* i
     CHECK(wait_for_halos(ctx));
     CHECK(ensure_chunk_table(ctx, ocean->mask));
     HIP_TRY(ctx, launch_ai_fluxes(ctx->stream, ctx->launch, ctx->ice_dev, ctx->ice_loop, ctx->ice_kernel, ctx->grid, ice, ocean,
-                                  atmos, out, ctx->d_ice_tables, ctx->d_ice_params, ctx->trip_hints ? ctx->d_trip_ice : nullptr, tail));
+                                  atmos, out, ctx->d_ice_tables, ctx->d_ice_params, ctx->trip_hints ? ctx->d_trip_ice : nullptr, tail, net_ice));
     return CF_OK;
 }
 
@@ -1239,12 +1240,19 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
         }
     }
     const bool any_tail = stress_held || interp_rides;
-    CHECK(atmosphere_sea_ice_fluxes_impl(ctx, ice_state, ocean, atmos, ai_fluxes, any_tail ? &T : nullptr));
+    // … and compute_net_sea_ice_fluxes! is pointwise on the interface solve's own outputs: in its epilogue (same function, same
+    // bits as net_sea_ice_flux_kernel) instead of an 8 µs launch behind it
+    const bool net_in_epilogue = ice_tail && ice_state && ice_state->concentration && net_ice && net_ice->top_heat && net_ice->bottom_heat &&
+                                 ai_fluxes && ai_fluxes->sensible_heat && ai_fluxes->latent_heat && ai_fluxes->temperature;
+    const NetIceOut NI{net_in_epilogue ? ice_state->concentration : nullptr, frazil_heat, interface_heat,
+                       net_in_epilogue ? net_ice->top_heat : nullptr, net_in_epilogue ? net_ice->bottom_heat : nullptr};
+    CHECK(atmosphere_sea_ice_fluxes_impl(ctx, ice_state, ocean, atmos, ai_fluxes, any_tail ? &T : nullptr, net_in_epilogue ? &NI : nullptr));
     if (interp_rides) CHECK(deferred_went_out_on_main(ctx));
     if (ice_tail && ctx->deferred.valid && ctx->deferred.out.u != atmos->u) {   // (no tiled interpolation configured: a launch of its own)
         HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out));
         CHECK(deferred_went_out_on_main(ctx));
     }
+    if (net_in_epilogue) return CF_OK;
     return cf_compute_net_sea_ice_fluxes(ctx, ice_state, ocean, atmos, ai_fluxes, frazil_heat, interface_heat, net_ice);
 }
 

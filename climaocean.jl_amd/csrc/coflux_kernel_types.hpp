@@ -73,6 +73,14 @@ struct IceStateIn {   // sea_ice.model fields the atmosphere–sea-ice interface
     const double* albedo;
 };
 
+struct NetIceOut {   // compute_net_sea_ice_fluxes! inside the interface solve's epilogue (all null: a launch of its own)
+    const double* conc;
+    const double* frazil;
+    const double* interface_heat;
+    double* top;
+    double* bottom;
+};
+
 struct NetOut {
     double* u;
     double* v;
@@ -208,6 +216,19 @@ __device__ __forceinline__ double net_face_stress(const DevParams& P, double rho
     const double tao = 0.5 * (rho_tau_a + rho_tau_b) * P.rho_o_inv;
     const double a = 0.5 * (aice_a + aice_b);
     return (1.0 - a) * tao + a * tau_io;
+}
+
+// compute_net_sea_ice_fluxes! of one wet interior cell: heat into the ice top (where there is ice) and into its bottom.
+// One function, contraction off: net_sea_ice_flux_kernel and the interface solve's epilogue give the same bits.
+__device__ __forceinline__ void net_sea_ice_cell(double albedo, double emissivity, double eps_sigma, double T_offset, double Qs, double Ql,
+                                                 double Ts_celsius, double Qc, double Qv, double conc, double Qf, double Qi, double& top,
+                                                 double& bottom) {
+#pragma clang fp contract(off)
+    const double T = Ts_celsius + T_offset, T2 = T * T;
+    const double Qu = eps_sigma * T2 * T2;
+    const double Qd = -(1.0 - albedo) * Qs - emissivity * Ql;
+    top = conc > 0.0 ? (Qd + Qu + Qc + Qv) : 0.0;
+    bottom = Qf + Qi;
 }
 
 __device__ __forceinline__ void store_net_cell(const NetOut& N, size_t k, const NetCell& C) {

@@ -96,7 +96,7 @@ struct AiTail {
 hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const IceParams& I,
                             const GridDesc& G, const cf_sea_ice_state* ice, const cf_ocean_surface* o,
                             const cf_exchange_fields* e, const cf_interface_fluxes* f, const double* d_tables,
-                            const DevParams* d_params, uint8_t* d_trip, const AiTail* tail = nullptr);
+                            const DevParams* d_params, uint8_t* d_trip, const AiTail* tail = nullptr, const NetIceOut* net_ice = nullptr);
 // build_chunk_table / cf_debug_chunk_plan: `wet_per_chunk` = AO_PLAN_TAIL asks for the automatic plan of a launch that carries
 // tail workgroups (CF_OPT_MERGED_PREFETCH = 2)
 constexpr int AO_PLAN_TAIL = -2;

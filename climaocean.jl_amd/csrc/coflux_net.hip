@@ -123,12 +123,8 @@ __global__ __launch_bounds__(NET_BLOCK) void net_sea_ice_flux_kernel(DevParams P
     const size_t k = cell_index(G, idx - j * G.nx, j);
     double sum_top = 0.0, sum_bottom = 0.0;
     if (cell_is_wet(P, mask, k)) {
-        const double alb = albedo_field ? albedo_field[k] : albedo;
-        const double T = Ts[k] + T_offset, T2 = T * T;
-        const double Qu = eps_sigma * T2 * T2;
-        const double Qd = -(1.0 - alb) * Qs[k] - emissivity * Ql[k];
-        sum_top = conc[k] > 0.0 ? (Qd + Qu + Qc[k] + Qv[k]) : 0.0;
-        sum_bottom = (Qf ? Qf[k] : 0.0) + (Qi ? Qi[k] : 0.0);
+        net_sea_ice_cell(albedo_field ? albedo_field[k] : albedo, emissivity, eps_sigma, T_offset, Qs[k], Ql[k], Ts[k], Qc[k], Qv[k], conc[k],
+                         Qf ? Qf[k] : 0.0, Qi ? Qi[k] : 0.0, sum_top, sum_bottom);
     }
     top[k] = sum_top;
     bottom[k] = sum_bottom;

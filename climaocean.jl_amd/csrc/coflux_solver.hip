@@ -333,6 +333,15 @@ size_t wet_list_capacity(int ncells) { return (size_t)chunk_table_capacity(ncell
 // LDS, tables included, is 39 KB each; everything else keeps three)
 // TAIL: workgroups behind the chunk table's interpolate the NEXT step's atmosphere state (see ao_lean_kernel; instantiated for
 // CoefficientBasedFluxes with the fused net fluxes, the OMIP-2 standard configuration)
+// land interior cell of the sea-ice interface launch with the net sea-ice fluxes in its epilogue: no heat either way
+__device__ __forceinline__ void ice_zero_net(SolverArgsPtr K, const GridDesc& G, size_t k, int i, int j) {
+    double* top = K->NI.top;
+    if (top && i >= 0 && i < G.nx && j >= 0 && j < G.ny) {
+        top[k] = 0.0;
+        K->NI.bottom[k] = 0.0;
+    }
+}
+
 template <bool COARE, int SPEC, bool FUSE_NET, int BLOCK, bool TAIL = false>
 __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BLOCK) ? CF_LEAN_WAVES : 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
     constexpr int CHUNK = Geom<BLOCK>::CHUNK;
@@ -530,6 +539,7 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
                 const FluxOut F = kread(&Kz->F);
                 const NetOut N = kread(&Kz->N);
                 zero_cell<FUSE_NET>(L, T_offset, G, F, N, k, i, j);
+                        if constexpr (SPEC == SOLVER_SEAICE || SPEC == SOLVER_SEAICE_LEAN) ice_zero_net(opaque(K), G, k, i, j);
             }
         }
         for (int d = 32; d; d >>= 1) {
@@ -577,6 +587,7 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
                         const int jj = row_of(idx, wx, wx_rcp);
                         const int i = idx - jj * wx - G.ring, j = jj - G.ring;
                         zero_cell<FUSE_NET>(L, T_offset, G, F, N, cell_index(G, i, j), i, j);
+                        if constexpr (SPEC == SOLVER_SEAICE || SPEC == SOLVER_SEAICE_LEAN) ice_zero_net(opaque(K), G, cell_index(G, i, j), i, j);
                     }
             }
         } else {  // stale list: redo the range the slow way
@@ -607,6 +618,7 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
                         const FluxOut F = kread(&Kz->F);
                         const NetOut N = kread(&Kz->N);
                         zero_cell<FUSE_NET>(L, T_offset, G, F, N, k, i, j);
+                        if constexpr (SPEC == SOLVER_SEAICE || SPEC == SOLVER_SEAICE_LEAN) ice_zero_net(opaque(K), G, k, i, j);
                     }
                 }
                 const unsigned long long m = __ballot(wet);
@@ -722,6 +734,19 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
                     R.iterations = s.it;
                     const FluxOut F = kread(&Ke->F);
                     store_fluxes(F, k, R);
+                    {   // compute_net_sea_ice_fluxes! of the cell (interior only), when the launch carries it
+                        const NetIceOut NI = kread(&Ke->NI);
+                        const int ci = idx2 - jj2 * wx - G.ring, cj = jj2 - G.ring;
+                        if (NI.top && ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {
+                            const IceStateIn S2 = kread(&Ke->S);
+                            double top, bottom;
+                            net_sea_ice_cell(S2.albedo ? S2.albedo[k] : Ice.albedo, Ice.emissivity, Ice.eps_sigma, Ice.T_offset, Ke->E.Qs[k],
+                                             Ke->E.Ql[k], R.Ts_ocean, R.Qc, R.Qv, NI.conc[k], NI.frazil ? NI.frazil[k] : 0.0,
+                                             NI.interface_heat ? NI.interface_heat[k] : 0.0, top, bottom);
+                            NI.top[k] = top;
+                            NI.bottom[k] = bottom;
+                        }
+                    }
                     if (use_static && W.trip) store_hint(&W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)], s.work);
                 }
                 continue;
@@ -968,7 +993,7 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
 hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const IceParams& Ice,
                             const GridDesc& G, const cf_sea_ice_state* ice, const cf_ocean_surface* o,
                             const cf_exchange_fields* e, const cf_interface_fluxes* f, const double* d_tables,
-                            const DevParams* d_params, uint8_t* d_trip, const AiTail* tail) {
+                            const DevParams* d_params, uint8_t* d_trip, const AiTail* tail, const NetIceOut* net_ice) {
     if (!L.d_chunk_begins || L.n_chunks <= 0) return hipErrorInvalidValue;
     SolverArgs A{};
     A.L = C;
@@ -990,6 +1015,7 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
     // constant roughness lengths and a gustiness floor (both production presets): the lean iteration body
     const bool lean = C.specialization == SOLVER_ICE && L.solver == CF_SOLVER_TABLES;
+    if (net_ice) A.NI = *net_ice;
     if (tail) {
         // tail workgroups behind the interface solve's (lean iteration, narrow geometry): the next step's interpolation and / or
         // this step's face stresses

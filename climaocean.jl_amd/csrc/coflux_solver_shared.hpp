@@ -86,6 +86,7 @@ struct SolverArgs {
     IceIn stress_ice;
     double* tau_x;
     double* tau_y;
+    NetIceOut NI;   // the sea-ice interface launch: compute_net_sea_ice_fluxes! in its epilogue
 };
 typedef const SolverArgs __attribute__((address_space(4)))* SolverArgsPtr;
 
