@@ -364,7 +364,12 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * A context in this mode cuts its solver chunks for it (equal chunks per CU where the surface fills
                                    * one dispatch generation, so that workgroups retire staggered): meant for stepping loops that
                                    * request every next state; a lone cf_update_state without a request runs ≈ 5 µs slower on that
-                                   * plan than on the default one.  Results are the same bits in every mode.                          */
+                                   * plan than on the default one.  Results are the same bits in every mode — with one aliasing caveat:
+                                   * in this mode cf_update_state_sea_ice computes compute_net_sea_ice_fluxes! in the interface solve's
+                                   * epilogue with the albedo that solve used; a caller that (a) uses the SeaIceAlbedo(hi, hs, Ts) scheme
+                                   * and (b) passes the SAME buffer as cf_sea_ice_state.top_temperature and as the interface
+                                   * temperature output gets, from the separate launches of the other modes, an albedo re-evaluated at
+                                   * the NEW skin temperature for the net fluxes.                                                    */
 #define CF_OPT_ICE_ORBIT_SHORTCUT 7 /* 1 (default): the atmosphere–sea-ice iteration stops as soon as its state repeats the state of two
                                      iterations ago bit for bit — an exact period-2 orbit, where the skin-temperature balance does not
                                      contract — and returns the iterate the remaining steps up to maxiter would end on (the same
