@@ -145,4 +145,4 @@ int cf_fail(cf_ctx* ctx, int code, const char* fmt, ...);
     } while (0)
 
 // coflux_abi.cpp: books ctx->deferred as launched on the main stream (see cf_update_state)
-extern "C" int deferred_went_out_on_main(cf_ctx* ctx);
+extern "C" __attribute__((visibility("hidden"))) int deferred_went_out_on_main(cf_ctx* ctx);
