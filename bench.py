@@ -55,12 +55,12 @@ def parse():
     ap.add_argument("--config", choices=("ocean", "sea_ice"), default="ocean",
                     help="ocean: BASELINE configs[1]; sea_ice: configs[2] (atmosphere–sea-ice interface + partition)")
     ap.add_argument("--pipeline", choices=("auto", "on", "off", "merged", "tail"), default="auto",
-                    help="interpolate the next step's atmosphere on the auxiliary stream during the solver; auto = off: "
-                         "measured slower at every slab size since the tiled kernel picks its rows per tile by size "
-                         "(1440x70: 0.0453 vs 0.0396 ms/step; 1440x560: 0.151 vs 0.121), and so is the same kernel gated "
-                         "behind the solver to run beside the net fluxes (0.133 / 0.060): a cross-stream dependency costs "
-                         "more than either kernel hides; merged = CF_OPT_MERGED_PREFETCH: the next step's interpolation inside this "
-                         "step's face-stress launch (two launches per step)")
+                    help="where the NEXT step's interpolate_atmosphere_state! runs (two sets of exchange fields).  tail = "
+                         "CF_OPT_MERGED_PREFETCH 2: tail workgroups of this step's solver launch (with sea ice: of the interface "
+                         "solve's, with this step's face stresses), 1440x560 0.0914 -> 0.0864 ms/step; merged = 1: inside this "
+                         "step's face-stress launch (-1 %); on = the auxiliary stream (measured slower: 0.119 vs 0.092); off = "
+                         "the un-pipelined three-launch step; auto = tail wherever the solver kernel can carry it (the round-3 "
+                         "ocean kernel, CoefficientBasedFluxes), else off")
     ap.add_argument("--net-diagnostics", action="store_true",
                     help="also write the three optional radiation diagnostics of cf_net_ocean_fluxes (24 B/cell beyond "
                          "the 88 + 40 B/cell contract of compute_net_ocean_fluxes!, SURVEY.md §8d)")
