@@ -58,7 +58,7 @@ def parse():
                     help="where the NEXT step's interpolate_atmosphere_state! runs (two sets of exchange fields).  tail = "
                          "CF_OPT_MERGED_PREFETCH 2: tail workgroups of this step's solver launch (with sea ice: of the interface "
                          "solve's, with this step's face stresses), 1440x560 0.0914 -> 0.0864 ms/step; merged = 1: inside this "
-                         "step's face-stress launch (-1 %); on = the auxiliary stream (measured slower: 0.119 vs 0.092); off = "
+                         "step's face-stress launch (-1 %%); on = the auxiliary stream (measured slower: 0.119 vs 0.092); off = "
                          "the un-pipelined three-launch step; auto = tail wherever the solver kernel can carry it (the round-3 "
                          "ocean kernel, CoefficientBasedFluxes), else off")
     ap.add_argument("--net-diagnostics", action="store_true",
