@@ -132,3 +132,16 @@ def test_solver_chunk_plan_covers_every_surface():
             assert all(n <= cus or w == 1024 for w, n in rounds[:-1]), (total, cus, rounds)
     rounds, _ = plan(10 ** 6, 256, forced=512)
     assert len(rounds) == 1 and rounds[0][0] == 512
+    # AO_PLAN_TAIL (-2): the plan of a launch that carries tail workgroups — three EQUAL chunks per CU exactly where the surface
+    # needs all three arrival layers (its workgroups then retire staggered); every other size keeps the automatic plan
+    full = 577498 * 64 + 232906
+    rounds, _ = plan(full, 256, forced=-2)
+    assert [w for w, _ in rounds] == [768, 768, 768] and sum(n for _, n in rounds) <= 3 * 256
+    for total in (full // 8, full // 2, full * 3 // 4, full * 3):
+        assert plan(total, 256, forced=-2)[0] == plan(total, 256)[0], total
+    for _ in range(500):
+        cus = rng.choice([8, 64, 256, 304])
+        total = rng.randrange(1, 2 * 10 ** 9)
+        rounds, unit = plan(total, cus, forced=-2)
+        covered = sum(w * unit * n for w, n in rounds)
+        assert rounds and all(n > 0 for _, n in rounds) and covered > total and covered - total <= max(w for w, _ in rounds) * unit + unit
