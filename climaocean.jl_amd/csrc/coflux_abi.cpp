@@ -1308,16 +1308,23 @@ int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int
     if (rows <= 0 || rows > G.hy || rows > G.ny) return fail(ctx, CF_ERR_INVALID, "rows = %d outside [1, min(hy, ny)]", rows);
     const size_t count = (size_t)rows * G.sj;  // whole rows, x-halos included
     const int south = ctx->rank - 1, north = ctx->rank + 1;
-    if (!ctx->comm_stream) {
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // Three-launch step: the rows travel on a communication stream beside the interpolation kernel, which does not read
+    // the ocean state.  With tail workgroups (CF_OPT_MERGED_PREFETCH = 2) the step has no such kernel — the solver launch
+    // that needs the rows comes next — and the two events each way would only be four queue packets (≈ 3 µs each,
+    // measured on the event this round removed from the step): the exchange goes onto the context's own stream.
+    const bool own_stream = ctx->merged_prefetch != 2;
+    if (own_stream && !ctx->comm_stream) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main_idle, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_comm_done, hipEventDisableTiming));
     }
-    // the rows may only be overwritten once everything already queued on the main stream has read them
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_main_idle, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_main_idle, 0));
-    hipStream_t cs = ctx->comm_stream;
+    hipStream_t cs = ctx->stream;
+    if (own_stream) {
+        // the rows may only be overwritten once everything already queued on the main stream has read them
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_main_idle, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_main_idle, 0));
+        cs = ctx->comm_stream;
+    }
     NCCL_TRY(ctx, g_rccl.GroupStart());
     for (int f = 0; f < nfields; ++f) {
         double* base = d_fields[f];
@@ -1335,8 +1342,10 @@ int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int
         }
     }
     NCCL_TRY(ctx, g_rccl.GroupEnd());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_done, cs));
-    ctx->comm_pending = true;  // consumed by the next ocean-reading launch (or cf_sync)
+    if (own_stream) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_done, cs));
+        ctx->comm_pending = true;  // consumed by the next ocean-reading launch (or cf_sync)
+    }
     return CF_OK;
 }
 

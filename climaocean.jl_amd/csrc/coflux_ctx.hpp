@@ -107,6 +107,8 @@ struct cf_ctx {
     // that the solver's workgroups are dispatched first and the interpolation only fills what they leave free
     struct Deferred {
         bool valid = false;
+        bool gated = false;  // ev_aux_gate was recorded when the request was made (not with merged_prefetch: the request
+                             // normally leaves on the main stream, where stream order gates it; a flush records it late)
         cf_atmos_source src{};
         cf_interp_weights w{};
         cf_exchange_fields out{};

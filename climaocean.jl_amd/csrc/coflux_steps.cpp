@@ -33,6 +33,8 @@ int cf_launch_prefetch(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_
         for (auto& p : ctx->prefetch)
             if (!p.valid) rec = &p;
     if (!rec) return fail(ctx, CF_ERR_INVALID, "two prefetched atmosphere states are already pending");
+    if (!ctx->deferred.gated) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux_gate, ctx->stream));  // (a later gate than needed: still ordered)
+    ctx->deferred.gated = false;
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_aux_gate, 0));
     // the LDS-free gather kernel (≤ 56 VGPRs, no LDS): it is resident BESIDE the solver's workgroups, which fill
     // the CU's LDS and 456 of 512 registers per SIMD; the tiled kernel would wait for them to retire
@@ -81,8 +83,11 @@ static int request_prefetch(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
     CHECK(ensure_aux_stream(ctx));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     CHECK(cf_flush_deferred_prefetch(ctx));  // at most one request waits for a solver launch
-    // the set written was last read by kernels already queued on the main stream: everything queued so far gates it
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_aux_gate, ctx->stream));
+    // the set written was last read by kernels already queued on the main stream: everything queued so far gates it.
+    // With CF_OPT_MERGED_PREFETCH the request leaves inside a main-stream launch (stream order is the gate) and an event
+    // per step would only put a barrier packet into the queue; the rare flush to the auxiliary stream records it then.
+    ctx->deferred.gated = !(defer && ctx->merged_prefetch != 0);
+    if (ctx->deferred.gated) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux_gate, ctx->stream));
     if (!defer) return cf_launch_prefetch(ctx, src, w, out);
     ctx->deferred.src = *src;
     ctx->deferred.w = *w;

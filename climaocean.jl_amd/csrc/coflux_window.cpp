@@ -15,6 +15,8 @@ struct cf_window {
     std::vector<hipEvent_t> ev_uploaded;    // per slot: its H2D copies have landed
     std::vector<int64_t> time_index;        // per slot: snapshot it holds, or INT64_MIN
     std::vector<char> in_flight;            // per slot: an upload was started and not yet waited for by the host
+    std::vector<char> ordered;              // per slot: `ordered_on` already waits for the slot's latest upload
+    hipStream_t ordered_on = nullptr;       // the compute stream those waits were queued on
 };
 
 extern "C" {
@@ -36,6 +38,7 @@ int cf_window_create(cf_ctx* ctx, int32_t ns_x, int32_t ns_y, int32_t n_slots, c
     w->plane = (size_t)ns_x * ns_y;
     w->time_index.assign(n_slots, INT64_MIN);
     w->in_flight.assign(n_slots, 0);
+    w->ordered.assign(n_slots, 0);
     w->ev_uploaded.assign(n_slots, nullptr);
     const size_t bytes = w->plane * n_slots * sizeof(float);
     bool ok = hipStreamCreateWithFlags(&w->copy_stream, hipStreamNonBlocking) == hipSuccess &&
@@ -97,6 +100,7 @@ int cf_window_commit(cf_window* w, int32_t slot, int64_t time_index) {
     HIP_TRY(ctx, hipEventRecord(w->ev_uploaded[slot], w->copy_stream));
     w->time_index[slot] = time_index;
     w->in_flight[slot] = 1;
+    w->ordered[slot] = 0;
     return CF_OK;
 }
 
@@ -127,8 +131,17 @@ int cf_window_source(cf_window* w, int64_t n1, int64_t n2, double time_fraction,
     if (!(time_fraction >= 0.0 && time_fraction <= 1.0))
         return fail(ctx, CF_ERR_INVALID, "time fraction %g outside [0, 1]", time_fraction);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, w->ev_uploaded[s1], 0));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, w->ev_uploaded[s2], 0));
+    // One wait per upload and stream: stream order carries it to everything queued behind (a wait on an event that has
+    // long fired still costs the queue a barrier packet — with two descriptors per step, +24 µs on an 86 µs step, measured)
+    if (w->ordered_on != ctx->stream) {
+        std::fill(w->ordered.begin(), w->ordered.end(), 0);
+        w->ordered_on = ctx->stream;
+    }
+    for (const int s : {s1, s2})
+        if (!w->ordered[s]) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, w->ev_uploaded[s], 0));
+            w->ordered[s] = 1;
+        }
     for (int v = 0; v < CF_JRA55_NVARS; ++v) out->data[v] = w->d_data[v];
     out->ns_x = w->ns_x;
     out->ns_y = w->ns_y;

@@ -52,6 +52,16 @@ def test_window_source_matches_oracle_and_reuses_slots():
     win.commit(1, 7)
     ctx.interpolate_atmosphere_state(win.source(7, 7, 0.0), w, atmos)
     assert np.max(np.abs(util.window(atmos["T"].cpu().numpy(), 3, 3, 90, 40, 1) - 300.0)) < 1e-10
+    # the compute stream waits for an upload ONCE (the first descriptor after the commit); a second commit of the same
+    # slot must be waited for again, however many descriptors of the old content were handed out in between
+    for value in (310.0, 320.0, 330.0):
+        for _ in range(3):
+            ctx.interpolate_atmosphere_state(win.source(7, 7, 0.0), w, atmos)
+        win.wait_slot(1)
+        view[...] = value
+        win.commit(1, 7)
+        ctx.interpolate_atmosphere_state(win.source(7, 7, 0.0), w, atmos)
+        assert np.max(np.abs(util.window(atmos["T"].cpu().numpy(), 3, 3, 90, 40, 1) - value)) < 1e-10
     win.close()
     ctx.close()
 
