@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--pipeline", choices=("auto", "on", "off", "merged", "tail"), default="auto",
                     help="where the NEXT step's interpolate_atmosphere_state! runs (two sets of exchange fields).  tail = "
                          "CF_OPT_MERGED_PREFETCH 2: tail workgroups of this step's solver launch (with sea ice: of the interface "
-                         "solve's, with this step's face stresses), 1440x560 0.0914 -> 0.0864 ms/step; merged = 1: inside this "
+                         "solve's, with this step's face stresses), 1440x560 0.0914 -> 0.0864 ms/step (0.0839 once the per-step event was gone); merged = 1: inside this "
                          "step's face-stress launch (-1 %%); on = the auxiliary stream (measured slower: 0.119 vs 0.092); off = "
                          "the un-pipelined three-launch step; auto = tail wherever the solver kernel can carry it (the round-3 "
                          "ocean kernel, CoefficientBasedFluxes), else off")
@@ -568,13 +568,13 @@ def main():
         # strong-scaling projection from single-GPU measurements of one rank's slab (scratch/slab_curve.py): a PROJECTION,
         # labelled as such — the driver computes the real curve from its own N-GPU runs
         try:
-            sc = json.load(open(os.path.join(ROOT, "profiles", "r04d_slab_curve.json")))
+            sc = json.load(open(os.path.join(ROOT, "profiles", "r04f_slab_curve.json")))
             if canonical and world == 1:
                 out["projected_scaling"] = dict(
                     kind="projection from one GPU, not a multi-GPU measurement",
                     speedup_before_halo_rows={k: round(v, 3) for k, v in sc["projected_speedup_before_halos"].items()},
                     slab_ms_per_step={k: round(v["ms_per_step"], 5) for k, v in sc["slabs"].items()},
-                    source="committed: profiles/r04d_slab_curve.json (python bench.py --ny 560/280/140/70 on one MI355X)",
+                    source="committed: profiles/r04f_slab_curve.json (python bench.py --ny 560/280/140/70 on one MI355X)",
                     note=sc["note"])
         except Exception:
             pass
