@@ -501,13 +501,26 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
         // list stale; the workgroup then redoes its range by classifying it — a stale list costs time, never
         // correctness).  The mask values were requested before the table DMA, so none of this waits for memory.
         unsigned hx = 0, hy = 0;
+        // No hint array (a fixed trip count: CoefficientBasedFluxes): the static list IS the order — it goes to LDS as it
+        // stands (wet entries first, index order), counted on the way; no histogram, no scan, no scatter, one barrier.
+        const bool unsorted = !W.trip;
+        int listed_here = 0;
 #pragma unroll
         for (int n = 0; n < PER_THREAD; ++n)
             if (my_idx[n] >= 0) {
-                atomicAdd(&hist[AO_BINS - 1 - trip_bin(my_trip[n])], 1);
+                if (unsorted) {
+                    list[tid + n * BLOCK] = ((unsigned)(tid + n * BLOCK) << AO_LIST_OFFSET_BITS) | (unsigned)(my_idx[n] - range_begin);
+                    ++listed_here;
+                } else {
+                    atomicAdd(&hist[AO_BINS - 1 - trip_bin(my_trip[n])], 1);
+                }
                 hx ^= cell_hash_lo((unsigned)my_idx[n]);
                 hy ^= cell_hash_hi((unsigned)my_idx[n]);
             }
+        if (unsorted) {
+            for (int d = 32; d; d >>= 1) listed_here += __shfl_xor(listed_here, d);
+            if (lane == 0) atomicAdd(&counters[0], listed_here);
+        }
         unsigned land = 0;  // bit n: strip n's cell is inside the range and dry — it gets its zeros after the last barrier
 #pragma unroll
         for (int n = 0; n < LAND_UNROLL; ++n) {
@@ -550,25 +563,27 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
             atomicXor(reinterpret_cast<unsigned*>(&counters[2]), hx);
             atomicXor(reinterpret_cast<unsigned*>(&counters[3]), hy);
         }
-        __syncthreads();
-        if (tid < 64) {  // exclusive scan of the AO_BINS (≤ 64) bin counts by one wave
-            const int v = lane < AO_BINS ? hist[lane] : 0;
-            int incl = v;
+        if (!unsorted) {
+            __syncthreads();
+            if (tid < 64) {  // exclusive scan of the AO_BINS (≤ 64) bin counts by one wave
+                const int v = lane < AO_BINS ? hist[lane] : 0;
+                int incl = v;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int up = __shfl_up(incl, d);
-                if (lane >= d) incl += up;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int up = __shfl_up(incl, d);
+                    if (lane >= d) incl += up;
+                }
+                if (lane < AO_BINS) bin_start[lane] = incl - v;
+                if (lane == 63) counters[0] = incl;
             }
-            if (lane < AO_BINS) bin_start[lane] = incl - v;
-            if (lane == 63) counters[0] = incl;
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < PER_THREAD; ++n)
+                if (my_idx[n] >= 0) {
+                    const int p = atomicAdd(&bin_start[AO_BINS - 1 - trip_bin(my_trip[n])], 1);
+                    list[p] = ((unsigned)(tid + n * BLOCK) << AO_LIST_OFFSET_BITS) | (unsigned)(my_idx[n] - range_begin);
+                }
         }
-        __syncthreads();
-#pragma unroll
-        for (int n = 0; n < PER_THREAD; ++n)
-            if (my_idx[n] >= 0) {
-                const int p = atomicAdd(&bin_start[AO_BINS - 1 - trip_bin(my_trip[n])], 1);
-                list[p] = ((unsigned)(tid + n * BLOCK) << AO_LIST_OFFSET_BITS) | (unsigned)(my_idx[n] - range_begin);
-            }
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the table DMA has landed
         __syncthreads();
         nwet = counters[0];
@@ -898,7 +913,9 @@ template <bool COARE, bool FUSE>
 static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const LoopParams& C, const GridDesc& G,
                            const OceanIn& O, const Exchange& E, const FluxOut& F, const IceIn& I, const NetOut& N,
                            double z_surface, long long mask_kind, double T_offset) {
-    const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip}, L.d_chunk_begins, I, N, IceStateIn{}, IceParams{},
+    // (CoefficientBasedFluxes runs a fixed trip count: no hint bytes to read, sort by or write back)
+    const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, C.specialization == SOLVER_LY ? nullptr : L.d_trip},
+                       L.d_chunk_begins, I, N, IceStateIn{}, IceParams{},
                        z_surface, mask_kind, T_offset, row_reciprocal(G.nx + 2 * G.ring)};
 #define CF_LAUNCH(COARE_, SPEC_)                                                                                                   \
     do {                                                                                                                          \
@@ -938,7 +955,7 @@ hipError_t launch_ly_fluxes_with_tail(hipStream_t st, const LaunchCfg& L, const 
     I.land = land;
     const NetOut N{net->u, net->v, net->T, net->S, net->shortwave_surface_flux, net->upwelling_longwave, net->downwelling_longwave,
                    net->downwelling_shortwave};
-    SolverArgs A{C, G, make_ocean(o), make_exchange(e), make_fluxes(f), L.d_tables, L.d_params, WetLists{L.d_wet_pos, L.d_trip},
+    SolverArgs A{C, G, make_ocean(o), make_exchange(e), make_fluxes(f), L.d_tables, L.d_params, WetLists{L.d_wet_pos, nullptr},
                  L.d_chunk_begins, I, N, IceStateIn{}, IceParams{}, P.z_surface, P.mask_kind, P.T_offset, row_reciprocal(G.nx + 2 * G.ring)};
     A.Si = make_source(next_src);
     A.Wi = make_weights(w);
