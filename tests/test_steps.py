@@ -89,6 +89,39 @@ def test_prefetch_mismatch_is_ignored_not_used():
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_request_flushed_by_sync_is_ordered_behind_the_readers_of_its_set(mode):
+    """A request that waits for a solver launch (cf_prefetch_atmosphere_state) and is flushed by cf_sync instead goes to the
+    auxiliary stream.  With CF_OPT_MERGED_PREFETCH its gate event is recorded at the flush, not at the request: the
+    interpolation must still run behind every kernel already queued that reads the set it overwrites, and the state it
+    leaves must be consumed as if it had been interpolated in its own step."""
+    ctx, states, src, w, _ = _setup()
+    ref = ctx.field_set(EXCHANGE_NAMES)
+    ctx.interpolate_atmosphere_state(src, w, ref, level1=1, level2=2, time_fraction=0.75)
+    rfl, rnet = ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+    ctx.update_state(src, w, states[1], ref, rfl, rnet, level1=1, level2=2, time_fraction=0.75)
+    ctx.sync()
+    ctx.set_option(abi.OPT_MERGED_PREFETCH, mode)
+    a, b = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(EXCHANGE_NAMES)
+    fl, net = ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+    for _ in range(3):   # work queued on the main stream that READS set b (the net fluxes read Qs, Ql, Mp)
+        ctx.update_state(src, w, states[0], b, fl, net, level1=0, level2=1, time_fraction=0.25)
+    want_fl = {k: v.clone() for k, v in fl.items()}
+    ctx.prefetch_atmosphere_state(src, w, b, level1=1, level2=2, time_fraction=0.75)   # overwrites b; no solver launch follows
+    ctx.sync()                                                                          # the flush
+    for k in FLUX_NAMES:   # the three queued steps saw the OLD contents of b
+        assert torch.equal(fl[k], want_fl[k]), k
+    for k in EXCHANGE_NAMES:
+        assert torch.equal(b[k], ref[k]), k
+    ctx.update_state(src, w, states[1], b, fl, net, level1=1, level2=2, time_fraction=0.75)   # consumes the pending state
+    ctx.sync()
+    for k in FLUX_NAMES:
+        assert torch.equal(fl[k], rfl[k]), k
+    for k in NET_NAMES:
+        assert torch.equal(net[k], rnet[k]), k
+    ctx.close()
+
+
 def _slab(rank, world, device=0):
     j0, j1 = slab_bounds(NY, rank, world)
     ctx, states, src, w, np_states = _setup(NX, j1 - j0, ny_global=NY, j_offset=j0, device=device)
