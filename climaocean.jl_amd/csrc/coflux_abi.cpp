@@ -751,7 +751,7 @@ int deferred_went_out_on_main(cf_ctx* ctx) {
 static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_interp_weights* w,
                              const cf_ocean_surface* ocean, const cf_exchange_fields* atmos,
                              const cf_interface_fluxes* fluxes, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net,
-                             bool hold_tail_work, bool* stress_held) {
+                             bool hold_tail_work, bool* stress_held, OceanRider* ocean_rider = nullptr) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
     CHECK(check_source(ctx, src));
@@ -793,7 +793,13 @@ static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_i
     const bool tail_ly = ctx->fast.specialization == SOLVER_LY && ctx->launch.solver == CF_SOLVER_TABLES;
     const bool tail = fuse && !fuse_interp && !hold_tail_work && ctx->merged_prefetch == 2 && ctx->deferred.valid &&
                       ctx->launch.interp_cap != 0 && ctx->deferred.out.u != atmos->u && !ctx->launch.ao_wide && (tail_lean || tail_ly);
-    if (tail) {
+    // With sea ice (cf_update_state_sea_ice): the ocean solve itself is handed to the caller, whose interface-solve launch carries
+    // its workgroups behind its own (ice_ocean_kernel) — the stresses then follow that launch
+    const bool ride = hold_tail_work && ocean_rider && fuse && !fuse_interp && tail_lean && !ctx->launch.ao_wide && !rec;
+    if (ride) {
+        HIP_TRY(ctx, make_ocean_rider(ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes, ice, net, ctx->d_land_freshwater,
+                                      ocean_rider));
+    } else if (tail) {
         int rows = 4, blocks = 1;
         interpolate_grid(ctx->launch, ctx->grid, &rows, &blocks);
         static const int tail_cap = [] {  // (experiments: COFLUX_EXPERIMENTS=1 COFLUX_TAIL_BLOCKS=n, read once)
@@ -1220,9 +1226,23 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
     const bool ice_tail = ctx->merged_prefetch == 2 && ctx->ice_loop.specialization == SOLVER_ICE &&
                           ctx->launch.solver == CF_SOLVER_TABLES && !ctx->launch.ao_wide;
     bool stress_held = false;
-    CHECK(update_state_impl(ctx, src, w, ocean, atmos, ao_fluxes, ice_partition, net, ice_tail, &stress_held));
+    // … and the ocean solve itself: its workgroups ride behind the interface solve's (both FP64-bound and independent of each
+    // other; two queues do not overlap them, one launch does — profiles/r04_experiments.md §17); the stresses, which need the
+    // ocean solve's ρτ everywhere, then get a launch of their own behind it
+    static const bool ocean_rides_allowed = [] {  // (experiments: COFLUX_EXPERIMENTS=1 COFLUX_OCEAN_RIDER=0 keeps the two solver launches)
+        const char* e = experiment_knob("COFLUX_OCEAN_RIDER");
+        return !(e && e[0] == '0');
+    }();
+    OceanRider rider;
+    CHECK(update_state_impl(ctx, src, w, ocean, atmos, ao_fluxes, ice_partition, net, ice_tail, &stress_held,
+                            ice_tail && ocean_rides_allowed ? &rider : nullptr));
     AiTail T{};
     bool interp_rides = false;
+    const bool stress_after = rider.valid && stress_held;
+    if (rider.valid) {
+        T.ocean = &rider;
+        stress_held = false;
+    }
     if (ice_tail) {
         if (stress_held) {
             T.d_ocean_params = ctx->launch.d_params;
@@ -1239,7 +1259,7 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
             interp_rides = true;
         }
     }
-    const bool any_tail = stress_held || interp_rides;
+    const bool any_tail = stress_held || interp_rides || rider.valid;
     // … and compute_net_sea_ice_fluxes! is pointwise on the interface solve's own outputs: in its epilogue (same function, same
     // bits as net_sea_ice_flux_kernel) instead of an 8 µs launch behind it
     const bool net_in_epilogue = ice_tail && ice_state && ice_state->concentration && net_ice && net_ice->top_heat && net_ice->bottom_heat &&
@@ -1247,6 +1267,7 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
     const NetIceOut NI{net_in_epilogue ? ice_state->concentration : nullptr, frazil_heat, interface_heat,
                        net_in_epilogue ? net_ice->top_heat : nullptr, net_in_epilogue ? net_ice->bottom_heat : nullptr};
     CHECK(atmosphere_sea_ice_fluxes_impl(ctx, ice_state, ocean, atmos, ai_fluxes, any_tail ? &T : nullptr, net_in_epilogue ? &NI : nullptr));
+    if (stress_after) HIP_TRY(ctx, launch_net_stress(ctx->stream, ctx->dev, ctx->grid, ocean, ao_fluxes, ice_partition, net));
     if (interp_rides) CHECK(deferred_went_out_on_main(ctx));
     if (ice_tail && ctx->deferred.valid && ctx->deferred.out.u != atmos->u) {   // (no tiled interpolation configured: a launch of its own)
         HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out));

@@ -81,8 +81,19 @@ hipError_t launch_interpolate_and_stress(hipStream_t st, const LaunchCfg& L, con
                                          const cf_net_ocean_fluxes* n);
 hipError_t launch_interpolate_background(hipStream_t st, const GridDesc& G, const cf_atmos_source* s,
                                          const cf_interp_weights* w, const cf_exchange_fields* e);
+// The ocean solve of this step as workgroups of ANOTHER launch (the sea-ice interface solve's: ice_ocean_kernel): the round-3
+// ocean kernel's argument block, filled by make_ocean_rider exactly as launch_ao_fluxes_lean fills it (fused net fluxes).
+struct OceanRider {
+    alignas(16) unsigned char args[1536];
+    int n_chunks = 0;
+    bool coare = false, valid = false;
+};
+hipError_t make_ocean_rider(const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G, const cf_ocean_surface* o,
+                            const cf_exchange_fields* e, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
+                            const cf_net_ocean_fluxes* net, const double* land, OceanRider* out);
 // what may ride in the tail workgroups of the sea-ice interface launch (launch_ai_fluxes)
 struct AiTail {
+    const OceanRider* ocean = nullptr;              // this step's ocean solve (then the stresses cannot ride: they need its ρτ)
     const cf_atmos_source* next_src = nullptr;      // the next step's interpolation …
     const cf_interp_weights* w = nullptr;
     const cf_exchange_fields* next_out = nullptr;

@@ -10,9 +10,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "coflux_solver_shared.hpp"
 #include "coflux_lean.hpp"
+#include "coflux_lean_kernel.hpp"
 
 namespace coflux {
 
@@ -342,15 +344,16 @@ __device__ __forceinline__ void ice_zero_net(SolverArgsPtr K, const GridDesc& G,
     }
 }
 
+// (a device routine: the kernel below, and ice_ocean_kernel, where the ocean solver's workgroups ride behind these)
 template <bool COARE, int SPEC, bool FUSE_NET, int BLOCK, bool TAIL = false>
-__global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BLOCK) ? CF_LEAN_WAVES : 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
+__device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int block) {
     constexpr int CHUNK = Geom<BLOCK>::CHUNK;
-    SolverArgsPtr K = opaque((SolverArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
+    SolverArgsPtr K = opaque(K_in);
     if constexpr (TAIL) {
         static_assert(BLOCK == 64 * IT_WAVES, "a tail workgroup is an interpolation workgroup");
         const int nch = (int)K->n_chunks;
-        if ((int)blockIdx.x >= nch) {
-            int b = (int)blockIdx.x - nch;
+        if (block >= nch) {
+            int b = block - nch;
             const int nb = (int)K->tail_blocks;
             const GridDesc Gt = kread(&K->G);
             if (b < nb) {
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
     const int tid = threadIdx.x, lane = tid & 63;
     const int wx = G.nx + 2 * G.ring;
     const unsigned wx_rcp = (unsigned)K->wx_reciprocal;
-    const int chunk = (int)blockIdx.x;  // dispatch order = layer order of the chunk table
+    const int chunk = block;  // dispatch order = layer order of the chunk table
     bool use_static = W.pos != nullptr;
     // Order of the start phase — everything is REQUESTED before anything is looked at, in straight-line code (a
     // branch around a load makes the compiler wait for all memory at the next join):
@@ -875,6 +878,37 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
     }
 }
 
+template <bool COARE, int SPEC, bool FUSE_NET, int BLOCK, bool TAIL = false>
+__global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BLOCK) ? CF_LEAN_WAVES : 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
+    ao_flux_fast_body<COARE, SPEC, FUSE_NET, BLOCK, TAIL>((SolverArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
+}
+
+// Config 3 in ONE solver launch: the atmosphere–sea-ice interface solve's workgroups first (the long, ragged ones: ≈ 30
+// iterations per cell, 3 … 100), the ocean solver's workgroups (coflux_lean_kernel.hpp, fused net-flux epilogue) BEHIND them in
+// dispatch order — they take the slots the interface solve's workgroups free as they retire — and the next step's
+// interpolation behind those.  The two solves are independent of each other (both read the exchange fields and the ocean
+// surface); two queues do not overlap them at all (scratch/two_ctx_overlap.py: 256.3 µs against 62.8 + 193.7), one launch does.
+// The face stresses need the ocean solve's ρτ everywhere: a launch of their own behind this one.
+struct IceOceanArgs {
+    SolverArgs A;   // the interface solve (TAIL form: n_chunks, tail_blocks … as in ao_flux_fast_kernel; no stress blocks)
+    LeanArgs O;     // the ocean solve
+    long long ocean_chunks;
+};
+template <bool COARE_ICE, bool COARE_OCEAN>
+__global__ __launch_bounds__(AO_BLOCK, 3) void ice_ocean_kernel(IceOceanArgs unused_by_name) {
+    typedef const IceOceanArgs __attribute__((address_space(4)))* ArgsPtr;
+    ArgsPtr K = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(K));
+    int block = (int)blockIdx.x;
+    const int nch = (int)K->A.n_chunks, noc = (int)K->ocean_chunks;
+    if (block >= nch && block < nch + noc) {
+        ao_lean_body<COARE_OCEAN, AO_BLOCK, true, false, false>((LeanArgsPtr)&K->O, block - nch);
+        return;
+    }
+    if (block >= nch + noc) block -= noc;  // the interpolation's workgroups keep their numbering (measured: ahead of the ocean solve's, 271 µs per step against 253)
+    ao_flux_fast_body<COARE_ICE, SOLVER_SEAICE_LEAN, false, AO_BLOCK, true>((SolverArgsPtr)&K->A, block);
+}
+
 // ---------------------------------------------------------------------------------------------
 // table / primitive self-test: y[n] = fn(x[n]) with the device's fast primitives (tests only)
 // ---------------------------------------------------------------------------------------------
@@ -1061,6 +1095,26 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
                                      tail->stress_ice->x_stress, tail->stress_ice->y_stress, nullptr};
             A.tau_x = tail->stress_net->u;
             A.tau_y = tail->stress_net->v;
+        }
+        if (tail->ocean) {
+            // the ocean solve's workgroups behind the interface solve's, the interpolation's behind those (ice_ocean_kernel)
+            if (!tail->ocean->valid || tail->stress_net || tail->ocean->n_chunks <= 0) return hipErrorInvalidValue;
+            static_assert(sizeof(LeanArgs) <= sizeof(tail->ocean->args), "OceanRider::args holds a LeanArgs");
+            IceOceanArgs M{};
+            M.A = A;
+            memcpy(&M.O, tail->ocean->args, sizeof(LeanArgs));
+            M.ocean_chunks = tail->ocean->n_chunks;
+            const dim3 mgrid((unsigned)(L.n_chunks + tail->ocean->n_chunks + A.tail_blocks));
+            constexpr size_t lds = (size_t)(Geom<AO_BLOCK>::LDS_BYTES > LeanGeom<AO_BLOCK>::LDS_BYTES ? Geom<AO_BLOCK>::LDS_BYTES : LeanGeom<AO_BLOCK>::LDS_BYTES);
+            static_assert(lds <= 53760, "three workgroups per CU");
+            if (coare) {
+                if (tail->ocean->coare) hipLaunchKernelGGL((ice_ocean_kernel<true, true>), mgrid, dim3(AO_BLOCK), lds, st, M);
+                else hipLaunchKernelGGL((ice_ocean_kernel<true, false>), mgrid, dim3(AO_BLOCK), lds, st, M);
+            } else {
+                if (tail->ocean->coare) hipLaunchKernelGGL((ice_ocean_kernel<false, true>), mgrid, dim3(AO_BLOCK), lds, st, M);
+                else hipLaunchKernelGGL((ice_ocean_kernel<false, false>), mgrid, dim3(AO_BLOCK), lds, st, M);
+            }
+            return hipGetLastError();
         }
         const dim3 tgrid((unsigned)(L.n_chunks + A.tail_blocks + A.stress_blocks));
         if (coare) hipLaunchKernelGGL((ao_flux_fast_kernel<true, SOLVER_SEAICE_LEAN, false, AO_BLOCK, true>), tgrid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, st, A);
