@@ -496,10 +496,14 @@ def main():
             except Exception:
                 continue
         ao_kernel = "ao_lean_kernel" if lean else "ao_flux_fast_kernel"
-        ao_key = (ao_kernel + (":fused" if fused else ":plain") + (":piped" if tail_mode else "")) if lean else ao_kernel
+        # the riders are priced only where the timed launch carried them: the event-bracketed pass over the schedule.  Without it
+        # (--config sea_ice, the torch halo path) `ao_ms` is the solver stage alone, back to back, and so is its byte count —
+        # with sea ice the ocean solve runs inside the interface solve's launch (ice_ocean_kernel), which has no roofline line here
+        tail_priced = tail_mode and prof is not None
+        ao_key = (ao_kernel + (":fused" if fused else ":plain") + (":piped" if tail_priced else "")) if lean else ao_kernel
         ao_what = "compute_atmosphere_ocean_fluxes!" + (" + the cell-local part of compute_net_ocean_fluxes! in its epilogue" if fused else "")
         ao_bytes = BYTES_AO_FUSED if fused else BYTES_AO
-        if tail_mode:   # the launch also interpolates the NEXT step's atmosphere state in its tail workgroups
+        if tail_priced:   # the launch also interpolates the NEXT step's atmosphere state in its tail workgroups
             ao_what += " + interpolate_atmosphere_state! of the next step in its tail workgroups"
             ao_bytes += BYTES_INTERP
 
@@ -535,11 +539,12 @@ def main():
                                                       "and JT, JS, SW written by the fused net-flux epilogue" if fused else
                                                       "80 B read + 48 B written (SURVEY §8d)") +
                                                      (" + 18.3 B of the JRA55 window read and 64 B of exchange fields written by the tail "
-                                                      "workgroups (interpolate_atmosphere_state! of the next step, SURVEY §8d)" if tail_mode else ""),
+                                                      "workgroups (interpolate_atmosphere_state! of the next step, SURVEY §8d)" if tail_priced else ""),
                                  frac_solver_and_net_only_176_B_per_cell=(BYTES_AO_FUSED * cells_rank / (ao_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                                                                          if tail_mode else None),
+                                                                          if tail_priced else None),
                                  frac_at_contract_128_B_per_cell=BYTES_AO * cells_rank / (ao_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 measured="HIP events around the kernel inside a separate event-bracketed pass over the timed schedule",
+                                 measured=("HIP events around the kernel inside a separate event-bracketed pass over the timed schedule" if prof else
+                                           "the solver stage alone, launched back to back on one set of inputs (cf_time_stage)"),
                                  avg_launch_ms_batches_sorted_by_trip_hints=prof_sorted[1][0] if prof_sorted else None,
                                  avg_launch_ms_back_to_back_same_inputs=ao_ms_alone),
                    roofline_interpolate=roof("interpolate_kernel (interpolate_atmosphere_state!)", BYTES_INTERP, cells_rank, interp_ms),
