@@ -883,16 +883,18 @@ __global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BL
     ao_flux_fast_body<COARE, SPEC, FUSE_NET, BLOCK, TAIL>((SolverArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
 }
 
-// Config 3 in ONE solver launch: the atmosphere–sea-ice interface solve's workgroups first (the long, ragged ones: ≈ 30
-// iterations per cell, 3 … 100), the ocean solver's workgroups (coflux_lean_kernel.hpp, fused net-flux epilogue) BEHIND them in
-// dispatch order — they take the slots the interface solve's workgroups free as they retire — and the next step's
-// interpolation behind those.  The two solves are independent of each other (both read the exchange fields and the ocean
+// Config 3 in ONE solver launch: the workgroups of the atmosphere–sea-ice interface solve (the long ones: ≈ 30 iterations per
+// cell, 3 … 100) and of the ocean solve (coflux_lean_kernel.hpp, fused net-flux epilogue) in one dispatch order — the ocean
+// solve's first arrival layer, every interface chunk, the rest of the ocean solve (it takes the slots the others free as they
+// retire), the next step's interpolation (launch_ai_fluxes lays the segments out).  The two solves are independent of each other (both read the exchange fields and the ocean
 // surface); two queues do not overlap them at all (scratch/two_ctx_overlap.py: 256.3 µs against 62.8 + 193.7), one launch does.
 // The face stresses need the ocean solve's ρτ everywhere: a launch of their own behind this one.
 struct IceOceanArgs {
     SolverArgs A;   // the interface solve (TAIL form: n_chunks, tail_blocks … as in ao_flux_fast_kernel; no stress blocks)
     LeanArgs O;     // the ocean solve
     long long ocean_chunks;
+    // dispatch order: up to eight segments of (kind, first, count); kind 0 = interface chunks, 1 = ocean chunks, 2 = interpolation
+    int nseg, seg_kind[8], seg_first[8], seg_count[8];
 };
 template <bool COARE_ICE, bool COARE_OCEAN>
 __global__ __launch_bounds__(AO_BLOCK, 3) void ice_ocean_kernel(IceOceanArgs unused_by_name) {
@@ -901,11 +903,26 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ice_ocean_kernel(IceOceanArgs unu
     asm volatile("" : "+s"(K));
     int block = (int)blockIdx.x;
     const int nch = (int)K->A.n_chunks, noc = (int)K->ocean_chunks;
-    if (block >= nch && block < nch + noc) {
-        ao_lean_body<COARE_OCEAN, AO_BLOCK, true, false, false>((LeanArgsPtr)&K->O, block - nch);
+    (void)noc;
+    int kind = 0, idx = 0;
+    {
+        int rest = block;
+        const int ns = K->nseg;
+        for (int q = 0; q < ns; ++q) {
+            const int c = K->seg_count[q];
+            if (rest < c) {
+                kind = K->seg_kind[q];
+                idx = K->seg_first[q] + rest;
+                break;
+            }
+            rest -= c;
+        }
+    }
+    if (kind == 1) {
+        ao_lean_body<COARE_OCEAN, AO_BLOCK, true, false, false>((LeanArgsPtr)&K->O, idx);
         return;
     }
-    if (block >= nch + noc) block -= noc;  // the interpolation's workgroups keep their numbering (measured: ahead of the ocean solve's, 271 µs per step against 253)
+    block = kind == 2 ? nch + idx : idx;  // the interpolation's workgroups: numbered as in ao_flux_fast_kernel's tail
     ao_flux_fast_body<COARE_ICE, SOLVER_SEAICE_LEAN, false, AO_BLOCK, true>((SolverArgsPtr)&K->A, block);
 }
 
@@ -1104,6 +1121,42 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
             M.A = A;
             memcpy(&M.O, tail->ocean->args, sizeof(LeanArgs));
             M.ocean_chunks = tail->ocean->n_chunks;
+            {
+                // (experiments: COFLUX_EXPERIMENTS=1 COFLUX_ICE_OCEAN_ORDER="I0:768,O0:768,T" — segments of interface / ocean chunks
+                // first:count and the interpolation, in dispatch order; scratch/ice_ocean_orders.sh)
+                static const char* order = experiment_knob("COFLUX_ICE_OCEAN_ORDER");
+                int n = 0;
+                if (order && order[0]) {
+                    const char* c = order;
+                    while (*c && n < 8) {
+                        const char k = *c++;
+                        if (k == 'T') {
+                            M.seg_kind[n] = 2; M.seg_first[n] = 0; M.seg_count[n] = (int)A.tail_blocks;
+                        } else {
+                            M.seg_kind[n] = k == 'O' ? 1 : 0;
+                            M.seg_first[n] = (int)strtol(c, (char**)&c, 10);
+                            if (*c == ':') ++c;
+                            M.seg_count[n] = (int)strtol(c, (char**)&c, 10);
+                            const int total = k == 'O' ? tail->ocean->n_chunks : L.n_chunks;  // (the knob speaks of 768 chunks: clamp)
+                            M.seg_first[n] = std::min(M.seg_first[n], total);
+                            M.seg_count[n] = std::min(M.seg_count[n], total - M.seg_first[n]);
+                        }
+                        ++n;
+                        if (*c == ',') ++c;
+                    }
+                } else {
+                    // the ocean solve's FIRST arrival layer (its largest chunks, one per CU) ahead of the interface solve's workgroups,
+                    // the rest behind them: the riders left for the end are the short ones (249.1 µs per step against 255.2 with every
+                    // ocean chunk behind; its smallest layer first 252.4; profiles/r04_experiments.md §17)
+                    const int noc_all = tail->ocean->n_chunks, head = std::min(std::max(L.cu_count, 0), noc_all);
+                    M.seg_kind[0] = 1; M.seg_first[0] = 0; M.seg_count[0] = head;
+                    M.seg_kind[1] = 0; M.seg_first[1] = 0; M.seg_count[1] = L.n_chunks;
+                    M.seg_kind[2] = 1; M.seg_first[2] = head; M.seg_count[2] = noc_all - head;
+                    M.seg_kind[3] = 2; M.seg_first[3] = 0; M.seg_count[3] = (int)A.tail_blocks;
+                    n = 4;
+                }
+                M.nseg = n;
+            }
             const dim3 mgrid((unsigned)(L.n_chunks + tail->ocean->n_chunks + A.tail_blocks));
             constexpr size_t lds = (size_t)(Geom<AO_BLOCK>::LDS_BYTES > LeanGeom<AO_BLOCK>::LDS_BYTES ? Geom<AO_BLOCK>::LDS_BYTES : LeanGeom<AO_BLOCK>::LDS_BYTES);
             static_assert(lds <= 53760, "three workgroups per CU");
