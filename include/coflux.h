@@ -361,9 +361,9 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * (round-3 ocean kernel and the CoefficientBasedFluxes kernel): they take the slots the solver's
                                    * workgroups free as they retire; with a sea-ice formulation (cf_update_state_sea_ice) the riders
                                    * sit in the interface solve's launch — the longest of the step — and the OCEAN SOLVE is one of
-                                   * them: its workgroups are dispatched behind the interface solve's, the interpolation's behind
-                                   * those, and the face stresses follow as a launch of their own (two solver launches on two
-                                   * queues do not overlap on this device; workgroups of one launch do).
+                                   * them: one dispatch order holds its first arrival layer, the interface solve's workgroups, the
+                                   * rest of its own and the interpolation's; the face stresses follow as a launch of their own
+                                   * (two solver launches on two queues do not overlap on this device; workgroups of one launch do).
                                    * A context in this mode cuts its solver chunks for it (equal chunks per CU where the surface fills
                                    * one dispatch generation, so that workgroups retire staggered): meant for stepping loops that
                                    * request every next state; a lone cf_update_state without a request runs ≈ 5 µs slower on that
