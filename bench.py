@@ -78,6 +78,10 @@ def parse():
     ap.add_argument("--fused-interp", type=int, choices=(0, 1), default=None,
                     help="CF_OPT_FUSED_INTERP: interpolate_atmosphere_state! inside the solver's prologue (two launches per step); "
                          "default: the library's choice")
+    ap.add_argument("--solver-path", choices=("exact", "certified"), default="exact",
+                    help="CF_OPT_SOLVER_PATH: the reference's own iteration, or the certified reduced-iteration solve with "
+                         "per-cell exact-path fallback (include/coflux.h)")
+    ap.add_argument("--certified-budget", type=int, default=800, help="CF_OPT_CERTIFIED_BUDGET in units of 1e-9")
     ap.add_argument("--no-sorted-pass", action="store_true",
                     help="skip the informational pass with CF_OPT_TRIP_HINTS = 1 (profiling runs: only the default configuration's launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample: passes that fit this wall time")
@@ -244,6 +248,9 @@ def main():
     ctx = FluxContext(nx, ny, h, h, params, ring=1, device=local_rank)
     if a.trip_hints != 2:
         ctx.set_option(abi.OPT_TRIP_HINTS, a.trip_hints)
+    if a.solver_path == "certified":
+        ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
+        ctx.set_option(abi.OPT_CERTIFIED_BUDGET, a.certified_budget)
     if a.fused_interp is not None:
         ctx.set_option(abi.OPT_FUSED_INTERP, a.fused_interp)
     ring_rows = ctx.grid.ring + 1

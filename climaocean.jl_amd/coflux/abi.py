@@ -26,6 +26,9 @@ MASK_NONE, MASK_U8, MASK_BOTTOM_HEIGHT = 0, 1, 2
 ALBEDO_CONSTANT, ALBEDO_LATITUDE_DEPENDENT = 0, 1
 OPT_SOLVER, OPT_INTERP_TILE_CAP, OPT_MAX_BLOCKS, OPT_TRIP_HINTS, OPT_AO_CHUNK, OPT_PROFILE_STRIDE, OPT_FUSED_NET = 0, 1, 2, 3, 4, 5, 6
 OPT_ICE_ORBIT_SHORTCUT, OPT_FUSED_INTERP, OPT_MERGED_PREFETCH = 7, 8, 9
+OPT_SOLVER_PATH, OPT_CERTIFIED_BUDGET = 10, 11
+SOLVER_PATH_EXACT, SOLVER_PATH_CERTIFIED = 0, 1      # how the Monin–Obukhov fixed point is reached (include/coflux.h)
+CERTIFIED_EXACT_FLAG = 0x100                         # `iterations` of a cell the certified path solved on the exact path
 SOLVER_TABLES, SOLVER_LIBM, SOLVER_TABLES_R2, SOLVER_TABLES_R2_OUTER = 0, 1, 2, 3   # 2, 3: A/B diagnostics (include/coflux.h)
 STAGE_INTERPOLATE, STAGE_AO_FLUXES, STAGE_NET_FLUXES, STAGE_UPDATE_STATE = 0, 1, 2, 3
 
@@ -202,7 +205,7 @@ EXPORTED_SYMBOLS = (
     "cf_interpolate_land_freshwater", "cf_set_land_freshwater", "cf_materialize_salinity_restoring",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
     "cf_window_upload", "cf_window_find", "cf_window_source",
-    "cf_ensure_chunk_table", "cf_solver_path",
+    "cf_ensure_chunk_table", "cf_solver_path", "cf_solver_iteration_path",
 )
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -237,6 +240,7 @@ def load_library(path=None):
     lib.cf_set_flux_params.argtypes = [vp, C.POINTER(FluxParams)]
     lib.cf_set_stream.argtypes = [vp, vp]
     lib.cf_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.cf_solver_iteration_path.argtypes = [vp, C.POINTER(C.c_int)]
     lib.cf_debug_eval.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     lib.cf_debug_chunk_plan.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     lib.cf_sync.argtypes = [vp]

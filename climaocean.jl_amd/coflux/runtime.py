@@ -304,6 +304,12 @@ class FluxContext:
         self._check(self.lib.cf_solver_path(self._h, C.byref(lean), C.byref(fused)), "cf_solver_path")
         return bool(lean.value), fused.value
 
+    def solver_iteration_path(self):
+        """abi.SOLVER_PATH_EXACT or abi.SOLVER_PATH_CERTIFIED: what the ocean solve would run with the current options."""
+        path = C.c_int()
+        self._check(self.lib.cf_solver_iteration_path(self._h, C.byref(path)), "cf_solver_iteration_path")
+        return path.value
+
     def time_copy(self, nbytes, launches=20):
         a = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)
         b = torch.empty_like(a)

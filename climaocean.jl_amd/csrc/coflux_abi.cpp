@@ -133,6 +133,9 @@ static int lower_params(cf_ctx* ctx, const cf_flux_params* p, DevParams* d) {
     return CF_OK;
 }
 
+// safety factor of the certificate for the accuracy of the secant Jacobian (measured ±4 %, scratch/certified_study.py)
+static constexpr double CERT_SAFETY = 1.25;
+
 static LoopParams loop_params(const cf_flux_params& p, const DevParams& d) {
     LoopParams C{};
     auto lg = [](double x) { return x > 0 ? std::log(x) : 0.0; };
@@ -191,6 +194,13 @@ static LoopParams loop_params(const cf_flux_params& p, const DevParams& d) {
     C.min_gust2 = d.min_gust * d.min_gust;
     C.x_scale = PSI_A * d.h_ref;
     C.two_inv_kappa = 2.0 / d.kappa;
+    // the certified path's first guess and thresholds (coflux_certified.hpp): neutral profile over a 1e-4 m surface
+    C.cert_u0 = 0.035;
+    C.cert_two_inv_u0 = 2.0 / C.cert_u0;
+    C.cert_chi0 = d.kappa / std::log(d.h_ref / 1e-4);
+    C.cert_accept = 1e-7;
+    C.cert_budget = 8e-7 / CERT_SAFETY;
+    C.cert_max_evals = 10;
     return C;
 }
 
@@ -282,6 +292,7 @@ static int install_params(cf_ctx* ctx, const cf_flux_params* params) {
     ctx->params = *params;
     ctx->dev = d;
     ctx->fast = loop_params(*params, d);
+    ctx->fast.cert_budget = ctx->certified_budget / CERT_SAFETY;
     if (!ctx->d_params && hipMalloc((void**)&ctx->d_params, sizeof(DevParams)) != hipSuccess)
         return fail(ctx, CF_ERR_HIP, "hipMalloc of the device parameter block failed");
     if (hipMemcpy(ctx->d_params, &d, sizeof(DevParams), hipMemcpyHostToDevice) != hipSuccess)
@@ -532,6 +543,15 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             if (value < 1) return fail(ctx, CF_ERR_INVALID, "profile stride %d must be >= 1", value);
             ctx->prof_stride = value;
             return CF_OK;
+        case CF_OPT_SOLVER_PATH:
+            if (value != CF_SOLVER_PATH_EXACT && value != CF_SOLVER_PATH_CERTIFIED) return fail(ctx, CF_ERR_INVALID, "solver path %d: 0 (exact) or 1 (certified)", value);
+            ctx->launch.certified = value;
+            return CF_OK;
+        case CF_OPT_CERTIFIED_BUDGET:
+            if (value < 50 || value > 1000000) return fail(ctx, CF_ERR_INVALID, "certified budget %d: 50 … 1000000 (units of 1e-9)", value);
+            ctx->certified_budget = value * 1e-9;
+            ctx->fast.cert_budget = ctx->certified_budget / CERT_SAFETY;
+            return CF_OK;
         case CF_OPT_AO_CHUNK:
             if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024 && value != 1280 && value != 3072)
                 return fail(ctx, CF_ERR_INVALID, "solver chunk %d: wet cells per workgroup must be 0 (automatic), 256, 512, 768, 1024, 1280 "
@@ -674,6 +694,19 @@ static bool net_fluxes_fused(const cf_ctx* ctx) {
             ctx->launch.solver == CF_SOLVER_TABLES_R2_OUTER) &&
            ctx->dev.albedo_kind == CF_ALBEDO_CONSTANT &&
            (lean || !ctx->launch.ao_wide);  // (round 2's kernel has the fused epilogue in the narrow geometry only)
+}
+
+int cf_solver_iteration_path(cf_ctx* ctx, int* path) {
+    if (!ctx || !path) return fail(ctx, CF_ERR_INVALID, "cf_solver_iteration_path: bad arguments");
+    const bool lean = ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
+    const bool fused_interp = net_fluxes_fused(ctx) && ctx->fused_interp != 0 && !ctx->launch.ao_wide;
+    // (a chunk plan that has been requested but not built yet: the wide geometry is decided when the table is built)
+    const bool wide_pending = !ctx->chunk_valid && ctx->launch.ao_chunk == 3072;  // (CF_OPT_AO_CHUNK = 3072: the wide geometry)
+    const bool narrow_pending = !ctx->chunk_valid && ctx->launch.ao_chunk != 3072;
+    LaunchCfg L = ctx->launch;
+    if (narrow_pending) L.ao_wide = 0;
+    *path = lean && !wide_pending && lean_certified_applies(L, ctx->fast, fused_interp) ? CF_SOLVER_PATH_CERTIFIED : CF_SOLVER_PATH_EXACT;
+    return CF_OK;
 }
 
 int cf_solver_path(cf_ctx* ctx, int* lean_kernel, int* fused_net) {

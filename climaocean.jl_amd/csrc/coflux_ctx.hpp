@@ -54,6 +54,7 @@ struct cf_ctx {
     bool trip_hints = true;
     bool lean_hints = false;         // the lean ocean kernel sorts its lists by trip count only when CF_OPT_TRIP_HINTS = 1
     int merged_prefetch = 0;         // CF_OPT_MERGED_PREFETCH: a requested next-step interpolation rides in the face-stress launch
+    double certified_budget = 8e-7;  // CF_OPT_CERTIFIED_BUDGET
     int fused_interp = 0;            // cf_update_state: the interpolation in the lean ocean kernel's prologue (0 off: measured slower; 1 when possible)
     int fused_net = 2;               // cf_update_state: net fluxes in the solver's epilogue + a stress kernel: 0 never, 1 when possible, 2 with the lean ocean kernel
     // cost-balanced chunk table of the solver, rebuilt when the wet mask (pointer / kind / surface z) changes

@@ -368,7 +368,7 @@ struct LoopParams {
     double b_t, log_A_t, log_lm_t, log_const_t;                 // temperature roughness
     int32_t maxiter, fixed, m_kind, q_kind, t_kind, same_scalar;
     int32_t specialization;  // SOLVER_OCEAN / SOLVER_ICE / SOLVER_GENERIC / SOLVER_LY (host-selected)
-    int32_t pad;
+    int32_t cert_max_evals;  // certified path (coflux_certified.hpp): evaluations before a lane is sent down the exact path
     // CoefficientBasedFluxes + LargeYeagerTransferCoefficients
     double ly_min_wind, ly_zeta_bound, ly_cd0, ly_cd1, ly_cd2, ly_cd3, ly_high_wind, ly_cd_high, ly_ce, ly_ch_s, ly_ch_u;
     double ly_lz, inv_kappa;  // log(h / 10 m), 1/κ
@@ -377,6 +377,11 @@ struct LoopParams {
     double min_gust2;         // U_G,min²
     double x_scale;           // PSI_A · h: the ψ table variable of h/L★ is 1 + x_scale·|1/L★|
     double two_inv_kappa;     // 2/κ
+    // the certified reduced-iteration solve (mo_iterate_certified)
+    double cert_u0, cert_two_inv_u0;  // start: u★ = cert_u0 · √(Δu² + U_G,min²); 2 / cert_u0
+    double cert_chi0;                 // start: χ = κ / log(h / 1e-4 m)
+    double cert_accept;               // relative residual below which the extrapolated state is accepted
+    double cert_budget;               // flux-metric budget of the truncation certificate ÷ the safety factor
 };
 
 constexpr int SOLVER_OCEAN = 0;    // Charnock-type momentum roughness, identical Reynolds-scaled scalars, U_G,min > 0

@@ -40,7 +40,12 @@ struct LaunchCfg {
     uint32_t* d_lean_sorted;    // the lean ocean kernel's lists: every chunk's wet cells ordered by last call's trip counts (coflux_solver_lean.hip)
     const int* d_lean_info;     // per chunk: wet cells listed, fingerprint of the wet set (x, y), 0
     int lean_hints;             // 1: the lean ocean kernel re-orders its lists by trip count at the end of every call
+    int certified;              // CF_OPT_SOLVER_PATH: 1 = the certified reduced-iteration solve wherever it applies (lean_certified_applies)
 };
+
+// CF_SOLVER_PATH_CERTIFIED runs in the lean ocean kernel's narrow geometry under the convergence stop rule, with index-ordered
+// lists and without the interpolation fused into the prologue; everywhere else the exact path runs.
+bool lean_certified_applies(const LaunchCfg& L, const LoopParams& C, bool fused_interp = false);
 
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
                               const cf_interp_weights* w, const cf_exchange_fields* e);

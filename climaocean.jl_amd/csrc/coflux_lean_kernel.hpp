@@ -7,6 +7,7 @@
 #include "coflux_interp_cell.hpp"
 #include "coflux_interp_tiles.hpp"
 #include "coflux_lean.hpp"
+#include "coflux_certified.hpp"
 #include "coflux_solver_shared.hpp"
 
 #ifndef CF_LEAN_WAVES
@@ -118,7 +119,13 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 // take the slots the solver's workgroups free as they retire): they interpolate the NEXT step's atmosphere state into the
 // other set of exchange fields with the tiled routine of interpolate_kernel — memory-bound work under the solver's
 // FP64-bound tail instead of a launch of its own in front of the next solver (cf_time_steps with two exchange sets).
-template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false>
+// CERT: the certified reduced-iteration solve (coflux_certified.hpp).  A batch runs mo_iterate_certified; the lanes it
+// does not certify put their list position into a queue in LDS (the trip-count histogram's space: this mode does not
+// sort) and skip the epilogue.  The LAST wave of the workgroup to run out of batches takes the queue in batches of its
+// own through the exact iteration (mo_iterate_lean) — ≈ 1 % of the cells, compacted per workgroup instead of holding
+// their whole batch for the reference's trip count; entries beyond the queue's capacity run the exact iteration in
+// their own batch, at once.
+template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false, bool CERT = false>
 __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
     using Geo = LeanGeom<BLOCK>;
     constexpr int CHUNK = Geo::CHUNK;
@@ -207,7 +214,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
     const int mask_kind = (mask == nullptr) ? CF_MASK_NONE : (int)K->mask_kind;
     const double z_surface = K->z_surface;
     const double T_offset = K->T_offset;
-    const bool sorting = use_static && K->sort_enabled != 0;
+    const bool sorting = !CERT && use_static && K->sort_enabled != 0;
     // sort_enabled = number of WINDOWS the chunk's list is sorted in: 1 = the whole chunk by trip count (64 bins);
     // 4 = each quarter of the list separately (16 one-count bins each): a batch's cells then stay within a quarter of the
     // chunk's range — a fourth of the lines per access a whole-chunk sort touches — and still run together
@@ -348,9 +355,20 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             if (lane == 0) st = atomicAdd(&counters[0], 64);
             return __shfl(st, 0);
         };
+        // CERT: the queue of list positions whose cells go down the exact path, and whether this wave is working it off
+        constexpr int QUEUE_CAP = 2 * AO_BINS;
+        int* queue = hist;  // (hist and cursor are contiguous)
+        static_assert(Geo::CURSOR_OFFSET == Geo::HIST_OFFSET + AO_BINS * 4, "the exact-path queue spans the histogram and the cursors");
+        bool straggling = false;
+        int limit = nwet;  // entries of the list this wave is claiming from (the chunk's list, or the queue)
+        // list position of this lane's cell in the batch that starts at `st`
+        auto position_of = [&](int st) -> int {
+            const int qq = min(st + lane, limit - 1);
+            if constexpr (CERT) return straggling ? queue[qq] : qq;
+            return qq;
+        };
         auto coords_of = [&](int st, int& ci, int& cj) -> size_t {
-            const int qq = min(st + lane, nwet - 1);
-            const int idx = range_begin + (int)(list[qq] & LEAN_OFFSET_MASK);
+            const int idx = range_begin + (int)(list[position_of(st)] & LEAN_OFFSET_MASK);
             const int jj = row_of(idx, wx, wx_rcp);
             ci = idx - jj * wx - G.ring;
             cj = jj - G.ring;
@@ -382,7 +400,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                 const SourceDesc S = kread(&Kb->S);
                 const WeightDesc Wt = kread(&Kb->Wt);
                 const ExchangeCell e = interp_cell(S, Wt, G, ci, cj, k);
-                if (st + lane < nwet) store_exchange(kread(&Kb->E), k, e);
+                if (st + lane < limit) store_exchange(kread(&Kb->E), k, e);
                 r.ua = e.u;
                 r.va = e.v;
                 r.Ta = e.T;
@@ -404,9 +422,27 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
         int start = claim();
         Raw raw{};
         if (start < nwet) raw = request(start);
-        while (start < nwet) {
+        for (;;) {
+            if constexpr (CERT) {
+                if (!straggling && start >= nwet) {
+                    // no batch left for this wave.  The last wave of the workgroup to get here works the queue off: every
+                    // other wave has made its entries before it counted itself out (LDS operations of a wave stay in order)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    int gone = 0;
+                    if (lane == 0) gone = atomicAdd(&counters[3], 1);
+                    gone = __shfl(gone, 0);
+                    if (gone != Geo::WAVES - 1) break;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    limit = min(((volatile int*)counters)[1], QUEUE_CAP);
+                    if (limit <= 0) break;
+                    straggling = true;
+                    start = 0;
+                    raw = request(start);
+                }
+            }
+            if (start >= limit) break;
             const int q = start + lane;
-            const bool in_range = q < nwet;
+            const bool in_range = q < limit;
             // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
             const LeanCell c = lean_prologue(P, L.kappa, tab, raw.ua, raw.va, raw.Ta, raw.pa, raw.qa, 0.5 * (raw.u0 + raw.u1),
                                              0.5 * (raw.v0 + raw.v1), raw.To, raw.So);
@@ -420,17 +456,44 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
 #ifdef CF_LEAN_STAMPS
             const unsigned long long t_it = __builtin_readcyclecounter();
 #endif
-            const Scales s = mo_iterate_lean<COARE>(L, c, tab, in_range);
+            Scales s;
+            bool finish = in_range;  // lanes whose results are written by this batch
+            if constexpr (CERT) {
+                bool exact = in_range;  // a batch from the queue: every lane takes the reference's iteration
+                if (!straggling) {
+                    s = mo_iterate_certified<COARE>(L, c, tab, in_range, exact);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(exact);
+                    if (m) {
+                        int slot = 0;
+                        if (lane == 0) slot = atomicAdd(&counters[1], __popcll(m));
+                        slot = __shfl(slot, 0) + __popcll(m & ((1ull << lane) - 1ull));
+                        if (exact && slot < QUEUE_CAP) {
+                            queue[slot] = q;
+                            exact = false;
+                            finish = false;
+                        }
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(exact) != 0ull) {
+                    const Scales e = mo_iterate_lean<COARE>(L, c, tab, exact);
+                    if (exact) {
+                        s = e;
+                        s.it |= CERT_EXACT_FLAG;
+                    }
+                }
+            } else {
+                s = mo_iterate_lean<COARE>(L, c, tab, in_range);
+            }
 #ifdef CF_LEAN_STAMPS
             stamp_iter += __builtin_readcyclecounter() - t_it;
             ++stamp_batches;
             {
-                int m = in_range ? s.it : 0;
+                int m = in_range ? (s.it & 0xff) : 0;
                 for (int d = 32; d; d >>= 1) m = max(m, __shfl_xor(m, d));
                 stamp_trips += (unsigned long long)m;
             }
 #endif
-            if (in_range) {
+            if (finish) {
                 LeanArgsPtr Ke = opaque(K);
                 // (cell coordinates recomputed from the list entry: cheaper than registers held across the iteration)
                 const size_t k = cell_of(start);
@@ -448,8 +511,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                 if (F.iters) gstore_i32(F.iters, (unsigned)k * 4u, R.iterations);
                 if constexpr (FUSE) {
                     // compute_net_ocean_fluxes!, the part that needs no neighbour: interior cells only
-                    const int qq = min(start + lane, nwet - 1);
-                    const int idx = range_begin + (int)(list[qq] & LEAN_OFFSET_MASK);
+                    const int idx = range_begin + (int)(list[position_of(start)] & LEAN_OFFSET_MASK);
                     const int jj = row_of(idx, wx, wx_rcp);
                     const int ci = idx - jj * wx - G.ring, cj = jj - G.ring;
                     if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {
@@ -476,8 +538,10 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                 }
             }
 #if !CF_LEAN_PREFETCH
-            const int next = claim();
-            if (next < nwet) raw = request(next);
+            int next;
+            if constexpr (CERT) next = straggling ? start + 64 : claim();
+            else next = claim();
+            if (next < limit) raw = request(next);
 #endif
             start = next;
         }

@@ -53,9 +53,9 @@ extern "C" int cf_debug_phase_read(unsigned long long* out, int n) {
 
 namespace coflux {
 
-template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false>
+template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false, bool CERT = false>
 __global__ __launch_bounds__(BLOCK, BLOCK == AO_BLOCK ? CF_LEAN_WAVES : 3) void ao_lean_kernel(LeanArgs unused_by_name) {
-    ao_lean_body<COARE, BLOCK, FUSE, FUSE_INTERP, TAIL>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
+    ao_lean_body<COARE, BLOCK, FUSE, FUSE_INTERP, TAIL, CERT>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -102,6 +102,11 @@ __global__ __launch_bounds__(256) void lean_list_build_kernel(const uint32_t* __
 hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32_t* d_wet_pos, const int* d_begins, uint32_t* d_sorted, int* d_info) {
     hipLaunchKernelGGL(lean_list_build_kernel, dim3(nchunks), dim3(256), 0, st, d_wet_pos, d_begins, wide ? AO_CHUNK_WIDE : AO_CHUNK, d_sorted, d_info);
     return hipGetLastError();
+}
+
+bool lean_certified_applies(const LaunchCfg& L, const LoopParams& C, bool fused_interp) {
+    return L.certified && C.specialization == SOLVER_OCEAN_LEAN && !C.fixed && !L.ao_wide && L.lean_hints == 0 && !fused_interp &&
+           C.cert_max_evals > 2 && C.tol > 0;
 }
 
 // the argument block of one ocean solve (everything but the tail workgroups' and the fused interpolation's descriptors)
@@ -162,6 +167,7 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
     LeanArgs A{};
     if (hipError_t err = fill_lean_args(L, P, C, G, o, e, f, ice, net, land, A)) return err;
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
+    const bool cert = lean_certified_applies(L, C, src != nullptr && next_out == nullptr);
     if (next_out) {
         // tail workgroups: `src`, `w` describe the NEXT step's interpolation into `next_out` (narrow geometry, fused net fluxes)
         if (!net || !src || !w || L.ao_wide || L.interp_cap <= 0 || tail_blocks <= 0) return hipErrorInvalidValue;
@@ -175,8 +181,13 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
         A.tail_rows = tail_rows;
         A.tail_cap = L.interp_cap;
         A.tail_pos = tail_pos < 0 || tail_pos > L.n_chunks ? L.n_chunks : tail_pos;
-        if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK, true, false, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
-        else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK, true, false, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        if (cert) {
+            if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK, true, false, true, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+            else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK, true, false, true, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        } else {
+            if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK, true, false, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+            else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK, true, false, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        }
         return hipGetLastError();
     }
 #define CF_LEAN_LAUNCH(COARE_, BLOCK_, FUSE_) \
@@ -195,6 +206,15 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
         } else {
             if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK_WIDE, false); else CF_LEAN_LAUNCH(false, AO_BLOCK_WIDE, false);
         }
+    } else if (cert) {
+#define CF_CERT_LAUNCH(COARE_, FUSE_) \
+    hipLaunchKernelGGL((ao_lean_kernel<COARE_, AO_BLOCK, FUSE_, false, false, true>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A)
+        if (net) {
+            if (coare) CF_CERT_LAUNCH(true, true); else CF_CERT_LAUNCH(false, true);
+        } else {
+            if (coare) CF_CERT_LAUNCH(true, false); else CF_CERT_LAUNCH(false, false);
+        }
+#undef CF_CERT_LAUNCH
     } else {
         if (net) {
             if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK, true); else CF_LEAN_LAUNCH(false, AO_BLOCK, true);

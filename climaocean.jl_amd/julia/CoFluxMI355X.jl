@@ -126,6 +126,21 @@ d2h!(b, dst::Array, src) = check(b.ctx, ccall((:cf_d2h, libcoflux), Cint, (Ptr{C
                                               b.ctx, dst, src, sizeof(dst)))
 sync(b) = check(b.ctx, ccall((:cf_sync, libcoflux), Cint, (Ptr{Cvoid},), b.ctx))
 
+# How the SimilarityTheoryFluxes fixed point is reached (include/coflux.h, CF_OPT_SOLVER_PATH): the reference's own
+# iteration (:exact, default) or the certified reduced-iteration solve with per-cell exact-path fallback (:certified,
+# every cell within `budget` — default 8e-7, in the flux metric of coflux.h — of the exact path's result).
+const CF_OPT_SOLVER_PATH = Cint(10)
+const CF_OPT_CERTIFIED_BUDGET = Cint(11)
+set_option!(b, option, value) = check(b.ctx, ccall((:cf_set_option, libcoflux), Cint, (Ptr{Cvoid}, Cint, Cint), b.ctx, option, value))
+function set_solver_path!(b, path::Symbol; budget = 8e-7)
+    path in (:exact, :certified) || throw(ArgumentError("solver path must be :exact or :certified"))
+    set_option!(b, CF_OPT_SOLVER_PATH, path == :certified ? 1 : 0)
+    path == :certified && set_option!(b, CF_OPT_CERTIFIED_BUDGET, round(Cint, budget * 1e9))
+    return b
+end
+solver_iteration_path(b) = (p = Ref{Cint}(0); check(b.ctx, ccall((:cf_solver_iteration_path, libcoflux), Cint, (Ptr{Cvoid}, Ref{Cint}), b.ctx, p));
+                            p[] == 1 ? :certified : :exact)
+
 # ---- the three functions of update_state! ------------------------------------------------------
 # Each body is ONE ccall; these are the methods a maintainer adds for
 #   interpolate_atmosphere_state!(interfaces::…{<:CoFluxBackend}, atmosphere, coupled_model) etc.

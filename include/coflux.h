@@ -377,6 +377,32 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                      iterations ago bit for bit — an exact period-2 orbit, where the skin-temperature balance does not
                                      contract — and returns the iterate the remaining steps up to maxiter would end on (the same
                                      bits, tested); 0: iterate to maxiter */
+#define CF_OPT_SOLVER_PATH 10      /* how the SimilarityTheoryFluxes fixed point of compute_atmosphere_ocean_fluxes! is reached
+                                   * (omip_simulation.jl:42-49):
+                                   * CF_SOLVER_PATH_EXACT (0, default): the reference's own iteration — same first guess (1e-4), same
+                                   * update order, same stop rule, identical trip counts, results within 7e-12 of the oracle.
+                                   * CF_SOLVER_PATH_CERTIFIED (1): the same map in FP64 from a neutral-profile first guess with
+                                   * Anderson(2) steps (4–6 evaluations per cell instead of 8–20), and a per-cell CERTIFICATE that
+                                   * the fixed point lies within CF_OPT_CERTIFIED_BUDGET of where the reference's stop rule would
+                                   * have left its iterate, in the metric |Δ flux| ≤ budget · max(|flux|, floor) with the floors
+                                   * 1 W m⁻² (sensible, latent heat), 1e-6 kg m⁻² s⁻¹ (water vapour), 1e-3 N m⁻² (ρτx, ρτy).  The
+                                   * bound is the worst case over every last drift the stop rule admits, from the map's Jacobian at
+                                   * the fixed point (csrc/coflux_certified.hpp).  Cells that cannot be certified (≈ 1 % at the default
+                                   * budget: near-neutral and dead-calm cells, where an absolute drift tolerance leaves the stopped
+                                   * iterate loosely determined) are solved by the exact path inside the same launch, so that EVERY
+                                   * cell is within the budget of the exact path's result.  Decisions are per cell: a result never
+                                   * depends on which cells share its wave, chunk or rank.  Applies where the round-3 ocean kernel
+                                   * runs in its narrow geometry under the convergence stop rule (cf_solver_iteration_path tells);
+                                   * FixedIterations(n), CoefficientBasedFluxes and the sea-ice interface always take the exact path.
+                                   * In this mode the optional `iterations` output is a diagnostic: the number of map evaluations of a
+                                   * certified cell, or CF_CERTIFIED_EXACT_FLAG | (the reference's trip count) for an exact-path cell;
+                                   * the optional friction_velocity / temperature_scale / humidity_scale outputs are the fixed point's. */
+#define CF_SOLVER_PATH_EXACT 0
+#define CF_SOLVER_PATH_CERTIFIED 1
+#define CF_CERTIFIED_EXACT_FLAG 0x100
+#define CF_OPT_CERTIFIED_BUDGET 11 /* the certificate's budget in units of 1e-9 (default 800 = 8e-7; 50 … 1000000 — anything above ≈ 900 gives up the 1e-6 guarantee and is for measurements).  The solve's own
+                                   * convergence error (≤ 2e-8 in the same metric) comes on top: the default keeps every cell
+                                   * within 1e-6 of the exact path, the north star's tolerance; measured worst ≈ 4e-7. */
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path on LDS-tabulated ψ / log / exp.  Accuracy of the tabulated primitives
                                against libm (tests/test_gpu_parity.py::test_device_primitives_accuracy): ψ_m, ψ_h ≤ 5e-12 of
                                max(|ψ|, 1) for |ζ| < 1024 (every state a converging iteration can stop on) and ≤ 2e-10 for
@@ -391,6 +417,9 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 #define CF_SOLVER_TABLES_R2 2 /* diagnostic, not part of the drop-in surface: CF_SOLVER_TABLES with round 2's body of the ocean iteration (A/B measurements) */
 #define CF_SOLVER_TABLES_R2_OUTER 3 /* diagnostic: round 3's iteration inside round 2's kernel structure (start-phase sort; A/B measurements) */
 int cf_set_option(cf_ctx* ctx, int option, int value);
+/* *path = CF_SOLVER_PATH_* that cf_compute_atmosphere_ocean_fluxes / cf_update_state would run with the current
+ * options, flux parameters and chunk geometry (the certified path falls back to the exact one where it does not apply). */
+int cf_solver_iteration_path(cf_ctx* ctx, int* path);
 /* Self-test hook: y[k] = f(x[k]) with the device primitives the solver uses
  * (f: 0 log, 1 exp, 2 cbrt, 3 sqrt, 4 1/x, 5 ψ_m(ζ), 6 ψ_h(ζ)); d_x, d_y device pointers.        */
 int cf_debug_eval(cf_ctx* ctx, int function, int n, const double* d_x, double* d_y);

@@ -13,7 +13,7 @@ STUB = open(os.path.join(ROOT, "climaocean.jl_amd", "julia", "CoFluxMI355X.jl"))
 HEADER = open(os.path.join(ROOT, "include", "coflux.h")).read()
 
 # measurement / self-test hooks a Julia host has no use for
-NOT_BOUND = {"cf_version", "cf_set_flux_params", "cf_set_stream", "cf_set_option", "cf_debug_eval", "cf_debug_chunk_plan", "cf_device_free",
+NOT_BOUND = {"cf_version", "cf_set_flux_params", "cf_set_stream", "cf_debug_eval", "cf_debug_chunk_plan", "cf_device_free",
              "cf_time_stage", "cf_time_copy", "cf_profile_enable", "cf_profile_read", "cf_comm_destroy", "cf_window_upload", "cf_solver_path"}
 
 JL_SIZE = {"Int32": 4, "Cint": 4, "Int64": 8, "Float64": 8, "Float32": 4}
