@@ -346,7 +346,8 @@ def main():
 
     def schedule_for(name):
         return ctx.make_schedule(states, atmos_sets, first_level=0, time_fraction=0.0, time_fraction_increment=inc,
-                                 pipeline=pipeline, halo_backend=backend_code.get(name, abi.HALO_NONE),
+                                 pipeline=abi.PIPELINE_CONTINUING if pipeline else 0,   # one loop over many calls
+                                 halo_backend=backend_code.get(name, abi.HALO_NONE),
                                  halo_rows=ring_rows if name in backend_code else 0,
                                  fold_north=tripolar and rank == world - 1)
 

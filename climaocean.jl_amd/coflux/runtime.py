@@ -348,7 +348,7 @@ class FluxContext:
         at = (abi.ExchangeFields * len(atmos_sets))(*[self.exchange_struct(a) for a in atmos_sets])
         sch.struct_size = C.sizeof(abi.RunSchedule)
         sch.n_ocean_states, sch.ocean_states = len(ocean_states), oc
-        sch.n_atmos_sets, sch.atmos, sch.pipeline = len(atmos_sets), at, 1 if pipeline else 0
+        sch.n_atmos_sets, sch.atmos, sch.pipeline = len(atmos_sets), at, int(pipeline)   # False / True (within the call) / abi.PIPELINE_CONTINUING
         sch.first_level, sch.halo_backend, sch.halo_rows = first_level, halo_backend, halo_rows
         sch.fold_north = 1 if fold_north else 0
         sch.time_fraction, sch.time_fraction_increment = float(time_fraction), float(time_fraction_increment)

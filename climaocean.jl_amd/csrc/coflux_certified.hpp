@@ -31,6 +31,11 @@ namespace coflux {
 
 // iterations reported for a cell the certified path sent down the exact path: CF_CERTIFIED_EXACT_FLAG | reference trips
 constexpr int CERT_EXACT_FLAG = 0x100;
+// Thresholds of the iteration, compile-time (each would otherwise hold scalar registers across the loop, which the
+// kernel does not have: 44 v_readlane per trip were measured with them in LoopParams).  Accept: relative residual below
+// 2⁻²³ ≈ 1.2e-7 (a double whose low word is zero: a 32-bit literal operand); at most ten evaluations.
+constexpr double CERT_ACCEPT = 0x1p-23;
+constexpr int CERT_MAX_EVALS = 10;
 
 // All 64 lanes of a wave must call this together.  `active` lanes solve; on return `need_exact` is set for the active
 // lanes that are not certified (their Scales are meaningless).  Scales.it = evaluations of the map.
@@ -48,13 +53,13 @@ __device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, cons
     // Anderson history, FP32: s = the step that led to the current state, fp = the previous residual, (dg2, df2) = the
     // older pair of differences of G and of the residual; ff = the residual of the last evaluation
     float s_u = 0.f, s_c = 0.f, fp_u = 0.f, fp_c = 0.f, dg2_u = 0.f, dg2_c = 0.f, df2_u = 0.f, df2_c = 0.f, ff_u = 0.f, ff_c = 0.f;
-    bool done = false;
+    bool done = false, failed = false;
     int it = 0;
     double log_A_q = L.log_A_q;
     asm("" : "+v"(log_A_q));
     for (int trip = 0;; ++trip) {
         const bool go = active && !done;
-        if (trip >= L.cert_max_evals || __builtin_amdgcn_ballot_w64(go) == 0ull) break;
+        if (trip >= CERT_MAX_EVALS || __builtin_amdgcn_ballot_w64(go) == 0ull) break;
         if (go) {
             // ---- one evaluation of the reference's map at (u★, χ): mo_iterate_lean's expressions ----
             const double kb = chi * B;
@@ -76,14 +81,28 @@ __device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, cons
             double Du = (L.log_h - log_lu) - ps.x;
             double Dq = (L.log_h - log_lq) - ps.y;
             if constexpr (!COARE) {
+                // ψ at the roughness-length arguments.  From the neutral start the iterates stay at |ℓ/L★| < 2⁻¹⁰ in all but
+                // ≈ 0.4 % of the cells (the exact path needs the general table for its first two iterates from u★ = 1e-4):
+                // the small-argument polynomials for every lane, and — a wave-level branch taken only where a lane needs it —
+                // the general table where both arguments share a segment (one chain of 16-byte reads, two accumulators:
+                // this loop cannot hold psi_eval_two's fourteen coefficient registers).  A lane whose arguments fall into
+                // different segments (|ℓ/L★| ≳ 1e-2) is not certified: the exact path solves it.
                 const double zu = lu * inv_L, zq = fexp_lean(tab, log_lq) * inv_L;
-                double2 pl;
-                if (fabs(zu) < SMALL_Z0 && fabs(zq) < SMALL_Z0) {
-                    asm volatile("" ::: "memory");
-                    pl = psi_small_mh(tab, inv_L < 0.0, zu, zq);
-                } else {
-                    asm volatile("" ::: "memory");
-                    pl = psi_eval_two(tab, psi_arg(zu), psi_arg(zq));
+                const bool small = fabs(zu) < SMALL_Z0 && fabs(zq) < SMALL_Z0;
+                double2 pl = psi_small_mh(tab, inv_L < 0.0, zu, zq);
+                if (__builtin_amdgcn_ballot_w64(!small) != 0ull) {
+                    const PsiArg a = psi_arg(zu), b = psi_arg(zq);
+                    const double2* cf = reinterpret_cast<const double2*>(tab) + (size_t)(a.side * (PSI_DEG + 1)) * PSI_SEG + a.k;
+                    double2 v = cf[PSI_DEG * PSI_SEG];
+                    double pm = v.x, ph = v.y;
+#pragma unroll
+                    for (int j = PSI_DEG - 1; j >= 0; --j) {
+                        v = cf[j * PSI_SEG];
+                        pm = __builtin_fma(pm, a.t, v.x);
+                        ph = __builtin_fma(ph, b.t, v.y);
+                    }
+                    failed |= !small && a.k != b.k;
+                    if (!small) pl = make_double2(pm, ph);
                 }
                 Du += pl.x;
                 Dq += pl.y;
@@ -122,7 +141,9 @@ __device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, cons
             us = gu - (double)cu;
             chi = gc - (double)cc;
             ++it;
-            if (aa && res < L.cert_accept) {
+            if (failed) {
+                done = true;
+            } else if (aa && res < CERT_ACCEPT) {
                 done = true;  // the extrapolated state is the answer; the history stays as it is for the certificate
             } else {
                 if (trip >= 1) {
@@ -135,8 +156,17 @@ __device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, cons
                 fp_c = ff_c;
                 s_u = ff_u - cu;
                 s_c = ff_c - cc;
+                // 1/u★ of the extrapolated state u★ = G_u (1 − t), t = c_u / G_u: 1/G_u is at hand.  The first Anderson step
+                // may be large (one reciprocal); from then on |t| ≲ 1e-2 and three terms of the series leave t⁴ — an
+                // inconsistency of the evaluation point that vanishes with the corrections, not an error of the map
                 ius = gius;
-                if (trip >= 2) ius = aa ? frcp1(us) : gius;
+                if (trip == 2) {
+                    ius = aa ? frcp1(us) : gius;
+                } else if (trip > 2) {
+                    const double t = (double)cu * gius;
+                    ius = __builtin_fma(gius * t, __builtin_fma(t, t + 1.0, 1.0), gius);
+                    if (fabs(t) > 0x1p-4) ius = frcp1(us);
+                }
             }
         }
     }
@@ -168,7 +198,7 @@ __device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, cons
         bound = fmaxf(bound, (kd_c * eq) * __builtin_amdgcn_rcpf(fmaxf(kd_c * ux, 1.f)));
         bound = fmaxf(bound, (kd_v * eq) * __builtin_amdgcn_rcpf(fmaxf(kd_v * ux, 1.f)));
         bound = fmaxf(bound, (kd_f * eq) * __builtin_amdgcn_rcpf(fmaxf(kd_f * ux, 1e-6f)));
-        certified = done && okJ && bound <= (float)L.cert_budget;  // (NaN anywhere: not certified)
+        certified = done && !failed && okJ && bound <= (float)L.cert_budget;  // (NaN anywhere: not certified)
     }
     need_exact = active && !certified;
     return Scales{us, chi * c.dtheta, chi * c.dq, it, it};

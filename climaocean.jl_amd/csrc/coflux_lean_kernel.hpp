@@ -83,7 +83,7 @@ struct LeanGeom {
 static_assert(LeanGeom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow lean solver workgroups must fit the CU's 160 KB of LDS");
 static_assert(LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
 #ifndef CF_SKIP_LDS_ASSERT
-static_assert(CF_LEAN_WAVES == 3 || LeanGeom<AO_BLOCK>::LDS_BYTES <= 40960, "four narrow lean workgroups per CU: 160 KB / 4 in 1280-byte granules");
+static_assert(CF_LEAN_WAVES <= 3 || LeanGeom<AO_BLOCK>::LDS_BYTES <= 40960, "four narrow lean workgroups per CU: 160 KB / 4 in 1280-byte granules");
 #endif
 
 // zero_interface_state of a land cell: all fluxes 0, T = 0 K (and, in the fused form, zero net fluxes inside the interior)
@@ -425,6 +425,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
         for (;;) {
             if constexpr (CERT) {
                 if (!straggling && start >= nwet) {
+                    LEAN_STAMP(4);  // (stamped builds: the end phase of a certified wave is its share of the exact-path queue)
                     // no batch left for this wave.  The last wave of the workgroup to get here works the queue off: every
                     // other wave has made its entries before it counted itself out (LDS operations of a wave stay in order)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -450,8 +451,10 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             if (in_range) gstore(opaque(K)->F.Ts, (unsigned)cell_of(start) * 8u, c.Ts - T_offset);
             const double Qs_kept = raw.Qs, Ql_kept = raw.Ql, Mp_kept = raw.Mp;  // (dead unless FUSE_INTERP)
 #if CF_LEAN_PREFETCH
-            const int next = claim();
-            if (next < nwet) raw = request(next);
+            int next;
+            if constexpr (CERT) next = straggling ? start + 64 : claim();
+            else next = claim();
+            if (next < limit) raw = request(next);
 #endif
 #ifdef CF_LEAN_STAMPS
             const unsigned long long t_it = __builtin_readcyclecounter();
@@ -461,7 +464,11 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             if constexpr (CERT) {
                 bool exact = in_range;  // a batch from the queue: every lane takes the reference's iteration
                 if (!straggling) {
-                    s = mo_iterate_certified<COARE>(L, c, tab, in_range, exact);
+                    // (the iteration's scalars are read from the argument block HERE, per batch: held for the kernel's
+                    // lifetime beside the exact iteration's and the batch loop's they do not fit the scalar registers —
+                    // 36 v_readlane per trip of the iteration were measured that way)
+                    const LoopParams Lc = kread(&opaque(K)->L);
+                    s = mo_iterate_certified<COARE>(Lc, c, tab, in_range, exact);
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(exact);
                     if (m) {
                         int slot = 0;
@@ -475,7 +482,8 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(exact) != 0ull) {
-                    const Scales e = mo_iterate_lean<COARE>(L, c, tab, exact);
+                    const LoopParams Le = kread(&opaque(K)->L);
+                    const Scales e = mo_iterate_lean<COARE>(Le, c, tab, exact);
                     if (exact) {
                         s = e;
                         s.it |= CERT_EXACT_FLAG;
@@ -552,7 +560,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
         if (tid < 4) counters[tid] = 0;
         __syncthreads();
     }
-    LEAN_STAMP(4);
+    if constexpr (!CERT) LEAN_STAMP(4);
     LEAN_STAMP_SET(6, stamp_iter | (stamp_trips << 40));
     LEAN_STAMP_SET(7, stamp_batches | ((unsigned long long)(have_list ? 1 : 0) << 32) | ((unsigned long long)(sorting ? 1 : 0) << 33));
     // ---- end phase: the list in next call's order (counting sort by this call's trip counts, longest first) --------

@@ -253,6 +253,7 @@ int cf_time_steps(cf_ctx* ctx, int64_t first_step, int nsteps, const cf_run_sche
         return fail(ctx, CF_ERR_INVALID, "cf_run_schedule.struct_size = %d, library expects %zu", S->struct_size, sizeof(cf_run_schedule));
     if (nsteps < 0 || first_step < 0 || S->n_ocean_states < 1 || !S->ocean_states || !S->atmos)
         return fail(ctx, CF_ERR_INVALID, "cf_time_steps: bad schedule");
+    if (S->pipeline < 0 || S->pipeline > CF_PIPELINE_CONTINUING) return fail(ctx, CF_ERR_INVALID, "cf_time_steps: pipeline = %d", S->pipeline);
     if (S->n_atmos_sets < 1 || S->n_atmos_sets > 2 || (S->pipeline && S->n_atmos_sets != 2))
         return fail(ctx, CF_ERR_INVALID, "cf_time_steps: %d exchange-field sets (pipelining needs 2)", S->n_atmos_sets);
     if (!(S->time_fraction >= 0.0) || !(S->time_fraction_increment >= 0.0) || S->first_level < 0 || S->first_level >= src->n_levels)
@@ -319,10 +320,12 @@ int cf_time_steps(cf_ctx* ctx, int64_t first_step, int nsteps, const cf_run_sche
         if (S->fold_north) CHECK(cf_fold_north_halo(ctx, rows, fold_loc, fold_sign, 4, ctx->grid.ring + 1));
         const cf_atmos_source s = source_at(step);
         const cf_exchange_fields* a = &S->atmos[S->n_atmos_sets == 2 ? step % 2 : 0];
-        if (S->pipeline) {
-            // (also on the last step of this call: the loop goes on in the next call, which finds the state pending; a
-            // caller that stops here has one unused interpolation in the other exchange set)
-            // queued BEFORE this step's kernels: the set it overwrites was last read by the previous step's net fluxes
+        // CF_PIPELINE_WITHIN_CALL: nothing beyond this call's steps is read or written.  CF_PIPELINE_CONTINUING: the last
+        // step also requests step first_step + nsteps (the loop goes on in the next call, which finds that state pending
+        // by its key; the caller promises the source levels of that step are resident and final, and that the other
+        // exchange set is not read after this call's last step: coflux.h).
+        // queued BEFORE this step's kernels: the set it overwrites was last read by the previous step's net fluxes
+        if (S->pipeline && (step + 1 < first_step + nsteps || S->pipeline == CF_PIPELINE_CONTINUING)) {
             const cf_atmos_source sn = source_at(step + 1);
             CHECK(cf_prefetch_atmosphere_state(ctx, &sn, w, &S->atmos[(step + 1) % 2]));
         }

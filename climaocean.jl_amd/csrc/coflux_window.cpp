@@ -91,6 +91,15 @@ int cf_window_commit(cf_window* w, int32_t slot, int64_t time_index) {
     cf_ctx* ctx = w->ctx;
     if (slot < 0 || slot >= w->n_slots) return fail(ctx, CF_ERR_INVALID, "slot %d outside [0, %d)", slot, w->n_slots);
     HIP_TRY(ctx, hipSetDevice(ctx->device));  // one process may drive several contexts / devices
+    // An interpolation requested AHEAD that reads this slot (cf_prefetch_atmosphere_state, cf_time_steps with
+    // CF_PIPELINE_CONTINUING) was computed — or would be — from the snapshot this commit replaces: it is void.  The step it
+    // was meant for then interpolates again, from the window's current contents.
+    for (auto& p : ctx->prefetch)
+        if (p.valid && (p.level1 == slot || p.level2 == slot)) {
+            if (!p.on_main && p.done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p.done, 0));  // its writes must not race the redo
+            p.valid = false;
+        }
+    if (ctx->deferred.valid && (ctx->deferred.src.level1 == slot || ctx->deferred.src.level2 == slot)) ctx->deferred.valid = false;
     // the device copy of this slot may only be overwritten once every interpolation already queued has read it
     HIP_TRY(ctx, hipEventRecord(w->ev_compute, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(w->copy_stream, w->ev_compute, 0));

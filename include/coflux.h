@@ -769,9 +769,21 @@ int cf_fold_north_halo(cf_ctx* ctx, double* const* d_fields, const int* location
  * without returning to the host language — per step (optional halo rows) → cf_update_state.  What varies from step
  * to step is what varies in a coupled run: the clock (the JRA55 time fraction ñ advances by Δt/Δt_snapshot and the
  * bracketing snapshots move through the window) and the ocean surface state (step s reads ocean_states[s mod n]).
- * With `pipeline` = 1 the atmosphere state of step s+1 is interpolated on the context's auxiliary stream while the
- * solver of step s runs (the prescribed atmosphere does not depend on the ocean); this needs two sets of exchange
- * fields, step s uses atmos[s mod 2].  All launches are stream ordered; nothing synchronises with the host.       */
+ * With `pipeline` ≠ 0 the atmosphere state of step s+1 is interpolated while the solver of step s runs (on the
+ * auxiliary stream, or inside the step's launches: CF_OPT_MERGED_PREFETCH; the prescribed atmosphere does not depend on
+ * the ocean); this needs two sets of exchange fields, step s uses atmos[s mod 2].
+ *   CF_PIPELINE_WITHIN_CALL (1): only steps of this call are prefetched — the call reads the source at the levels of
+ *     steps first_step … first_step + nsteps − 1 and nothing else, and leaves the other exchange set as the last-but-one
+ *     step left it.
+ *   CF_PIPELINE_CONTINUING (2): the last step also requests step first_step + nsteps, for a loop that goes on in the
+ *     next call (which recognises the pending state by its output set, levels and time fraction).  The caller
+ *     guarantees that the source slots of that step are resident and FINAL when this call is made (a sliding window
+ *     must not recommit them in between — cf_window_commit / an upload into a level a pending request reads voids it
+ *     silently), and that exchange set (first_step + nsteps) mod 2 is not read after this call's last step: it is
+ *     overwritten.  A caller that stops after such a call has one unused interpolation in that set.
+ * All launches are stream ordered; nothing synchronises with the host.       */
+#define CF_PIPELINE_WITHIN_CALL 1
+#define CF_PIPELINE_CONTINUING 2
 #define CF_HALO_NONE 0
 #define CF_HALO_RCCL 1
 #define CF_HALO_PEER 2
@@ -780,7 +792,7 @@ typedef struct cf_run_schedule {
     int32_t n_ocean_states;          /* ≥ 1 */
     const cf_ocean_surface* ocean_states;
     int32_t n_atmos_sets;            /* 1, or 2 with pipeline */
-    int32_t pipeline;
+    int32_t pipeline;                /* 0, CF_PIPELINE_WITHIN_CALL or CF_PIPELINE_CONTINUING */
     const cf_exchange_fields* atmos; /* n_atmos_sets entries */
     int32_t first_level;             /* memory level of snapshot n₁ at step 0; levels advance cyclically */
     int32_t halo_backend;            /* CF_HALO_* */

@@ -380,6 +380,54 @@ def proto32_report(name, fluxes, rel=True, **kw):
               % (name, tol_a, n[wet].mean(), n[wet].max(), np.bincount(n[wet], minlength=9)[3:11].tolist(), bm.mean(), 100 * fl.sum() / wet.sum(), (n >= 10)[wet].sum(), e_fp[ok].max(), e_rf[ok].max()))
 
 
+def bound_refined(c, J, x, tol=1e-8, r_pow=1.5, eps_sub=1e-3):
+    """Directional truncation bound: where J has real, separated eigenvalues (lam2^2 <= |lam1|^(2 r_pow)) the reference's
+    last drift lies along the dominant eigenvector up to eps_sub; elsewhere the worst case over all directions."""
+    worst = bound_from_J(c, J, x, tol)
+    a, b, cc, d = J[0, 0], J[0, 1], J[1, 0], J[1, 1]
+    tr, det = a + d, a * d - b * cc
+    disc = tr * tr - 4 * det
+    sq = np.sqrt(np.maximum(disc, 0))
+    l1 = np.where(tr >= 0, (tr + sq) / 2, (tr - sq) / 2)      # dominant (larger |.|)
+    with np.errstate(all='ignore'):
+        l2 = np.where(l1 != 0, det / np.where(l1 != 0, l1, 1), 0)
+    sep = (disc > 0) & (l2 * l2 <= np.abs(l1) ** (2 * r_pow)) & (np.abs(l1) < 0.95)
+    # eigenvector of l1: (b, l1 - a) or (l1 - d, cc): the better conditioned
+    v1a = np.array([b, l1 - a]); v1b = np.array([l1 - d, cc])
+    use_a = (np.abs(v1a[0]) + np.abs(v1a[1])) >= (np.abs(v1b[0]) + np.abs(v1b[1]))
+    v = np.where(use_a, v1a, v1b)
+    S = np.maximum(c['Sabs'], 1e-300)
+    nw = np.abs(v[0]) + S * np.abs(v[1])
+    with np.errstate(all='ignore'):
+        s = tol / np.where(nw > 0, nw, 1)
+        mu = np.abs(l1 / (l1 - 1))
+    u, chi = x
+    eu = mu * s * np.abs(v[0])
+    eq = mu * s * np.abs(chi * v[0] + u * v[1])
+    out = c['rho'] * 2 * u * eu / np.maximum(c['rho'] * u * u, 1e-3)
+    for K, D, sc in ((c['rho'] * c['cpm'], c['dth'], 1.0), (c['rho'] * c['Lv'], c['dq'], 1.0), (c['rho'], c['dq'], 1e-6)):
+        flux = np.abs(K * D * u * chi)
+        out = np.maximum(out, np.abs(K * D) * eq / np.maximum(flux, sc))
+    refined = out + eps_sub * worst
+    ok = sep & (nw > 0) & np.isfinite(refined)
+    return np.where(c['wet'], np.where(ok, np.minimum(refined, worst), worst), 0), sep
+
+
+def refined_report(name, fluxes):
+    c = setup(fluxes); wet = c['wet']
+    us_r, chi_r, n_r = reference_path(c)
+    xs = fixed_point(c, np.array([us_r, chi_r]))
+    J = jac_fd(c, xs)
+    e_ref = flux_err(c, (us_r, chi_r), (xs[0], xs[1]))
+    w = bound_from_J(c, J, xs)
+    for r_pow in (1.25, 1.5, 2.0):
+        b, sep = bound_refined(c, J, xs, r_pow=r_pow, eps_sub=(1e-6) ** (r_pow - 1))
+        viol = (e_ref > b)[wet].sum()
+        print('%s r_pow %.2f: separated %.1f%% of wet cells; violations (actual > refined bound) %d, worst actual/bound %.3f' % (name, r_pow, 100 * sep[wet].mean(), viol, (e_ref / np.maximum(b, 1e-300))[wet].max()))
+        for budget in (2e-7, 4e-7, 8e-7):
+            print('    budget %.0e: flagged worst-case %.3f%%  refined %.4f%%  (x1.25 safety: %.4f%%); actual beyond: %.1f ppm' % (budget, 100 * (w > budget)[wet].mean(), 100 * (b > budget)[wet].mean(), 100 * (1.25 * b > budget)[wet].mean(), 1e6 * (e_ref > budget)[wet].mean()))
+
+
 if __name__ == '__main__':
     mode = sys.argv[2] if len(sys.argv) > 2 else 'bound'
     cfgs = (('default', ic.SimilarityTheoryFluxes), ('corrected', ic.corrected_atmosphere_ocean_fluxes))
@@ -388,3 +436,4 @@ if __name__ == '__main__':
         elif mode == 'anatomy': flag_anatomy(name, mk())
         elif mode == 'proto': proto_report(name, mk())
         elif mode == 'proto32': proto32_report(name, mk())
+        elif mode == 'refined': refined_report(name, mk())

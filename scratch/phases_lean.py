@@ -15,6 +15,8 @@ for label in cfgs:
     if label.startswith("fixed"): fl.solver_stop_criteria = ic.FixedIterations(int(label[5:]))
     ctx = FluxContext(nx, ny, h, h, ic.flux_params(fl))
     if os.environ.get("CHUNK"): ctx.set_option(abi.OPT_AO_CHUNK, int(os.environ["CHUNK"]))
+    if os.environ.get("CERT"):   # certified solver path with this budget (units of 1e-9)
+        ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED); ctx.set_option(abi.OPT_CERTIFIED_BUDGET, int(os.environ["CERT"]))
     ocean = {k: ctx.to_device(ocean_np[k]) for k in ("T", "S", "u", "v", "mask")}
     src = {k: ctx.to_device(v) for k, v in src_np.items()}
     w = dict(separable=True, fi=ctx.to_device(fi), fj=ctx.to_device(fj), latitude=ctx.to_device(phi))
