@@ -391,6 +391,12 @@ class FluxContext:
         buf = C.create_string_buffer(unique_id, abi.COMM_ID_BYTES)
         self._check(self.lib.cf_comm_init(self._h, buf, rank, nranks), "cf_comm_init")
 
+    def comm_count(self):
+        """(nranks, rank, device) as RCCL itself reports them for the communicator of comm_init (cf_comm_count)."""
+        n, r, d = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.cf_comm_count(self._h, C.byref(n), C.byref(r), C.byref(d)), "cf_comm_count")
+        return n.value, r.value, d.value
+
     def halo_exchange_rows(self, tensors, rows=1):
         arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         self._check(self.lib.cf_halo_exchange_rows(self._h, arr, len(tensors), rows), "cf_halo_exchange_rows")

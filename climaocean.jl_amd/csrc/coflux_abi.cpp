@@ -995,6 +995,9 @@ static int load_rccl(cf_ctx* ctx) {
     SYM(Recv, "ncclRecv");
     SYM(GetErrorString, "ncclGetErrorString");
     SYM(AllReduce, "ncclAllReduce");
+    SYM(CommCount, "ncclCommCount");
+    SYM(CommUserRank, "ncclCommUserRank");
+    SYM(CommCuDevice, "ncclCommCuDevice");
 #undef SYM
     g_rccl.handle = h;
     return CF_OK;
@@ -1025,6 +1028,19 @@ int cf_comm_init(cf_ctx* ctx, const void* id128, int rank, int nranks) {
     NCCL_TRY(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, id, rank));
     ctx->rank = rank;
     ctx->nranks = nranks;
+    return CF_OK;
+}
+
+int cf_comm_count(cf_ctx* ctx, int* nranks, int* rank, int* device) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    if (!ctx->comm) return fail(ctx, CF_ERR_COMM, "cf_comm_init has not been called");
+    int n = 0, r = -1, d = -1;
+    NCCL_TRY(ctx, g_rccl.CommCount(ctx->comm, &n));
+    NCCL_TRY(ctx, g_rccl.CommUserRank(ctx->comm, &r));
+    NCCL_TRY(ctx, g_rccl.CommCuDevice(ctx->comm, &d));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (device) *device = d;
     return CF_OK;
 }
 

@@ -718,6 +718,10 @@ int cf_profile_read(cf_ctx* ctx, int kernel, double* avg_ms, int* records);
 int cf_comm_unique_id(void* id128);
 int cf_comm_init(cf_ctx* ctx, const void* id128, int rank, int nranks);
 int cf_comm_destroy(cf_ctx* ctx);
+/* RCCL's own view of the communicator cf_comm_init made: the number of ranks it connected (ncclCommCount), this rank's index
+ * (ncclCommUserRank) and the HIP device it sits on (ncclCommCuDevice); any of the three may be NULL.  What a launcher
+ * prints beside its own WORLD_SIZE so that a run whose ranks never met shows (bench.py: config.rccl_comm_ranks).       */
+int cf_comm_count(cf_ctx* ctx, int* nranks, int* rank, int* device);
 /* Exchange `rows` boundary rows of `nfields` ocean-grid arrays with the south (rank−1) and north
  * (rank+1) neighbours: my first/last interior rows → their north/south halos.  With ring = 1 the kernels
  * also compute the ring row j = ny, whose cell-centre v needs the y-face at j = ny + 1: exchange

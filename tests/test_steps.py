@@ -372,8 +372,45 @@ def test_bench_n_rank_code_path_rehearsal():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 40 and "rehearsal" in line
-    assert line["config"]["halo_verified"] == ["peer"] and line["config"]["rows_per_rank"] == 60
+    assert line["config"]["halo_verified"] == {"peer": True} and line["config"]["rows_per_rank"] == 60
     assert line["value"] > 0 and line["config"]["step_loop"].startswith("cf_time_steps")
+    # what a first contact with N devices must show: per-rank step times, both solver paths, how many
+    # steps ran before the timed region, the spread of the repetitions
+    assert len(line["ms_per_step_by_rank"]) == 2 and line["repetitions"] == 3 and len(line["ms_per_step_spread"]) == 2
+    assert line["untimed_steps"] >= line["settle_steps"] + 5 and set(line["solver_paths_ms_per_step"]) == {"exact", "certified"}
+    assert line["config"]["solver_path"] in ("exact", "certified") and "rccl_comm_ranks" in line["config"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", ["latlon", "tripolar"])
+def test_bench_selftest_two_ranks_sharing_the_device(grid):
+    """bench.py --gpus 2 --selftest: halo verification, ten steps of cf_time_steps with halo rows, the gathered surface
+    against the single-domain oracle — the diagnosable first contact with a multi-GPU node, rehearsed with two processes
+    on this box's one device (peer-direct rows over HIP IPC)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    size = ["--nx", "360", "--ny", "120"] if grid == "latlon" else ["--nx", "360", "--ny", "180", "--grid", "tripolar"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--selftest"] + size,
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["selftest"] == "ok" and line["stages"][0] == "halo_backends" and line["stages"][-1] == "compare_with_oracle"
+    assert max(line["worst_scaled_error_vs_oracle"].values()) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_bench_selftest_names_the_failing_stage():
+    """A halo backend that cannot work here (RCCL between two processes sharing one device is filtered out, so asking for it
+    leaves no backend) must end with a non-zero exit and the stage's name in the JSON line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--selftest", "--halo-backend", "rccl",
+                        "--nx", "360", "--ny", "120"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["selftest"] == "failed" and line["failed_stage"] == "halo_backends"
 
 
 def test_sea_ice_step_with_tail_workgroups_is_bitwise_the_plain_step():
