@@ -6,7 +6,7 @@ the value the library reports and that every declared symbol is exported.
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 COMM_ID_BYTES = 128
 PEER_HANDLE_BYTES = 64
 HALO_NONE, HALO_RCCL, HALO_PEER = 0, 1, 2
@@ -77,6 +77,7 @@ class FluxParams(C.Structure):
                 ("velocity_difference", C.c_int32), ("mask_kind", C.c_int32),
                 ("tolerance", C.c_double), ("von_karman", C.c_double),
                 ("gustiness_parameter", C.c_double), ("minimum_gustiness", C.c_double),
+                ("shear_gustiness_coefficient", C.c_double),
                 ("similarity_profile_floor", C.c_double),
                 ("momentum_roughness", Roughness), ("temperature_roughness", Roughness),
                 ("water_vapor_roughness", Roughness),

@@ -136,6 +136,7 @@ class SimilarityTheoryFluxes:
     von_karman_constant: float = 0.4
     gustiness_parameter: float = 1.0
     minimum_gustiness: float = 0.2          # UNVERIFIED default (COARE); 0.5 in ":corrected", :40,44
+    shear_gustiness_coefficient: float = 0.0   # c of the shear-aware form (launch.sh:67-72): 0 = off, see include/coflux.h
     stability_functions: StabilityFunctions = field(default_factory=atmosphere_ocean_stability_functions)
     momentum_roughness_length: Union[float, MomentumRoughnessLength] = field(default_factory=MomentumRoughnessLength)
     temperature_roughness_length: Union[float, ScalarRoughnessLength] = field(default_factory=ScalarRoughnessLength)
@@ -184,6 +185,16 @@ def corrected_atmosphere_ocean_fluxes(FT=float, minimum_gustiness=0.5):
             wave_formulation=WindDependentWaveFormulation(), air_kinematic_viscosity=nu),
         temperature_roughness_length=ScalarRoughnessLength(air_kinematic_viscosity=nu),
         water_vapor_roughness_length=ScalarRoughnessLength(air_kinematic_viscosity=nu))
+
+
+def shear_aware_atmosphere_ocean_fluxes(FT=float, shear_gustiness_coefficient=0.04, minimum_gustiness=0.5):
+    """The `:shear_aware` flux configuration the reference's launcher describes (experiments/OMIPSimulations/scripts/
+    launch.sh:67-72, emitted at :350): the `:corrected` fluxes with the Mahrt–Sun (1995) / Edson (2013) gustiness
+    U_G² = (β w★)² + (c |Δu|)² + U_G,0², c = 0.04.  The reference's build_coupled_model does not accept the symbol
+    (omip_simulation.jl:160); models.build_coupled_model takes it only with allow_shear_aware=True."""
+    f = corrected_atmosphere_ocean_fluxes(FT, minimum_gustiness=minimum_gustiness)
+    f.shear_gustiness_coefficient = float(shear_gustiness_coefficient)
+    return f
 
 
 def corrected_atmosphere_sea_ice_fluxes(FT=float):
@@ -424,6 +435,7 @@ def flux_params(fluxes: Optional[SimilarityTheoryFluxes] = None, *,
     p.von_karman = f.von_karman_constant
     p.gustiness_parameter = f.gustiness_parameter
     p.minimum_gustiness = f.minimum_gustiness
+    p.shear_gustiness_coefficient = getattr(f, "shear_gustiness_coefficient", 0.0)
     p.similarity_profile_floor = f.similarity_profile_floor
     p.momentum_roughness = _roughness_block(f.momentum_roughness_length, scalar=False)
     p.temperature_roughness = _roughness_block(f.temperature_roughness_length, scalar=True)

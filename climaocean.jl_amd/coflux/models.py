@@ -486,11 +486,14 @@ def omip_forcing(arch, sea_ice, *, forcing_dir, start_date, end_date, repeat_yea
 
 
 def build_coupled_model(ocean, sea_ice, atmosphere, radiation, land, flux_configuration, *, velocity_formulation="relative",
-                        ocean_minimum_salinity=1):
+                        ocean_minimum_salinity=1, allow_shear_aware=False, shear_gustiness_coefficient=0.04):
     """build_coupled_model(ocean, sea_ice, atmosphere, radiation, land, flux_configuration; velocity_formulation = :relative,
     ocean_minimum_salinity = 1) — /root/reference/src/OMIPConfigurations/omip_simulation.jl:115-164, the same three-way
     switch and the same error strings.  Options for `flux_configuration`: "default", "corrected", "ncar" (Julia symbols
-    as strings); for `velocity_formulation`: "relative", "wind"."""
+    as strings); for `velocity_formulation`: "relative", "wind".  With allow_shear_aware=True (not a reference keyword)
+    "shear_aware" — the configuration launch.sh:67-72,350 describes and the reference's own switch rejects — builds the
+    `:corrected` interfaces with the shear-aware gustiness (c = shear_gustiness_coefficient); without the flag it raises
+    the reference's error."""
     flux_configuration = str(flux_configuration).lstrip(":")
     velocity_formulation = str(velocity_formulation).lstrip(":")
     albedo = getattr(getattr(radiation, "sea_ice_surface", None), "albedo", None)
@@ -509,6 +512,9 @@ def build_coupled_model(ocean, sea_ice, atmosphere, radiation, land, flux_config
         ao, ai = ic.corrected_atmosphere_ocean_fluxes(), ic.corrected_atmosphere_sea_ice_fluxes()
     elif flux_configuration == "ncar":
         ao, ai = ic.ncar_atmosphere_ocean_fluxes(), ic.ncar_atmosphere_sea_ice_fluxes()
+    elif flux_configuration == "shear_aware" and allow_shear_aware:
+        ao = ic.shear_aware_atmosphere_ocean_fluxes(shear_gustiness_coefficient=shear_gustiness_coefficient)
+        ai = ic.corrected_atmosphere_sea_ice_fluxes()
     else:
         raise ValueError(f"Unknown flux_configuration: {flux_configuration}. Options: :default, :corrected, :ncar")
     interfaces = ComponentInterfaces(atmosphere, ocean, sea_ice, atmosphere_ocean_fluxes=ao, atmosphere_sea_ice_fluxes=ai,

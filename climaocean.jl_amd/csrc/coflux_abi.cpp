@@ -99,6 +99,13 @@ static int lower_params(cf_ctx* ctx, const cf_flux_params* p, DevParams* d) {
     D.kappa = p->von_karman;
     D.beta_gust = p->gustiness_parameter;
     D.min_gust = p->minimum_gustiness;
+    D.wind2_scale = 1.0;
+    D.wind2_add = 0.0;
+    if (p->shear_gustiness_coefficient > 0.0) {  // U_G² = (β w★)² + (c|Δu|)² + U_G,min²: the three terms add, nothing is floored
+        D.wind2_scale = 1.0 + p->shear_gustiness_coefficient * p->shear_gustiness_coefficient;
+        D.wind2_add = p->minimum_gustiness * p->minimum_gustiness;
+        D.min_gust = 0.0;
+    }
     D.profile_floor = p->similarity_profile_floor;
     D.tol = p->tolerance;
     D.h_ref = p->reference_height;
@@ -333,6 +340,7 @@ int cf_default_flux_params(cf_flux_params* p) {
     p->von_karman = 0.4;
     p->gustiness_parameter = 1.0;
     p->minimum_gustiness = 0.2;
+    p->shear_gustiness_coefficient = 0.0;
     p->similarity_profile_floor = 1.0;
     const double nu0 = 1.326e-5;
     cf_roughness m{};

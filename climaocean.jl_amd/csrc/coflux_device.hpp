@@ -26,7 +26,10 @@ struct DevParams {
     // sea water (Raoult)
     double sw_inv_w, sw_inv_mu;
     // similarity theory
-    double kappa, beta_gust, min_gust, profile_floor, tol;
+    double kappa, beta_gust, min_gust, profile_floor, tol;  // min_gust: the FLOOR of the gust term — U_G,min, or 0 in the shear-aware form
+    // U² = wind2_scale·|Δu|² + wind2_add + max((β w★)², min_gust²): (1, 0) by default; shear-aware gustiness
+    // (cf_flux_params.shear_gustiness_coefficient c > 0): (1 + c², U_G,min²) with min_gust = 0
+    double wind2_scale, wind2_add;
     double h_ref, h_bl, g, inv_g, log_h;
     int32_t similarity_form, stability, stop_kind, maxiter, velocity_difference, mask_kind;
     cf_roughness rm, rt, rq;
@@ -266,7 +269,7 @@ __device__ __forceinline__ CellFluxes solve_cell(const DevParams& P, double ua, 
             double bstar = g_over_Tv * (ts * b_theta + b_q * qq);
             double Jb = -us * bstar;
             double Ug = fmax(P.beta_gust * cbrt(fmax(Jb, 0.0) * P.h_bl), P.min_gust);
-            double U = sqrt(dU2 + Ug * Ug);
+            double U = sqrt(fma(dU2, P.wind2_scale, P.wind2_add) + Ug * Ug);
 
             double lu = momentum_roughness(P.rm, P.inv_g, us, alpha, nu_m);
             double lq = scalar_roughness(P.rq, lu, us, nu_q);

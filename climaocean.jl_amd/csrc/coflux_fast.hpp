@@ -428,6 +428,9 @@ __device__ __forceinline__ CellConsts cell_prologue(const DevParams& P, double m
     c.dv = dv;
     c.dU2 = du * du + dv * dv;
     c.dU = fsqrt(c.dU2);
+    // from here on dU2 is what enters the wind-speed scale (DevParams::wind2_*: the shear-aware gustiness folds its
+    // (c|Δu|)² + U_G,min² in; (1, 0) otherwise — the multiply-add is then exact)
+    c.dU2 = __builtin_fma(c.dU2, P.wind2_scale, P.wind2_add);
     c.U_calm = fsqrt1(__builtin_fma(min_gust, min_gust, c.dU2));  // U when the gustiness sits at its floor
 
     const double lam_s = liquid_fraction_fast(P, logt, Ts);

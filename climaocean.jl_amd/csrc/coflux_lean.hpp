@@ -185,6 +185,7 @@ __device__ __forceinline__ LeanCell lean_prologue(const DevParams& P, double kap
     if (P.rm.kind == CF_ROUGHNESS_WIND_CHARNOCK) alpha = fmax(P.rm.charnock, P.rm.wind_a1 * fmin(dU, P.rm.wind_umax) + P.rm.wind_a2);
     c.lam_nu = P.rm.laminar * nu_m;
     c.alpha_g = alpha * P.inv_g;
+    c.dU2 = __builtin_fma(c.dU2, P.wind2_scale, P.wind2_add);  // from here on: what enters the wind-speed scale (DevParams::wind2_*)
     // epilogue
     const double rho_dir = rho * inv_dU;
     c.rdu = rho_dir * du;

@@ -718,6 +718,7 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
                     }
                     c.dU2 = c.du * c.du + c.dv * c.dv;
                     c.dU = fsqrt(c.dU2);
+                    c.dU2 = __builtin_fma(c.dU2, P.wind2_scale, P.wind2_add);  // (what enters the wind-speed scale: DevParams::wind2_*)
                     double alpha = P.rm.charnock;
                     if (P.rm.kind == CF_ROUGHNESS_WIND_CHARNOCK)
                         alpha = fmax(P.rm.charnock, P.rm.wind_a1 * fmin(c.dU, P.rm.wind_umax) + P.rm.wind_a2);

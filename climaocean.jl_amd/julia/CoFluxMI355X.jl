@@ -53,6 +53,7 @@ mutable struct CfFluxParams
     similarity_form::Int32; stability_functions::Int32; stop_kind::Int32; maxiter::Int32
     velocity_difference::Int32; mask_kind::Int32
     tolerance::Float64; von_karman::Float64; gustiness_parameter::Float64; minimum_gustiness::Float64
+    shear_gustiness_coefficient::Float64
     similarity_profile_floor::Float64
     momentum_roughness::CfRoughness; temperature_roughness::CfRoughness; water_vapor_roughness::CfRoughness
     reference_height::Float64; boundary_layer_height::Float64; gravitational_acceleration::Float64
@@ -250,6 +251,12 @@ end
 
 # ---- latitude-slab halo rows over RCCL (Distributed(GPU(), partition = Partition(1, R))) -------
 comm_unique_id() = (id = zeros(UInt8, 128); ccall((:cf_comm_unique_id, libcoflux), Cint, (Ptr{UInt8},), id); id)
+# (nranks, rank, device) as RCCL itself reports them for this backend's communicator — beside MPI.Comm_size in a launcher's log
+function comm_count(b)
+    n, r, d = Ref{Cint}(0), Ref{Cint}(0), Ref{Cint}(0)
+    check(b.ctx, ccall((:cf_comm_count, libcoflux), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Cint}), b.ctx, n, r, d))
+    return (n[], r[], d[])
+end
 comm_init!(b, id::Vector{UInt8}, rank, nranks) =   # `id` is MPI.bcast from rank 0
     check(b.ctx, ccall((:cf_comm_init, libcoflux), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), b.ctx, id, rank, nranks))
 halo_exchange_rows!(b, fields::Vector{Ptr{Float64}}, rows = 2) =   # rows = ring + 1: the ring row reads v[j+1]

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 1
+#define CF_ABI_VERSION 2 /* 2: cf_flux_params.shear_gustiness_coefficient */
 
 /* status codes */
 #define CF_OK 0
@@ -154,6 +154,13 @@ typedef struct cf_flux_params {
     double von_karman;            /* 0.4  */
     double gustiness_parameter;   /* β, 1 (0 in :ncar sea ice, omip_simulation.jl:109) */
     double minimum_gustiness;     /* 0.5 ocean :40,44; 0.2 ice :66 */
+    double shear_gustiness_coefficient; /* c of the shear-aware gustiness (Mahrt & Sun 1995 / Edson 2013;
+                                     experiments/OMIPSimulations/scripts/launch.sh:67-72,350, `:shear_aware`):
+                                     0 (default) = off, the wind-speed scale is U² = |Δu|² + max((β w★)², U_G,min²);
+                                     c > 0 (launch.sh: 0.04) = U² = |Δu|² + U_G², U_G² = (β w★)² + (c |Δu|)² + U_G,min²
+                                     — the convective, shear and background terms ADD, and the shear term raises the
+                                     gust at every wind speed.  The reference's own build_coupled_model rejects the
+                                     symbol (omip_simulation.jl:160); the formula is the one its launcher states. */
     double similarity_profile_floor; /* guard: log(h/ℓ) − ψ(h/L) [+ψ(ℓ/L)] is floored at this value (1.0),
                                         i.e. transfer coefficients are capped at κ/floor.  Only the
                                         pathological first iterates from the 1e-4 initial guess (ζ ≈ −10⁵)

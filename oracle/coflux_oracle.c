@@ -268,6 +268,18 @@ static double air_viscosity(const cf_roughness* r, double T_kelvin) {
 
 /* roughness_length(ℓ::MomentumRoughnessLength, u★, …); `U` = |Δu| at the reference height feeds
  * the wind-dependent Charnock parameter (Edson 2013 eq. 13, omip_simulation.jl:35). */
+/* Wind-speed scale of the similarity profiles, U² = |Δu|² + U_G².  Default: U_G = max(β w★, U_G,min) with the convective
+ * velocity scale w★ = (J_b h_bl)^⅓ of an unstable layer (J_b = −u★ b★ > 0), 0 otherwise.  Shear-aware form
+ * (launch.sh:67-72, Mahrt & Sun 1995 / Edson 2013): U_G² = (β w★)² + (c |Δu|)² + U_G,min², c = shear_gustiness_coefficient. */
+static double wind_speed_scale(const cf_flux_params* P, double Jb, double dU2) {
+    const double wstar = P->gustiness_parameter * cbrt(fmax(Jb, 0.0) * P->boundary_layer_height);
+    const double c = P->shear_gustiness_coefficient;
+    if (c > 0.0)
+        return sqrt(dU2 + wstar * wstar + c * c * dU2 + P->minimum_gustiness * P->minimum_gustiness);
+    const double Ug = fmax(wstar, P->minimum_gustiness);
+    return sqrt(dU2 + Ug * Ug);
+}
+
 static double momentum_roughness(const cf_roughness* r, double g, double ustar, double U, double Ts) {
     if (r->kind == CF_ROUGHNESS_CONSTANT) return r->constant_length;
     double alpha = r->charnock;
@@ -408,10 +420,8 @@ static cell_result solve_cell(const cf_flux_params* P, double ua, double va, dou
             /* iterate_interface_fluxes */
             double bstar = g / Tv * (tstar * (1.0 + delta * qv_s) + delta * Tv * qstar);
             double Jb = -ustar * bstar;
-            double Ug = P->gustiness_parameter * cbrt(fmax(Jb, 0.0) * P->boundary_layer_height);
-            Ug = fmax(Ug, P->minimum_gustiness);
             double dU = sqrt(du * du + dv * dv);
-            double U = sqrt(du * du + dv * dv + Ug * Ug);
+            double U = wind_speed_scale(P, Jb, du * du + dv * dv);
 
             double lu = momentum_roughness(&P->momentum_roughness, g, ustar, dU, Ts);
             double lq = scalar_roughness(&P->water_vapor_roughness, lu, ustar, Ts);
@@ -733,8 +743,7 @@ static cell_result solve_ice_cell(const cf_flux_params* P, const cf_sea_ice_para
         /* iterate_interface_fluxes */
         double bstar = g / Tv * (tstar * (1.0 + delta * qv_s) + delta * Tv * qstar);
         double Jb = -ustar * bstar;
-        double Ug = fmax(P->gustiness_parameter * cbrt(fmax(Jb, 0.0) * P->boundary_layer_height), P->minimum_gustiness);
-        double U = sqrt(du * du + dv * dv + Ug * Ug);
+        double U = wind_speed_scale(P, Jb, du * du + dv * dv);
         double lu = momentum_roughness(&P->momentum_roughness, g, ustar, dU, Ts);
         double lq = scalar_roughness(&P->water_vapor_roughness, lu, ustar, Ts);
         double lt = scalar_roughness(&P->temperature_roughness, lu, ustar, Ts);

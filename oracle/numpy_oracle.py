@@ -175,6 +175,16 @@ def scalar_length(r, lu, us, Ts):
     return np.minimum(lq, lm)
 
 
+def _wind_speed_scale(fluxes, Jb, dU2, h_bl):
+    """U of the similarity profiles: |Δu|² + U_G² with U_G = max(β w★, U_G,min), or — shear-aware form, launch.sh:67-72 —
+    U_G² = (β w★)² + (c |Δu|)² + U_G,min² when the formulation carries a shear_gustiness_coefficient c > 0."""
+    wstar = fluxes.gustiness_parameter * np.cbrt(np.maximum(Jb, 0.0) * h_bl)
+    c = getattr(fluxes, "shear_gustiness_coefficient", 0.0)
+    if c > 0.0:
+        return np.sqrt(dU2 * (1.0 + c * c) + wstar * wstar + fluxes.minimum_gustiness ** 2)
+    return np.sqrt(dU2 + np.maximum(wstar, fluxes.minimum_gustiness) ** 2)
+
+
 # ---------------------------------------------------------------------------------------------
 # the solver
 # ---------------------------------------------------------------------------------------------
@@ -229,8 +239,7 @@ def atmosphere_ocean_fluxes(fluxes, ocean, atmos, *, hx, hy, ring, thermodynamic
     while active.any() and it < maxit:
         b = g / Tv * (ts * (1 + delta * qv) + delta * Tv * qq)
         Jb = -us * b
-        Ug = np.maximum(fluxes.gustiness_parameter * np.cbrt(np.maximum(Jb, 0.0) * h_bl), fluxes.minimum_gustiness)
-        U = np.sqrt(du * du + dv * dv + Ug * Ug)
+        U = _wind_speed_scale(fluxes, Jb, du * du + dv * dv, h_bl)
         lu = momentum_length(fluxes.momentum_roughness_length, g, us, dU, Ts)
         lq = scalar_length(fluxes.water_vapor_roughness_length, lu, us, Ts)
         lt = scalar_length(fluxes.temperature_roughness_length, lu, us, Ts)
@@ -344,8 +353,7 @@ def atmosphere_sea_ice_fluxes(fluxes, iprops, ice, ocean, atmos, *, hx, hy, ring
         S = th.state_pTq(pa, Tn, qs)
         Tv, qv = th.T_virtual(S), th.q_vapor(S)
         b = g / Tv * (ts * (1 + delta * qv) + delta * Tv * qq)
-        Ug = np.maximum(fluxes.gustiness_parameter * np.cbrt(np.maximum(-us * b, 0.0) * h_bl), fluxes.minimum_gustiness)
-        U = np.sqrt(du * du + dv * dv + Ug * Ug)
+        U = _wind_speed_scale(fluxes, -us * b, du * du + dv * dv, h_bl)
         lu = momentum_length(fluxes.momentum_roughness_length, g, us, dU, Tn)
         lq = scalar_length(fluxes.water_vapor_roughness_length, lu, us, Tn)
         lt = scalar_length(fluxes.temperature_roughness_length, lu, us, Tn)

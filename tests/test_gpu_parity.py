@@ -110,6 +110,33 @@ def test_config1_plumbing_90x40_all_formulations(config):
     assert np.mean(it_g != it_r) < 0.01
 
 
+@pytest.mark.parametrize("config", list(util.SHEAR_CONFIGS))
+def test_shear_aware_gustiness_through_every_solver_body(config):
+    """cf_flux_params.shear_gustiness_coefficient > 0 (launch.sh:67-72,350) outside the `:shear_aware` preset, which
+    runs the lean COARE kernel (test_config1_plumbing…[shear_aware]): the lean log-profile kernel, the constant-roughness
+    body, a formulation without convective gust; tables and libm; separate launches and the fused step; and the certified
+    path, which starts from the same wind-speed scale."""
+    fluxes, vd = util.SHEAR_CONFIGS[config]()
+    params = ic.flux_params(fluxes, velocity_difference=vd)
+    case = util.build_case(90, 40)
+    ref = run_oracle(case, params)
+    compare(case, run_gpu(case, params), ref, 1)
+    compare(case, run_gpu(case, params, fused=True), ref, 1)
+    compare(case, run_gpu(case, params, solver=abi.SOLVER_LIBM), ref, 1)
+    got = run_gpu(case, params, fused=True, options=((abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED),))
+    compare(case, got, ref, 1, tol_solver=1e-6 if config == "default_shear" else TOL_SOLVER)
+    # and c = 0 is today's formulation, bit for bit
+    plain, _ = util.SHEAR_CONFIGS[config]()
+    plain.shear_gustiness_coefficient = 0.0
+    base = util.CONFIGS["default"]()[0] if config == "default_shear" else None
+    if base is not None:
+        a = run_gpu(case, ic.flux_params(plain, velocity_difference=vd))
+        b = run_gpu(case, ic.flux_params(base, velocity_difference=vd))
+        for k in a["fluxes"]:
+            np.testing.assert_array_equal(a["fluxes"][k], b["fluxes"][k], err_msg=k)
+        assert not np.array_equal(a["fluxes"]["x_momentum"], run_gpu(case, params)["fluxes"]["x_momentum"])
+
+
 @pytest.mark.parametrize("config", ["default", "corrected", "sea_ice_corrected", "sea_ice_ncar"])
 def test_libm_cross_check_solver(config):
     """The same iteration on ocml's libm (CF_SOLVER_LIBM) agrees with the oracle as well."""

@@ -105,6 +105,10 @@ def test_build_coupled_model_rejects_unknown_options_with_the_reference_strings(
         cm.build_coupled_model(None, None, None, None, None, "corrected", velocity_formulation="sideways")
     with pytest.raises(ValueError, match=r"Unknown flux_configuration: shear_aware\. Options: :default, :corrected, :ncar"):
         cm.build_coupled_model(None, None, None, None, None, ":shear_aware")   # launch.sh:350 emits it; build_coupled_model rejects it
+    # the formulation itself exists (include/coflux.h: shear_gustiness_coefficient) and is reachable behind an explicit flag
+    f = ic.shear_aware_atmosphere_ocean_fluxes()
+    assert f.shear_gustiness_coefficient == 0.04 and ic.flux_params(f).shear_gustiness_coefficient == 0.04
+    assert ic.flux_params(ic.corrected_atmosphere_ocean_fluxes()).shear_gustiness_coefficient == 0.0
 
 
 def test_tripolar_grid_weights_fold_and_rotation_without_a_gpu():

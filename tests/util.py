@@ -22,6 +22,22 @@ CONFIGS = {
     "sea_ice_ncar": lambda: (ic.ncar_atmosphere_sea_ice_fluxes(), None),
     "ncar": lambda: (ic.ncar_atmosphere_ocean_fluxes(), None),
     "fixed5": lambda: (ic.SimilarityTheoryFluxes(solver_stop_criteria=ic.FixedIterations(5)), None),
+    # launch.sh:67-72,350: `:corrected` with the shear-aware gustiness U_G² = (β w★)² + (0.04 |Δu|)² + U_G,0²
+    "shear_aware": lambda: (ic.shear_aware_atmosphere_ocean_fluxes(), ic.RelativeVelocity()),
+}
+
+
+def _with_shear(fluxes, c=0.04):
+    fluxes.shear_gustiness_coefficient = c
+    return fluxes
+
+
+# the same gustiness form through the other solver bodies: README defaults (log profile, constant Charnock), constant
+# roughness lengths (the generic / sea-ice-type body), Large–Yeager stability functions
+SHEAR_CONFIGS = {
+    "default_shear": lambda: (_with_shear(ic.SimilarityTheoryFluxes()), None),
+    "constant_roughness_shear": lambda: (_with_shear(ic.corrected_atmosphere_sea_ice_fluxes(), 0.08), ic.WindVelocity()),
+    "no_convective_gust_shear": lambda: (_with_shear(ic.ncar_atmosphere_sea_ice_fluxes()), None),
 }
 
 
@@ -35,6 +51,7 @@ ICE_CONFIGS = {
     "sea_ice_ncar": lambda: (ic.ncar_atmosphere_sea_ice_fluxes(), ic.WindVelocity()),
     "sea_ice_default": lambda: (ic.SimilarityTheoryFluxes(), None),
     "sea_ice_fixed5": lambda: (_fixed(ic.corrected_atmosphere_sea_ice_fluxes(), 5), None),
+    "sea_ice_shear": lambda: (_with_shear(ic.corrected_atmosphere_sea_ice_fluxes()), ic.RelativeVelocity()),
 }
 
 
