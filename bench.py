@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--net-diagnostics", action="store_true",
                     help="also write the three optional radiation diagnostics of cf_net_ocean_fluxes (24 B/cell beyond "
                          "the 88 + 40 B/cell contract of compute_net_ocean_fluxes!, SURVEY.md §8d)")
+    ap.add_argument("--ice-free-cells", choices=("iterate", "zero"), default="iterate",
+                    help="--config sea_ice: CF_OPT_ICE_FREE_CELLS — iterate (default: the interface solve runs on every wet cell) or "
+                         "zero (opt-in: open water gets zero_interface_state; reported beside the default, never instead of it)")
     ap.add_argument("--ice-orbit-shortcut", type=int, choices=(0, 1), default=1,
                     help="--config sea_ice: CF_OPT_ICE_ORBIT_SHORTCUT (0 = iterate every abandoned cell to maxiter)")
     ap.add_argument("--share-device", action="store_true",
@@ -303,7 +306,10 @@ def main():
         ice_cfg = ic.corrected_atmosphere_sea_ice_fluxes() if a.flux_configuration != "ncar" else ic.ncar_atmosphere_sea_ice_fluxes()
         ctx.set_sea_ice_formulation(ic.flux_params(ice_cfg))
         ctx.set_option(abi.OPT_ICE_ORBIT_SHORTCUT, a.ice_orbit_shortcut)
+        ctx.set_option(abi.OPT_ICE_FREE_CELLS, abi.ICE_FREE_ZERO if a.ice_free_cells == "zero" else abi.ICE_FREE_ITERATE)
         si_np = syn.sea_ice_state(nx, ny, h, h, ny_global=ny_global, j_offset=j0)
+        if a.ice_free_cells == "zero":   # the opt-in's definition of open water is ℵ = 0 AND hᵢ = 0: no thickness where there is no ice
+            si_np["thickness"] = np.where(ocean_np[0]["ice_concentration"] > 0, si_np["thickness"], 0.0)
         ice = {k: ctx.to_device(ocean_np[0]["ice_" + k]) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")}
         ice_state = dict(concentration=ice["concentration"], **{k: ctx.to_device(si_np[k]) for k in ("thickness", "top_temperature", "u", "v", "albedo")})
         ai = ctx.field_set(FLUX_NAMES)
@@ -680,6 +686,7 @@ def main():
                    config=dict(workload=workload, global_cells=cells_total, parallelism=f"latitude-slab x{world}",
                                rows_per_rank=ny, halo_backend=best, halo_verified=(halo_verified if world > 1 else None),
                                rccl_comm_ranks=rccl_comm_ranks, solver_path=chosen,
+                               ice_free_cells=(a.ice_free_cells if a.config == "sea_ice" else None),
                                certified_budget=(a.certified_budget * 1e-9 if "certified" in path_results else None),
                                halo_rows=ring_rows if world > 1 else 0, pipelined_interpolation=pipeline,
                                pipeline_mode=mode,

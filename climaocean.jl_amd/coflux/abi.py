@@ -26,7 +26,8 @@ MASK_NONE, MASK_U8, MASK_BOTTOM_HEIGHT = 0, 1, 2
 ALBEDO_CONSTANT, ALBEDO_LATITUDE_DEPENDENT = 0, 1
 OPT_SOLVER, OPT_INTERP_TILE_CAP, OPT_MAX_BLOCKS, OPT_TRIP_HINTS, OPT_AO_CHUNK, OPT_PROFILE_STRIDE, OPT_FUSED_NET = 0, 1, 2, 3, 4, 5, 6
 OPT_ICE_ORBIT_SHORTCUT, OPT_FUSED_INTERP, OPT_MERGED_PREFETCH = 7, 8, 9
-OPT_SOLVER_PATH, OPT_CERTIFIED_BUDGET = 10, 11
+OPT_SOLVER_PATH, OPT_CERTIFIED_BUDGET, OPT_ICE_FREE_CELLS = 10, 11, 12
+ICE_FREE_ITERATE, ICE_FREE_ZERO = 0, 1
 PIPELINE_WITHIN_CALL, PIPELINE_CONTINUING = 1, 2   # cf_run_schedule.pipeline
 SOLVER_PATH_EXACT, SOLVER_PATH_CERTIFIED = 0, 1      # how the Monin–Obukhov fixed point is reached (include/coflux.h)
 CERTIFIED_EXACT_FLAG = 0x100                         # `iterations` of a cell the certified path solved on the exact path

@@ -547,6 +547,11 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->ice_orbit_shortcut = value != 0;
             ctx->ice_kernel.orbit_shortcut = value != 0 ? 1.0 : 0.0;
             return CF_OK;
+        case CF_OPT_ICE_FREE_CELLS:
+            if (value != CF_ICE_FREE_ITERATE && value != CF_ICE_FREE_ZERO) return fail(ctx, CF_ERR_INVALID, "ice-free cells %d: 0 (iterate) or 1 (zero)", value);
+            ctx->ice_free_zero = value == CF_ICE_FREE_ZERO;
+            ctx->ice_kernel.ice_free_zero = ctx->ice_free_zero ? 1.0 : 0.0;
+            return CF_OK;
         case CF_OPT_PROFILE_STRIDE:
             if (value < 1) return fail(ctx, CF_ERR_INVALID, "profile stride %d must be >= 1", value);
             ctx->prof_stride = value;
@@ -1115,6 +1120,7 @@ int cf_set_sea_ice_formulation(cf_ctx* ctx, const cf_flux_params* ice_fluxes, co
     K.T_offset = ice->temperature_offset;
     K.semi_implicit = ice->skin_temperature_scheme == CF_SKIN_SEMI_IMPLICIT ? 1.0 : 0.0;
     K.orbit_shortcut = ctx->ice_orbit_shortcut ? 1.0 : 0.0;
+    K.ice_free_zero = ctx->ice_free_zero ? 1.0 : 0.0;
     ctx->ice_kernel = K;
     if (!ctx->ice_ready && ctx->merged_prefetch == 2) ctx->chunk_valid = false;   // (the chunk plan depends on it, see ensure_chunk_table)
     ctx->ice_ready = true;

@@ -78,6 +78,7 @@ struct cf_ctx {
     LoopParams ice_loop{};
     IceParams ice_kernel{};
     bool ice_orbit_shortcut = true;  // CF_OPT_ICE_ORBIT_SHORTCUT
+    bool ice_free_zero = false;      // CF_OPT_ICE_FREE_CELLS = CF_ICE_FREE_ZERO
     const double* d_land_freshwater = nullptr;   // cf_set_land_freshwater (borrowed)
     bool ice_albedo_ccsm3 = false;   // cf_set_sea_ice_albedo: SeaIceAlbedo(hi, hs, Ts) wherever no albedo field is given
     cf_sea_ice_albedo_params ice_albedo{};

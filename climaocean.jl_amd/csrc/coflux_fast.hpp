@@ -658,6 +658,7 @@ struct IceParams {  // kernarg
     double dT_max, T_melt, T_fw, liquidus_slope, eps_sigma, emissivity, albedo, T_offset;
     double semi_implicit;  // 1: upwelling longwave linearised about the previous skin temperature (CF_SKIN_SEMI_IMPLICIT)
     double orbit_shortcut; // 1 (default): an exact period-2 orbit ends the iteration early (CF_OPT_ICE_ORBIT_SHORTCUT)
+    double ice_free_zero;  // 1: cells with ℵ = 0 and hᵢ = 0 get zero_interface_state instead of an iteration (CF_OPT_ICE_FREE_CELLS)
 };
 
 struct IceConsts {

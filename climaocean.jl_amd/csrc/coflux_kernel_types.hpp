@@ -71,6 +71,7 @@ struct IceStateIn {   // sea_ice.model fields the atmosphere–sea-ice interface
     const double* u;
     const double* v;
     const double* albedo;
+    const double* concentration;  // ℵ: read only with CF_OPT_ICE_FREE_CELLS = zero (null otherwise)
 };
 
 struct NetIceOut {   // compute_net_sea_ice_fluxes! inside the interface solve's epilogue (all null: a launch of its own)

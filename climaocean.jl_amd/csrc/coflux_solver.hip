@@ -690,6 +690,7 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
                 const IceParams Ice = kread(&K->Ice);
                 IceConsts c;
                 double Ts;
+                bool ice_free = false;
                 {
                     const int idx = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
                     const int jj = row_of(idx, wx, wx_rcp);
@@ -724,14 +725,20 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
                         alpha = fmax(P.rm.charnock, P.rm.wind_a1 * fmin(c.dU, P.rm.wind_umax) + P.rm.wind_a2);
                     c.alpha_g = alpha * P.inv_g;
                     Ts = S.top_temperature[k] + Ice.T_offset;
+                    // CF_OPT_ICE_FREE_CELLS = zero: open water (ℵ = 0 and hᵢ = 0) has no atmosphere–sea-ice interface
+                    if (Ice.ice_free_zero != 0.0 && S.concentration) ice_free = S.concentration[k] == 0.0 && S.thickness[k] == 0.0;
                 }
-                Scales s;
-                if constexpr (SPEC == SOLVER_SEAICE_LEAN) {
-                    const LeanIceConsts lc{c.rho, c.cp, c.qav, c.Ls, c.Ti, c.hk, c.Qd, c.theta_a, c.pa, frcp1(c.pa), frcp1(c.rho * P.R_v), c.dU2};
-                    s = ice_iterate_lean<COARE>(P, L, Ice, lc, tab, in_range, Ts);
-                } else {
-                    s = ice_iterate<COARE>(P, L, Ice, c, tab, in_range, Ts);
+                Scales s{0.0, 0.0, 0.0, 0, 0};
+                const bool solve = in_range && !ice_free;
+                if (__ballot(solve) != 0ull) {  // (a batch of open water — most of the surface — skips the solve altogether)
+                    if constexpr (SPEC == SOLVER_SEAICE_LEAN) {
+                        const LeanIceConsts lc{c.rho, c.cp, c.qav, c.Ls, c.Ti, c.hk, c.Qd, c.theta_a, c.pa, frcp1(c.pa), frcp1(c.rho * P.R_v), c.dU2};
+                        s = ice_iterate_lean<COARE>(P, L, Ice, lc, tab, solve, Ts);
+                    } else {
+                        s = ice_iterate<COARE>(P, L, Ice, c, tab, solve, Ts);
+                    }
                 }
+                if (ice_free) s = Scales{0.0, 0.0, 0.0, 0, 0};  // zero_interface_state: no fluxes; the skin temperature stays the input
                 if (in_range) {
                     SolverArgsPtr Ke = opaque(K);
                     const int idx2 = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
@@ -747,6 +754,7 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
                     R.rho_tau_x = c.rho * tau * c.du;
                     R.rho_tau_y = c.rho * tau * c.dv;
                     R.Ts_ocean = Ts - Ice.T_offset;
+                    if (ice_free) R.Ts_ocean = kread(&Ke->S).top_temperature[k];  // (zero_interface_state: the input, bit for bit)
                     R.ustar = s.us;
                     R.tstar = s.ts;
                     R.qstar = s.qq;
@@ -1074,7 +1082,7 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     A.g_params = d_params;
     A.W = WetLists{L.d_wet_pos, d_trip};
     A.chunk_begins = L.d_chunk_begins;
-    A.S = IceStateIn{ice->thickness, ice->top_temperature, ice->u, ice->v, ice->albedo};
+    A.S = IceStateIn{ice->thickness, ice->top_temperature, ice->u, ice->v, ice->albedo, Ice.ice_free_zero != 0.0 ? ice->concentration : nullptr};
     A.Ice = Ice;
     A.z_surface = P.z_surface;
     A.mask_kind = P.mask_kind;

@@ -410,6 +410,17 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 #define CF_OPT_CERTIFIED_BUDGET 11 /* the certificate's budget in units of 1e-9 (default 800 = 8e-7; 50 … 1000000 — anything above ≈ 900 gives up the 1e-6 guarantee and is for measurements).  The solve's own
                                    * convergence error (≤ 2e-8 in the same metric) comes on top: the default keeps every cell
                                    * within 1e-6 of the exact path, the north star's tolerance; measured worst ≈ 4e-7. */
+#define CF_OPT_ICE_FREE_CELLS 12   /* what compute_atmosphere_sea_ice_fluxes! does on wet cells that carry no ice (ℵ = 0 AND hᵢ = 0):
+                                   * CF_ICE_FREE_ITERATE (0, default): the interface iteration runs on every wet cell, as the recalled
+                                   * upstream kernel does — on a 1/4° surface with polar ice 77 % of the interface solve's time;
+                                   * CF_ICE_FREE_ZERO (1): such cells get zero_interface_state — zero interface fluxes, zero iterations,
+                                   * the skin temperature left at its input — and whole batches of open water skip the solve.
+                                   * The five net ocean fields do not read the atmosphere–sea-ice interface, and the net sea-ice
+                                   * fluxes of every cell with ℵ > 0 are the same bits in both modes (tested); the interface
+                                   * fluxes and the net sea-ice fluxes of ice-free cells differ (they weight nothing: ℵ = 0).  Which of
+                                   * the two upstream does is one of the forks julia/oracle_dump.jl records. */
+#define CF_ICE_FREE_ITERATE 0
+#define CF_ICE_FREE_ZERO 1
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path on LDS-tabulated ψ / log / exp.  Accuracy of the tabulated primitives
                                against libm (tests/test_gpu_parity.py::test_device_primitives_accuracy): ψ_m, ψ_h ≤ 5e-12 of
                                max(|ψ|, 1) for |ζ| < 1024 (every state a converging iteration can stop on) and ≤ 2e-10 for

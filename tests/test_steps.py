@@ -451,3 +451,49 @@ def test_sea_ice_step_with_tail_workgroups_is_bitwise_the_plain_step():
         ctx.close()
     for k in results[0]:
         assert torch.equal(results[0][k], results[1][k]), k
+
+
+@pytest.mark.gpu
+def test_ice_free_cells_zero_mode_changes_nothing_where_there_is_ice():
+    """CF_OPT_ICE_FREE_CELLS = CF_ICE_FREE_ZERO (opt-in): wet cells with ℵ = 0 and hᵢ = 0 get zero_interface_state instead of
+    the interface iteration.  Against the default mode on the same inputs, through cf_update_state_sea_ice with every rider:
+    the five net ocean fields bitwise, the atmosphere–sea-ice interface fluxes and the net sea-ice fluxes bitwise wherever
+    there is ice; open water reports zero fluxes, zero iterations and its input skin temperature."""
+    results = {}
+    for mode in (abi.ICE_FREE_ITERATE, abi.ICE_FREE_ZERO):
+        ctx, states, src, w, (o0, _) = _setup(n_levels=4)
+        ctx.set_sea_ice_formulation(ic.flux_params(ic.corrected_atmosphere_sea_ice_fluxes()))
+        ctx.set_option(abi.OPT_ICE_FREE_CELLS, mode)
+        ctx.set_option(abi.OPT_MERGED_PREFETCH, 2)
+        si = syn.sea_ice_state(NX, NY, H, H)
+        conc = o0["ice_concentration"]
+        assert (conc == 0).any() and (conc > 0).any()
+        si["thickness"] = np.where(conc > 0, si["thickness"], 0.0)
+        ice = {k: ctx.to_device(o0["ice_" + k]) for k in ("concentration", "interface_heat", "salt_flux", "x_stress", "y_stress")}
+        ice_state = dict(concentration=ice["concentration"], **{k: ctx.to_device(si[k]) for k in ("thickness", "top_temperature", "u", "v", "albedo")})
+        atmos, fl, net = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+        ai = ctx.field_set(FLUX_NAMES)
+        ai["iterations"] = ctx.zeros(torch.int32)
+        net_ice = ctx.field_set(("top_heat", "bottom_heat"))
+        for step in range(3):
+            ctx.update_state_sea_ice(src, w, states[step % 2], atmos, fl, net, ice, ice_state, ai, net_ice, level1=0, level2=1,
+                                     time_fraction=0.1 * step)
+        ctx.sync()
+        results[mode] = dict(net={k: v.cpu().numpy() for k, v in net.items()}, ai={k: v.cpu().numpy() for k, v in ai.items()},
+                             net_ice={k: v.cpu().numpy() for k, v in net_ice.items()}, fl={k: v.cpu().numpy() for k, v in fl.items()})
+        ctx.close()
+    a, b = results[abi.ICE_FREE_ITERATE], results[abi.ICE_FREE_ZERO]
+    inner = (slice(H, H + NY), slice(H, H + NX))
+    icy = (conc > 0)[inner]
+    water = (conc == 0)[inner] & (o0["mask"] != 0)[inner]
+    for k in a["net"]:
+        np.testing.assert_array_equal(a["net"][k], b["net"][k], err_msg="net ocean " + k)
+    for k in a["fl"]:
+        np.testing.assert_array_equal(a["fl"][k], b["fl"][k], err_msg="ocean interface " + k)
+    for grp in ("ai", "net_ice"):
+        for k in a[grp]:
+            np.testing.assert_array_equal(a[grp][k][inner][icy], b[grp][k][inner][icy], err_msg=f"{grp}.{k} on ice")
+    assert water.any() and np.all(b["ai"]["iterations"][inner][water] == 0) and np.all(a["ai"]["iterations"][inner][water] > 0)
+    for k in ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum"):
+        assert np.all(b["ai"][k][inner][water] == 0.0), k
+    np.testing.assert_array_equal(b["ai"]["temperature"][inner][water], si["top_temperature"][inner][water])

@@ -98,14 +98,15 @@ ICE_FLUX_FIELDS = ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", 
 
 
 def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=None, maxiter=100, tol_slow=1e-6, slow=40,
-                       orbit_shares=((1e-9, 0.97), (1e-6, 0.995), (1e-3, 0.999))):
+                       orbit_shares=((1e-9, 0.97), (1e-6, 0.995), (1e-3, 0.999)), sum_bias_tol=1e-6):
     """Sea-ice interface comparison, same-shape windows.  The recalled skin-temperature balance does not contract for
     thick ice in wind (gain ≈ (h/k)·∂Q/∂T > 1, explicit and semi-implicit form alike): such cells orbit under the ±ΔTmax
     limiter until `maxiter`.  Most of those orbits are attracting cycles both sides land on — measured on the GPU
     (scratch/orbit_cells.py): 98.9–99.6 % of the abandoned cells agree with the oracle to 1e-9, ≥ 99.8 % to 1e-6 — and a
     few per ten thousand amplify rounding without bound (errors up to O(1)).  So the cells the reference leaves at
     `maxiter` ARE compared in value, as a distribution: at least `orbit_shares` of them within each
-    tolerance, every one finite, and both sides must abandon the same cells.  A wrong Q_d, albedo or ℒ_s on thick ice
+    tolerance, every one finite, both sides must abandon the same cells, and the abandoned cells' SUMMED sensible and latent
+    heat fluxes agree to `sum_bias_tol` of the surface total (a systematic error on thick ice cannot pass as outliers).  A wrong Q_d, albedo or ℒ_s on thick ice
     moves every one of them and fails the first share.  Cells that converge but need more than `slow` iterations (a
     weakly contracting orbit, ≈ 1.3× amplification per iteration) are held to the north star's `tol_slow` = 1e-6, every
     other cell to `tol_converged`; trip counts must be identical on all converged cells."""
@@ -143,4 +144,28 @@ def compare_ice_fluxes(got, ref, tol_converged, tol_unconverged=None, maxiter=10
                 have = float((e[unconv] <= tol).mean())
                 assert have >= share, ("abandoned cells within", tol, have, "needed", share, n)
                 worst["abandoned<=%g" % tol] = have
+            # ... and what the shares could hide: a systematic error on the abandoned cells would show in their SUMS (the
+            # rounding-amplifying orbits scatter both ways).  The summed heat fluxes of the abandoned cells must agree to
+            # 1e-6 of the summed magnitudes over the whole surface (uniform cell weights: a relative statement), and the
+            # count of cells beyond 1e-6 is reported per field
+            # (summed over the abandoned cells that agree to 1e-3: the ≤ 0.1 % the last share lets through are the
+            # rounding-amplifying orbits — errors up to O(1) in single cells, which on a small surface would swamp any
+            # sum; their count and their largest absolute error are reported)
+            calm = unconv & (e <= 1e-3)
+            for k in ("sensible_heat", "latent_heat"):
+                g, r = np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64)
+                total = float(np.abs(r).sum())
+                bias = abs(float((g[calm] - r[calm]).sum()))
+                worst["abandoned_sum_bias." + k] = bias / max(total, 1e-300)
+                worst["abandoned_outlier_max_abs." + k] = float(np.abs(g - r)[unconv & ~calm].max(initial=0.0))
+                assert bias <= sum_bias_tol * total, ("summed difference over the abandoned cells", k, bias, total)
+            worst["abandoned_outliers"] = int((unconv & ~calm).sum())
+            for k in ICE_FLUX_FIELDS:
+                g, r = np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64)
+                err = np.abs(g - r) / np.maximum(np.abs(r), FIELD_SCALE[k])
+                worst["abandoned_beyond_1e-6." + k] = int((err[unconv] > 1e-6).sum())
+            print("[sea-ice abandoned cells] n = %d; beyond 1e-6 per field: %s; summed-heat-flux bias / surface total: %s; %d beyond 1e-3, largest |Δ| %s W/m²" % (
+                n, {k.split(".")[1]: v for k, v in worst.items() if str(k).startswith("abandoned_beyond")},
+                {k.split(".")[1]: "%.1e" % v for k, v in worst.items() if str(k).startswith("abandoned_sum_bias")}, worst["abandoned_outliers"],
+                {k.split(".")[1]: "%.2g" % v for k, v in worst.items() if str(k).startswith("abandoned_outlier_max_abs")}))
     return worst
