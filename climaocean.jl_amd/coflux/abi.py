@@ -208,7 +208,7 @@ EXPORTED_SYMBOLS = (
     "cf_interpolate_land_freshwater", "cf_set_land_freshwater", "cf_materialize_salinity_restoring",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
     "cf_window_upload", "cf_window_find", "cf_window_source",
-    "cf_ensure_chunk_table", "cf_solver_path", "cf_solver_iteration_path", "cf_comm_count",
+    "cf_ensure_chunk_table", "cf_solver_path", "cf_solver_iteration_path", "cf_comm_count", "cf_discard_prefetched_atmosphere_state",
 )
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -244,6 +244,7 @@ def load_library(path=None):
     lib.cf_set_stream.argtypes = [vp, vp]
     lib.cf_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.cf_solver_iteration_path.argtypes = [vp, C.POINTER(C.c_int)]
+    lib.cf_discard_prefetched_atmosphere_state.argtypes = [vp]
     lib.cf_comm_count.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.cf_debug_eval.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     lib.cf_debug_chunk_plan.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]

@@ -385,7 +385,15 @@ class PrescribedSeaIce:
 # ---------------------------------------------------------------------------------------------
 # ComponentInterfaces / OceanSeaIceModel
 # ---------------------------------------------------------------------------------------------
-class ComponentInterfaces:
+class ComponentInterfaces:  # noqa: D101 — documented below
+    @property
+    def exchange_atmosphere_state(self):
+        return self._exchange_sets[self._exchange_current]
+
+    @property
+    def _exchange_other(self):
+        return self._exchange_sets[1 - self._exchange_current]
+
     """ComponentInterfaces(atmosphere, ocean, sea_ice; radiation, atmosphere_ocean_fluxes,
     atmosphere_ocean_velocity_difference, ocean_minimum_salinity) — omip_simulation.jl:128-158."""
 
@@ -410,8 +418,13 @@ class ComponentInterfaces:
         ctx = self.context
         self.weights = grid.interpolation_weights(ctx.to_device)
         self.fold_north = bool(getattr(grid, "fold_north", False))
-        self.exchange_atmosphere_state = ctx.field_set(EXCHANGE_NAMES)
-        self._exchange_other = None   # second set of exchange fields: run!(simulation) requests every next state into it
+        # interfaces.exchange_atmosphere_state — the reference updates ONE field set in place.  Here it is a property over two
+        # private sets: outside run!(simulation) it is always set 0 (stable tensors: what a writer or a diagnostic may hold
+        # on to); inside run! every step's solver launch also interpolates the NEXT step's state, into the other set, so the
+        # current state alternates between the two — read it through the property there, do not keep the dict or its tensors
+        # across steps.  run! leaves the final state in set 0 and restores the context's options.
+        self._exchange_sets = [ctx.field_set(EXCHANGE_NAMES), None]
+        self._exchange_current = 0
         fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL if store_similarity_scales else ())
         self.atmosphere_ocean_interface = SimpleNamespace(fluxes=SimpleNamespace(**fluxes), _fields=fluxes)
         bc = ocean.model.top_boundary_conditions
@@ -561,14 +574,16 @@ def update_state(model):
     # bits as interpolating it when its step comes).  A sliding window needs a third slot for that: the request makes the
     # next bracketing snapshots resident while this step may still read the current ones.
     if getattr(itf, "_next_state_in_other", False):   # requested by the previous step: this step's state is in the other set
-        itf.exchange_atmosphere_state, itf._exchange_other = itf._exchange_other, itf.exchange_atmosphere_state
+        itf._exchange_current = 1 - itf._exchange_current
         itf._next_state_in_other = False
     dt_next = getattr(model, "_pipeline_dt", None)
     pipelined = dt_next is not None and (atm.provider is None or atm.n_slots >= 3)
     if pipelined:
         if itf._exchange_other is None:
-            itf._exchange_other = itf.context.field_set(EXCHANGE_NAMES)
+            itf._exchange_sets[1 - itf._exchange_current] = itf.context.field_set(EXCHANGE_NAMES)
+        if not getattr(itf, "_tail_mode", False):   # (restored by run!: a lone update_state! is ≈ 5 µs slower on the tail plan)
             itf.context.set_option(abi.OPT_MERGED_PREFETCH, 2)
+            itf._tail_mode = True
         src_n, n1n, n2n, frac_n = atm.source(itf.context, model.clock.time + dt_next)
         itf.context.prefetch_atmosphere_state(src_n, itf.weights, itf._exchange_other, level1=n1n, level2=n2n, time_fraction=frac_n)
     if itf.atmosphere_sea_ice_interface is not None:
@@ -615,6 +630,19 @@ def run(simulation):
             time_step(m, simulation.dt)
     finally:
         m._pipeline_dt = None
+        itf = m.interfaces
+        # the state at the model's clock goes back to set 0 (what callers may hold), the pending request is dropped, and the
+        # context returns to the options it had: the chunk plan of a lone update_state!, the auxiliary-stream prefetch
+        if getattr(itf, "_next_state_in_other", False):
+            itf._next_state_in_other = False     # (the requested state of a step that will not run; the next run! asks again)
+        itf.context.discard_prefetched_atmosphere_state()
+        if itf._exchange_current != 0:
+            for k, t in itf._exchange_sets[0].items():
+                t.copy_(itf._exchange_sets[1][k])
+            itf._exchange_current = 0
+        if getattr(itf, "_tail_mode", False):
+            itf.context.set_option(abi.OPT_MERGED_PREFETCH, 0)
+            itf._tail_mode = False
     m.interfaces.context.sync()
 
 

@@ -340,6 +340,10 @@ class FluxContext:
         self._check(self.lib.cf_prefetch_atmosphere_state(self._h, C.byref(s), C.byref(w), C.byref(e)),
                     "cf_prefetch_atmosphere_state")
 
+    def discard_prefetched_atmosphere_state(self):
+        """Forget requested-ahead atmosphere states (cf_discard_prefetched_atmosphere_state): on leaving a stepping loop."""
+        self._check(self.lib.cf_discard_prefetched_atmosphere_state(self._h), "cf_discard_prefetched_atmosphere_state")
+
     def make_schedule(self, ocean_states, atmos_sets, *, first_level=0, time_fraction=0.0, time_fraction_increment=0.0,
                       pipeline=False, halo_backend=abi.HALO_NONE, halo_rows=0, fold_north=False):
         """cf_run_schedule for cf_time_steps; keeps the ctypes arrays alive on the returned object."""

@@ -585,10 +585,23 @@ int cf_debug_eval(cf_ctx* ctx, int function, int n, const double* d_x, double* d
 
 int cf_set_stream(cf_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
-    if (hip_stream == CF_STREAM_LEGACY)
-        ctx->stream = nullptr;  // the null stream handle: legacy default-stream semantics in every HIP call
-    else
-        ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream == CF_STREAM_LEGACY ? nullptr  // the null stream handle: legacy default-stream semantics in every HIP call
+                       : (hip_stream ? (hipStream_t)hip_stream : ctx->own_stream);
+    if (next != ctx->stream) {
+        // a requested-ahead atmosphere state that was launched ON the old stream is consumed by stream order alone (no event):
+        // the new stream has to wait for it
+        bool pending = false;
+        for (auto& p : ctx->prefetch) pending |= p.valid && p.on_main;
+        if (pending) {
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            hipEvent_t ev = nullptr;
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(ev, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(next, ev, 0));
+            HIP_TRY(ctx, hipEventDestroy(ev));
+        }
+    }
+    ctx->stream = next;
     return CF_OK;
 }
 
@@ -695,6 +708,13 @@ int cf_ensure_chunk_table(cf_ctx* ctx, const void* mask) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return ensure_chunk_table(ctx, mask);
+}
+
+// A requested interpolation that rides in another launch stages its JRA55 tile (4 waves × 9 variables × cap × 8 B) in THAT
+// launch's dynamic LDS: a solver launch has ≥ 40 960 B (CF_OPT_INTERP_TILE_CAP ≤ 142), the face-stress launch 64 KB.  A cap
+// beyond that falls through to the stand-alone interpolation on the main stream.
+static bool interp_tile_fits(const cf_ctx* ctx, size_t lds_bytes) {
+    return ctx->launch.interp_cap > 0 && (size_t)4 * CF_JRA55_NVARS * (size_t)ctx->launch.interp_cap * sizeof(double) <= lds_bytes;
 }
 
 static bool net_fluxes_fused(const cf_ctx* ctx) {
@@ -838,7 +858,7 @@ static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_i
     const bool tail_lean = ctx->launch.d_lean_info && ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
     const bool tail_ly = ctx->fast.specialization == SOLVER_LY && ctx->launch.solver == CF_SOLVER_TABLES;
     const bool tail = fuse && !fuse_interp && !hold_tail_work && ctx->merged_prefetch == 2 && ctx->deferred.valid &&
-                      ctx->launch.interp_cap != 0 && ctx->deferred.out.u != atmos->u && !ctx->launch.ao_wide && (tail_lean || tail_ly);
+                      interp_tile_fits(ctx, 40960) && ctx->deferred.out.u != atmos->u && !ctx->launch.ao_wide && (tail_lean || tail_ly);
     // With sea ice (cf_update_state_sea_ice): the ocean solve itself is handed to the caller, whose interface-solve launch carries
     // its workgroups behind its own (ice_ocean_kernel) — the stresses then follow that launch
     const bool ride = hold_tail_work && ocean_rider && fuse && !fuse_interp && tail_lean && !ctx->launch.ao_wide && !rec;
@@ -872,7 +892,7 @@ static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_i
     // face-stress launch on the main stream — two independent memory-bound kernels, one launch boundary fewer (on a
     // latitude slab a boundary is a tenth of the step).  Otherwise it goes out on the auxiliary stream right behind the
     // solver: the solver's workgroups are dispatched first, the gather kernel takes what they leave free.
-    const bool merge = fuse && !hold_tail_work && ctx->merged_prefetch == 1 && ctx->deferred.valid && ctx->launch.interp_cap != 0 &&
+    const bool merge = fuse && !hold_tail_work && ctx->merged_prefetch == 1 && ctx->deferred.valid && interp_tile_fits(ctx, 65536) &&
                        ctx->deferred.out.u != atmos->u;
     if (ctx->merged_prefetch == 0) CHECK(cf_flush_deferred_prefetch(ctx));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
@@ -1286,6 +1306,7 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
     if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
     // CF_OPT_MERGED_PREFETCH = 2: the face stresses of this step and a requested next-step interpolation ride in the tail
     // workgroups of the interface solve — the longest launch of the step, whose workgroups retire over tens of microseconds
+    if (ocean) CHECK(ensure_chunk_table(ctx, ocean->mask));  // (ao_wide below is decided when the table is built: ADVICE r4)
     const bool ice_tail = ctx->merged_prefetch == 2 && ctx->ice_loop.specialization == SOLVER_ICE &&
                           ctx->launch.solver == CF_SOLVER_TABLES && !ctx->launch.ao_wide;
     bool stress_held = false;
@@ -1314,7 +1335,7 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
             T.stress_ice = ice_partition;
             T.stress_net = net;
         }
-        if (ctx->deferred.valid && ctx->deferred.out.u != atmos->u && ctx->launch.interp_cap != 0) {
+        if (ctx->deferred.valid && ctx->deferred.out.u != atmos->u && interp_tile_fits(ctx, 40960)) {
             interpolate_grid(ctx->launch, ctx->grid, &T.interp_rows, &T.interp_blocks);
             T.next_src = &ctx->deferred.src;
             T.w = &ctx->deferred.w;

@@ -83,6 +83,14 @@ static int request_prefetch(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
     CHECK(ensure_aux_stream(ctx));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     CHECK(cf_flush_deferred_prefetch(ctx));  // at most one request waits for a solver launch
+    // An earlier request into the SAME exchange set that went out on the auxiliary stream and was never consumed (another
+    // clock, a switch of CF_OPT_MERGED_PREFETCH in between): this request supersedes it, and whichever stream writes the
+    // set next — the main stream in the merged forms — is ordered behind that kernel
+    for (auto& p : ctx->prefetch)
+        if (p.valid && !p.on_main && p.key == out->u) {
+            if (p.done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p.done, 0));
+            p.valid = false;
+        }
     // the set written was last read by kernels already queued on the main stream: everything queued so far gates it.
     // With CF_OPT_MERGED_PREFETCH the request leaves inside a main-stream launch (stream order is the gate) and an event
     // per step would only put a barrier packet into the queue; the rare flush to the auxiliary stream records it then.
@@ -241,6 +249,19 @@ int cf_fold_north_halo(cf_ctx* ctx, double* const* d_fields, const int* location
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_fold_north(ctx->stream, F, G, rows));
+    return CF_OK;
+}
+
+int cf_discard_prefetched_atmosphere_state(cf_ctx* ctx) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->deferred.valid = false;   // requested, not launched: never will be
+    for (auto& p : ctx->prefetch)
+        if (p.valid) {
+            // launched on the auxiliary stream: whatever the caller does to that exchange set next is ordered behind it
+            if (!p.on_main && p.done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p.done, 0));
+            p.valid = false;
+        }
     return CF_OK;
 }
 

@@ -282,6 +282,10 @@ prefetch_atmosphere_state!(b, src_next::CfAtmosSource, w::CfInterpWeights, out::
     check(b.ctx, ccall((:cf_prefetch_atmosphere_state, libcoflux), Cint,
                        (Ptr{Cvoid}, Ref{CfAtmosSource}, Ref{CfInterpWeights}, Ref{CfExchangeFields}), b.ctx, src_next, w, out))
 
+# on leaving the stepping loop: no later update_state! may mistake a requested-ahead state for the one it asks for
+discard_prefetched_atmosphere_state!(b) =
+    check(b.ctx, ccall((:cf_discard_prefetched_atmosphere_state, libcoflux), Cint, (Ptr{Cvoid},), b.ctx))
+
 # the solver's schedule for a wet mask, built ahead of the first step (optional: the first call builds it otherwise)
 ensure_chunk_table!(b, mask::Ptr{Cvoid}) =
     check(b.ctx, ccall((:cf_ensure_chunk_table, libcoflux), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), b.ctx, mask))

@@ -848,6 +848,11 @@ int cf_solver_path(cf_ctx* ctx, int* lean_kernel, int* fused_net);
  * seam — is unchanged.                                                                                          */
 int cf_prefetch_atmosphere_state(cf_ctx* ctx, const cf_atmos_source* src_next, const cf_interp_weights* w,
                                  const cf_exchange_fields* out);
+/* Forget every atmosphere state that was requested ahead and not consumed (cf_prefetch_atmosphere_state, cf_time_steps with
+ * CF_PIPELINE_CONTINUING): a caller that leaves its stepping loop, overwrites an exchange set that holds such a state, or
+ * changes the clock calls this so that no later cf_update_state mistakes the set's contents for the state it asks for.
+ * An interpolation already running on the auxiliary stream is ordered ahead of whatever follows on the context's stream. */
+int cf_discard_prefetched_atmosphere_state(cf_ctx* ctx);
 
 #ifdef __cplusplus
 }

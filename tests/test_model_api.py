@@ -80,8 +80,15 @@ def test_run_requests_every_next_state_and_gives_the_bits_of_the_plain_loop():
         cm.set_surface(ocean, T=state["T"], S=state["S"], u=state["u"], v=state["v"], mask=state["mask"])
         coupled = cm.OceanSeaIceModel(ocean, atmosphere=cm.JRA55PrescribedAtmosphere(snaps))
         if piped:
-            cm.run(cm.Simulation(coupled, dt=50 * cm.minutes, stop_iteration=9))
+            held = coupled.interfaces.exchange_atmosphere_state        # what an output writer would hold on to
+            cm.run(cm.Simulation(coupled, dt=50 * cm.minutes, stop_iteration=8))
             assert coupled.interfaces._exchange_other is not None
+            # outside run! the public field set is the one handed out before it, with the state at the model's clock in it
+            assert coupled.interfaces.exchange_atmosphere_state is held
+            # ... and a step taken by hand afterwards does not mistake the state run! had requested ahead for its own
+            cm.time_step(coupled, 50 * cm.minutes)
+            coupled.interfaces.context.sync()
+            assert coupled.interfaces.exchange_atmosphere_state is held
         else:
             for _ in range(9):
                 cm.time_step(coupled, 50 * cm.minutes)
