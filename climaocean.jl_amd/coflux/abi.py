@@ -208,7 +208,7 @@ EXPORTED_SYMBOLS = (
     "cf_interpolate_land_freshwater", "cf_set_land_freshwater", "cf_materialize_salinity_restoring",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
     "cf_window_upload", "cf_window_find", "cf_window_source",
-    "cf_ensure_chunk_table", "cf_solver_path", "cf_solver_iteration_path", "cf_comm_count", "cf_discard_prefetched_atmosphere_state",
+    "cf_ensure_chunk_table", "cf_solver_path", "cf_solver_iteration_path", "cf_comm_count", "cf_build_stamp", "cf_discard_prefetched_atmosphere_state",
 )
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -220,6 +220,23 @@ class CofluxLibraryMissing(RuntimeError):
 
 
 _lib = None
+
+
+def source_stamp():
+    """sha256[:16] over csrc/*.{hip,cpp,hpp,h} + include/coflux.h in the Makefile's order, or None when the sources are not
+    there (an installed library without its tree)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+    names = sorted(os.path.basename(f) for ext in ("hip", "cpp", "hpp", "h") for f in glob.glob(os.path.join(csrc, "*." + ext)))
+    header = os.path.join(csrc, "..", "..", "include", "coflux.h")
+    if not names or not os.path.exists(header):
+        return None
+    # GNU make's $(sort) orders byte-wise, "../../include/coflux.h" ahead of every plain file name
+    h = hashlib.sha256()
+    for f in [header] + [os.path.join(csrc, n) for n in names]:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_library(path=None):
@@ -235,6 +252,12 @@ def load_library(path=None):
     lib = C.CDLL(p)
     vp = C.c_void_p
     lib.cf_version.restype = C.c_int
+    lib.cf_build_stamp.restype = C.c_char_p
+    want, have = source_stamp(), lib.cf_build_stamp().decode()
+    if want is not None and have != want and os.environ.get("COFLUX_ALLOW_STALE_LIBRARY") != "1":
+        raise CofluxLibraryMissing(
+            f"{p} was built from other sources than this tree's (stamp {have}, tree {want}): rebuild it with "
+            "`python __graft_entry__.py build` (COFLUX_ALLOW_STALE_LIBRARY=1 loads it anyway: A/B builds only)")
     lib.cf_default_flux_params.argtypes = [C.POINTER(FluxParams)]
     lib.cf_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Grid), C.POINTER(FluxParams)]
     lib.cf_destroy.argtypes = [vp]
@@ -318,7 +341,7 @@ def load_library(path=None):
     lib.cf_window_source.argtypes = [vp, C.c_int64, C.c_int64, C.c_double, C.POINTER(AtmosSource)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("cf_last_error", "cf_device_alloc", "cf_window_host_buffer"):
+        if name not in ("cf_last_error", "cf_device_alloc", "cf_window_host_buffer", "cf_build_stamp"):
             fn.restype = C.c_int
     if path is None:
         _lib = lib

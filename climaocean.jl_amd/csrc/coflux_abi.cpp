@@ -315,6 +315,11 @@ extern "C" {
 
 int cf_version(void) { return CF_ABI_VERSION; }
 
+#ifndef CF_BUILD_STAMP
+#define CF_BUILD_STAMP "unstamped"
+#endif
+const char* cf_build_stamp(void) { return CF_BUILD_STAMP; }
+
 const char* cf_last_error(const cf_ctx* ctx) {
     if (!ctx) return g_error.c_str();
     static thread_local std::string copy;  // the text may be rewritten by another thread (window reader) after we return

@@ -118,6 +118,9 @@ function CoFluxBackend(device::Integer, grid::CfGrid, params::CfFluxParams)
     return backend
 end
 
+# sha256[:16] of the sources the loaded library was built from (include/coflux.h): compare with the tree the stub ships with
+build_stamp() = unsafe_string(ccall((:cf_build_stamp, libcoflux), Cstring, ()))
+
 default_flux_params() = (p = CfFluxParams(); ccall((:cf_default_flux_params, libcoflux), Cint, (Ref{CfFluxParams},), p); p)
 
 device_alloc(b, bytes) = ccall((:cf_device_alloc, libcoflux), Ptr{Cvoid}, (Ptr{Cvoid}, Csize_t), b.ctx, bytes)

@@ -316,6 +316,9 @@ typedef struct cf_interp_weights {
  * Lifecycle
  * ---------------------------------------------------------------------------------------- */
 int cf_version(void);
+/* The first 16 hex digits of the sha256 over the library's sources (csrc/*.{hip,cpp,hpp,h} and this header, in sorted
+ * order) as they were when it was built: a host binding compares it with the tree it ships with and refuses a stale build. */
+const char* cf_build_stamp(void);
 /* Creates a context bound to HIP device `device`.  Fails (CF_ERR_NODEVICE) when there is no GPU. */
 int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_params* params);
 int cf_destroy(cf_ctx* ctx);

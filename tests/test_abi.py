@@ -145,3 +145,16 @@ def test_solver_chunk_plan_covers_every_surface():
         rounds, unit = plan(total, cus, forced=-2)
         covered = sum(w * unit * n for w, n in rounds)
         assert rounds and all(n > 0 for _, n in rounds) and covered > total and covered - total <= max(w for w, _ in rounds) * unit + unit
+
+
+def test_loader_refuses_a_library_built_from_other_sources(tmp_path, monkeypatch):
+    """cf_build_stamp (sha256 of the sources at build time) against the tree the Python mirror sits in: a stale or foreign
+    libcoflux.so — an A/B build left in scratch/, one `LIBCOFLUX=` away from the tests — is refused unless the caller says
+    so."""
+    lib = abi.load_library()
+    assert lib.cf_build_stamp().decode() == abi.source_stamp() and len(abi.source_stamp()) == 16
+    monkeypatch.setattr(abi, "source_stamp", lambda: "0123456789abcdef")
+    with pytest.raises(abi.CofluxLibraryMissing, match="built from other sources"):
+        abi.load_library(abi.LIB_PATH)
+    monkeypatch.setenv("COFLUX_ALLOW_STALE_LIBRARY", "1")
+    assert abi.load_library(abi.LIB_PATH).cf_version() == abi.ABI_VERSION
