@@ -470,7 +470,13 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                     const LoopParams Lc = kread(&opaque(K)->L);
                     s = mo_iterate_certified<COARE>(Lc, c, tab, in_range, exact);
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(exact);
-                    if (m) {
+                    // (a workgroup's FIRST uncertified cells, met when its list is already handed out: the exact iteration at once,
+                    // from the registers they are in — a queue of one or two cells would cost the workgroup a lone wave's reload,
+                    // prologue and ≈ 15 dependent trips at its very end.  With the usual dozen per workgroup the queue has entries
+                    // long before that, and compaction — sixteen batches' cells in one — is what makes this path pay:
+                    // profiles/r05_experiments.md)
+                    const bool in_place = ((volatile int*)counters)[1] == 0 && ((volatile int*)counters)[0] >= nwet;
+                    if (m && !in_place) {
                         int slot = 0;
                         if (lane == 0) slot = atomicAdd(&counters[1], __popcll(m));
                         slot = __shfl(slot, 0) + __popcll(m & ((1ull << lane) - 1ull));
