@@ -625,16 +625,16 @@ def main():
 
         def variant_key(name):
             """profile kernel name → the key the roofline looks up: the lean solver's template variants are told apart
-            (<COARE, BLOCK, FUSE, FUSE_INTERP[, PIPE]>: the event-bracketed pass runs the un-pipelined one)"""
+            (<COARE, BLOCK, FUSE, FUSE_INTERP[, TAIL[, CERT]]>)"""
             base = name.split("<")[0].split("::")[-1].strip()
             if base == "ao_lean_kernel" and "<" in name:
                 t = [x.strip() for x in name.split("<")[1].split(">")[0].split(",")]
-                fuse_net, piped = t[2] == "true", len(t) > 4 and t[4] == "true"
-                return base + (":fused" if fuse_net else ":plain") + (":piped" if piped else "")
+                fuse_net, piped, cert = t[2] == "true", len(t) > 4 and t[4] == "true", len(t) > 5 and t[5] == "true"
+                return base + (":fused" if fuse_net else ":plain") + (":piped" if piped else "") + (":certified" if cert else "")
             return base
         traffic, traffic_source, sq, sq_source = {}, None, {}, None
         canonical = (nx, ny, a.flux_configuration, world, a.config) == (1440, 560, "default", 1, "ocean")
-        for tag in ("r04", "r03", "r02", "r01"):
+        for tag in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
                 if canonical:
@@ -644,7 +644,7 @@ def main():
                 break
             except Exception:
                 continue
-        for tag in ("r04", "r03"):
+        for tag in ("r05", "r04", "r03"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json")))
                 if canonical:
@@ -658,7 +658,8 @@ def main():
         # (--config sea_ice, the torch halo path) `ao_ms` is the solver stage alone, back to back, and so is its byte count —
         # with sea ice the ocean solve runs inside the interface solve's launch (ice_ocean_kernel), which has no roofline line here
         tail_priced = tail_mode and prof is not None
-        ao_key = (ao_kernel + (":fused" if fused else ":plain") + (":piped" if tail_priced else "")) if lean else ao_kernel
+        ao_key = (ao_kernel + (":fused" if fused else ":plain") + (":piped" if tail_priced else "") +
+                  (":certified" if chosen == "certified" else "")) if lean else ao_kernel
         ao_what = "compute_atmosphere_ocean_fluxes!" + (" + the cell-local part of compute_net_ocean_fluxes! in its epilogue" if fused else "")
         ao_bytes = BYTES_AO_FUSED if fused else BYTES_AO
         if tail_priced:   # the launch also interpolates the NEXT step's atmosphere state in its tail workgroups
@@ -739,13 +740,14 @@ def main():
         # strong-scaling projection from single-GPU measurements of one rank's slab (scratch/slab_curve.py): a PROJECTION,
         # labelled as such — the driver computes the real curve from its own N-GPU runs
         try:
-            sc = json.load(open(os.path.join(ROOT, "profiles", "r04f_slab_curve.json")))
+            sc = json.load(open(os.path.join(ROOT, "profiles", next(f for f in ("r05_slab_curve.json", "r04f_slab_curve.json")
+                                                                         if os.path.exists(os.path.join(ROOT, "profiles", f))))))
             if canonical and world == 1:
                 out["projected_scaling"] = dict(
                     kind="projection from one GPU, not a multi-GPU measurement",
                     speedup_before_halo_rows={k: round(v, 3) for k, v in sc["projected_speedup_before_halos"].items()},
                     slab_ms_per_step={k: round(v["ms_per_step"], 5) for k, v in sc["slabs"].items()},
-                    source="committed: profiles/r04f_slab_curve.json (python bench.py --ny 560/280/140/70 on one MI355X)",
+                    source="committed: profiles/r05_slab_curve.json, else r04f (python bench.py --ny 560/280/140/70 on one MI355X)",
                     note=sc["note"])
         except Exception:
             pass

@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 TAG=${1:-r02a}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --steps 20 --no-cpu-baseline > $OUT/bench_steps20.json 2>> $OUT/bench.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2>> $OUT/bench.err
 python bench.py --flux-configuration corrected --no-cpu-baseline > $OUT/bench_corrected.json 2>> $OUT/bench.err
 python bench.py --flux-configuration ncar --no-cpu-baseline > $OUT/bench_ncar.json 2>> $OUT/bench.err
 python bench.py --ny 70 --no-cpu-baseline > $OUT/bench_slab70.json 2>> $OUT/bench.err
@@ -48,6 +48,9 @@ PY
 rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ $OUT/pmc_SQ2
 python scratch/slab_curve.py $TAG > $OUT/slab_curve.log 2>&1
 python bench.py --config sea_ice --no-cpu-baseline > $OUT/bench_sea_ice.json 2>> $OUT/bench.err
+python bench.py --config sea_ice --ice-free-cells zero --no-cpu-baseline > $OUT/bench_sea_ice_zero.json 2>> $OUT/bench.err
+python bench.py --solver-path certified --no-cpu-baseline > $OUT/bench_certified.json 2>> $OUT/bench.err
+python bench.py --solver-path certified --flux-configuration corrected --no-cpu-baseline > $OUT/bench_certified_corrected.json 2>> $OUT/bench.err
 python bench.py --grid tripolar --nx 2160 --ny 1080 --flux-configuration corrected --no-cpu-baseline --no-sorted-pass > $OUT/bench_tripolar_2160x1080.json 2>> $OUT/bench.err
 python bench.py --grid tripolar --nx 360 --ny 180 --flux-configuration corrected --no-cpu-baseline --no-sorted-pass > $OUT/bench_tripolar_360x180.json 2>> $OUT/bench.err
 for f in bench bench_steps20 bench_corrected bench_ncar bench_slab70 bench_profiled; do python -c "

@@ -12,7 +12,8 @@ for ranks, ny in ((1, 560), (2, 280), (4, 140), (8, 70)):
         print(ny, "FAILED", r.stderr[-500:]); continue
     d = json.loads(line[-1])
     out[str(ranks)] = dict(ny=ny, ms_per_step=d["ms_per_step"], samples=d["ms_per_step_samples"], stages_ms=d["stages_ms"],
-                           solver_ms=d["roofline"]["avg_launch_ms"])
+                           solver_ms=d["roofline"]["avg_launch_ms"], solver_path=d["config"].get("solver_path"),
+                           solver_paths_ms_per_step=d.get("solver_paths_ms_per_step"))
     print(ranks, ny, d["ms_per_step"], json.dumps(d["stages_ms"]), flush=True)
 base = out["1"]["ms_per_step"]
 proj = {k: base / v["ms_per_step"] for k, v in out.items()}
