@@ -586,10 +586,14 @@ def main():
     # dependent kernels cost stream time, so they stay out of the region `value` is measured on) ------------------
     def instrumented(n, hints):
         ctx.set_option(abi.OPT_TRIP_HINTS, hints)
-        run_steps(best, sched, next_step, 4)                      # settle (and rebuild hints) after the switch
+        # settle (and rebuild hints) after the switch — and bring the clocks back up: the solver-path decision above ran the
+        # CPU oracle for a second with the device idle, and a cold device measured this pass's launches 10 % slow (85.9 vs
+        # 78.1 µs, profiles/r05_experiments.md §4).  The step count of the timed region's own settle loop: the same on every rank
+        idle = 4 + (settle.get(best) or 0)
+        run_steps(best, sched, next_step, idle)
         ctx.set_option(abi.OPT_PROFILE_STRIDE, 1)
         ctx.profile_enable(n)
-        run_steps(best, sched, next_step + 4, n)
+        run_steps(best, sched, next_step + idle, n)
         out = [ctx.profile_read(k) for k in range(3)]
         ctx.profile_enable(0)
         return out
