@@ -120,11 +120,11 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 // other set of exchange fields with the tiled routine of interpolate_kernel — memory-bound work under the solver's
 // FP64-bound tail instead of a launch of its own in front of the next solver (cf_time_steps with two exchange sets).
 // CERT: the certified reduced-iteration solve (coflux_certified.hpp).  A batch runs mo_iterate_certified; the lanes it
-// does not certify put their list position into a queue in LDS (the trip-count histogram's space: this mode does not
-// sort) and skip the epilogue.  The LAST wave of the workgroup to run out of batches takes the queue in batches of its
-// own through the exact iteration (mo_iterate_lean) — ≈ 1 % of the cells, compacted per workgroup instead of holding
-// their whole batch for the reference's trip count; entries beyond the queue's capacity run the exact iteration in
-// their own batch, at once.
+// does not certify (≈ 1.5 % of the cells) put their list position into a queue in LDS (the trip-count histogram's space:
+// this mode does not sort) and skip the epilogue.  The first wave of the workgroup to run out of batches closes the queue
+// and works it off as one batch of the exact iteration (mo_iterate_lean) — compaction: sixteen batches' cells in one —;
+// cells that fail their certificate after the close, entries beyond the queue's capacity, and a workgroup's first
+// uncertified cells when its list is already handed out run the exact iteration in their own batch at once.
 template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false, bool CERT = false>
 __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
     using Geo = LeanGeom<BLOCK>;
@@ -242,6 +242,9 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
     }
     if (tid < 4) counters[tid] = 0;
     if (tid < AO_BINS) hist[tid] = 0;
+    if constexpr (CERT) {  // the exact-path queue (hist + cursor): every entry invalid until its producer has written it
+        if (tid < 2 * AO_BINS) hist[tid] = -1;
+    }
     LEAN_STAMP(1);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): my mask words and my share of the DMA have landed
     LEAN_STAMP(2);
@@ -343,6 +346,9 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                 end = begin + CHUNK;
                 __syncthreads();
                 if (tid < 4) counters[tid] = 0;
+                if constexpr (CERT) {
+                    if (tid < 2 * AO_BINS) hist[tid] = -1;
+                }
                 __syncthreads();
                 continue;
             }
@@ -357,6 +363,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
         };
         // CERT: the queue of list positions whose cells go down the exact path, and whether this wave is working it off
         constexpr int QUEUE_CAP = 2 * AO_BINS;
+        constexpr int QUEUE_CLOSED = 1 << 20;
         int* queue = hist;  // (hist and cursor are contiguous)
         static_assert(Geo::CURSOR_OFFSET == Geo::HIST_OFFSET + AO_BINS * 4, "the exact-path queue spans the histogram and the cursors");
         bool straggling = false;
@@ -426,16 +433,21 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             if constexpr (CERT) {
                 if (!straggling && start >= nwet) {
                     LEAN_STAMP(4);  // (stamped builds: the end phase of a certified wave is its share of the exact-path queue)
-                    // no batch left for this wave.  The last wave of the workgroup to get here works the queue off: every
-                    // other wave has made its entries before it counted itself out (LDS operations of a wave stay in order)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    int gone = 0;
-                    if (lane == 0) gone = atomicAdd(&counters[3], 1);
-                    gone = __shfl(gone, 0);
-                    if (gone != Geo::WAVES - 1) break;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    limit = min(((volatile int*)counters)[1], QUEUE_CAP);
-                    if (limit <= 0) break;
+                    // no batch left for this wave.  The FIRST wave of the workgroup to get here closes the queue and works it
+                    // off: one atomic add of QUEUE_CLOSED onto the fill count returns the number of entries reserved so far —
+                    // the closer waits for those to be written — and every later reservation lands beyond the capacity, i.e.
+                    // on the in-place path: the (at most three) batches still in flight run the exact iteration on their own
+                    // uncertified cells, from registers.  The queue batch — reload, prologue, the slowest of a dozen lanes'
+                    // ≈ 15 trips: ≈ 20 µs for a lone wave — then runs BESIDE the workgroup's last certified batches instead of
+                    // behind them (the last wave taking the queue: 65.7 µs per launch, the first: 62.2; closing a round
+                    // earlier: 70.0 — seven of sixteen batches then pay the in-place price; profiles/r05_experiments.md §1)
+                    int filled = 0;
+                    if (lane == 0) filled = atomicAdd(&counters[1], QUEUE_CLOSED);
+                    filled = __shfl(filled, 0);
+                    if (filled <= 0 || filled >= QUEUE_CLOSED) break;
+                    limit = min(filled, QUEUE_CAP);
+                    for (int e = lane; e < limit; e += 64)
+                        while (((volatile int*)queue)[e] < 0) __builtin_amdgcn_s_sleep(1);
                     straggling = true;
                     start = 0;
                     raw = request(start);
@@ -564,6 +576,9 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
         end = range_end;
         __syncthreads();  // list and counters are reused
         if (tid < 4) counters[tid] = 0;
+        if constexpr (CERT) {
+            if (tid < 2 * AO_BINS) hist[tid] = -1;
+        }
         __syncthreads();
     }
     if constexpr (!CERT) LEAN_STAMP(4);
