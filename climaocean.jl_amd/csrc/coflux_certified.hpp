@@ -220,6 +220,9 @@ __device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, cons
         const float rX = __builtin_amdgcn_rcpf(dX);
         const float a = (dg1_u * dx2_c - dg2_u * s_c) * rX, b = (dg2_u * s_u - dg1_u * dx2_u) * rX;
         const float cj = (dg1_c * dx2_c - dg2_c * s_c) * rX, d = (dg2_c * s_u - dg1_c * dx2_u) * rX;
+        // the linear regime the bound presumes, and a reference that stops on its drift rather than on maxiter: ρ(J) < 0.6
+        const float tr = a + d, dj = a * d - b * cj, disc = tr * tr - 4.f * dj;
+        const float rho_j = disc >= 0.f ? 0.5f * (fabsf(tr) + __builtin_sqrtf(disc)) : __builtin_sqrtf(dj);
         const float det = (a - 1.f) * (d - 1.f) - b * cj;
         const float rd = __builtin_amdgcn_rcpf(det);
         const float i11 = (d - 1.f) * rd, i12 = -b * rd, i21 = -cj * rd, i22 = (a - 1.f) * rd;
@@ -236,7 +239,7 @@ __device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, cons
         bound = fmaxf(bound, (kd_c * eq) * __builtin_amdgcn_rcpf(fmaxf(kd_c * ux, 1.f)));
         bound = fmaxf(bound, (kd_v * eq) * __builtin_amdgcn_rcpf(fmaxf(kd_v * ux, 1.f)));
         bound = fmaxf(bound, (kd_f * eq) * __builtin_amdgcn_rcpf(fmaxf(kd_f * ux, 1e-6f)));
-        certified = done && !failed && okJ && bound <= (float)L.cert_budget;  // (NaN anywhere: not certified)
+        certified = done && !failed && okJ && rho_j < 0.6f && bound <= (float)L.cert_budget;  // (NaN anywhere: not certified)
     }
     need_exact = active && !certified;
     return Scales{us, chi * c.dtheta, chi * c.dq, it, it};

@@ -105,8 +105,11 @@ hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32
 }
 
 bool lean_certified_applies(const LaunchCfg& L, const LoopParams& C, bool fused_interp) {
+    // (maxiter ≥ 40: a cell is certified only where the map's spectral radius is below 0.6 — from the 1e-4 first guess the
+    // reference then needs fewer than 40 trips to bring its drift under any tolerance ≥ 1e-9, i.e. it stops on the drift,
+    // not on the cap, which the certificate presumes)
     return L.certified && C.specialization == SOLVER_OCEAN_LEAN && !C.fixed && !L.ao_wide && L.lean_hints == 0 && !fused_interp &&
-           C.cert_max_evals > 2 && C.tol > 0;
+           C.cert_max_evals > 2 && C.tol >= 1e-9 && C.maxiter >= 40;
 }
 
 // the argument block of one ocean solve (everything but the tail workgroups' and the fused interpolation's descriptors)

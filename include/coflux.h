@@ -402,7 +402,7 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * iterate loosely determined) are solved by the exact path inside the same launch, so that EVERY
                                    * cell is within the budget of the exact path's result.  Decisions are per cell: a result never
                                    * depends on which cells share its wave, chunk or rank.  Applies where the round-3 ocean kernel
-                                   * runs in its narrow geometry under the convergence stop rule (cf_solver_iteration_path tells);
+                                   * runs in its narrow geometry under the convergence stop rule with tolerance ≥ 1e-9 and maxiter ≥ 40 (cf_solver_iteration_path tells);
                                    * FixedIterations(n), CoefficientBasedFluxes and the sea-ice interface always take the exact path.
                                    * In this mode the optional `iterations` output is a diagnostic: the number of map evaluations of a
                                    * certified cell, or CF_CERTIFIED_EXACT_FLAG | (the reference's trip count) for an exact-path cell;

@@ -222,3 +222,19 @@ def test_certified_budget_option_and_path_query():
             e = util.rel_err(util.window(got["fluxes"][k], 3, 3, 360, 80, 1), util.window(ref["fluxes"][k], 3, 3, 360, 80, 1), util.FIELD_SCALE[k])
             assert e <= ppb * 1e-9 + 5e-8, (ppb, k, e)
     assert shares[0] > shares[1] > shares[2] > 0
+
+
+def test_certified_path_needs_a_reference_that_stops_on_its_drift():
+    """The certificate presumes the reference's iteration stops on its drift test: with a cap below 40 trips, or a tolerance
+    below 1e-9, the option falls back to the exact path (cf_solver_iteration_path says so) and results are the exact path's."""
+    for stop in (ic.ConvergenceStopCriteria(tolerance=1e-8, maxiter=30), ic.ConvergenceStopCriteria(tolerance=1e-10, maxiter=100)):
+        params = ic.flux_params(ic.SimilarityTheoryFluxes(solver_stop_criteria=stop))
+        ctx = FluxContext(90, 40, 3, 3, params)
+        ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
+        assert ctx.solver_iteration_path() == abi.SOLVER_PATH_EXACT
+        ctx.close()
+        case = util.build_case(90, 40)
+        a = run_gpu(case, params, options=CERTIFIED)
+        b = run_gpu(case, params)
+        for k in a["fluxes"]:
+            np.testing.assert_array_equal(a["fluxes"][k], b["fluxes"][k], err_msg=k)
