@@ -401,7 +401,8 @@ class ComponentInterfaces:  # noqa: D101 — documented below
                  atmosphere_sea_ice_fluxes=None, atmosphere_ocean_velocity_difference=None,
                  atmosphere_sea_ice_velocity_difference=None, sea_ice_properties=None, ocean_minimum_salinity=0.0,
                  ocean_properties=None, store_similarity_scales=False, sea_ice_ocean_heat_flux=None,
-                 sea_ice_albedo=None, time_step=20 * minutes):
+                 sea_ice_albedo=None, time_step=20 * minutes, solver_path="exact", certified_budget=8e-7,
+                 ice_free_cells="iterate"):
         grid = ocean.grid
         (nx, ny, _), (hx, hy, _) = grid.size, grid.halo
         self.radiation = radiation or Radiation()
@@ -416,6 +417,16 @@ class ComponentInterfaces:  # noqa: D101 — documented below
                                 stefan_boltzmann_constant=self.radiation.stefan_boltzmann_constant)
         self.context = FluxContext(nx, ny, hx, hy, params, ring=1, device=grid.device)
         ctx = self.context
+        # implementation choices of this backend, not reference keywords (include/coflux.h): how the similarity fixed point is
+        # reached — "exact" = the reference's iteration, "certified" = the reduced-iteration solve, every cell within
+        # `certified_budget` of the exact path's fluxes — and what the sea-ice interface does on open water
+        if solver_path not in ("exact", "certified") or ice_free_cells not in ("iterate", "zero"):
+            raise ValueError(f"solver_path = {solver_path!r} (exact | certified), ice_free_cells = {ice_free_cells!r} (iterate | zero)")
+        if solver_path == "certified":
+            ctx.set_option(abi.OPT_CERTIFIED_BUDGET, int(round(certified_budget * 1e9)))
+            ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
+        if ice_free_cells == "zero":
+            ctx.set_option(abi.OPT_ICE_FREE_CELLS, abi.ICE_FREE_ZERO)
         self.weights = grid.interpolation_weights(ctx.to_device)
         self.fold_north = bool(getattr(grid, "fold_north", False))
         # interfaces.exchange_atmosphere_state — the reference updates ONE field set in place.  Here it is a property over two

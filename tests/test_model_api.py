@@ -298,3 +298,33 @@ def test_config3_with_three_equation_exchange_and_ccsm3_albedo():
     bot = model.interfaces.net_fluxes.sea_ice.bottom_heat.cpu().numpy()
     assert util.rel_err(W(top)[conv], W(nsi["top_heat"])[conv], 1.0) < 1e-8
     assert util.rel_err(W(bot), W(nsi["bottom_heat"]), 1.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_model_runs_on_the_certified_solver_path_within_its_budget():
+    """ComponentInterfaces(…; solver_path = "certified"): run!(simulation) with the tail-workgroup pipeline on the certified
+    path against the same run on the exact path — net fluxes and interface fluxes within 1e-6 of the components' scales,
+    and the context says which path ran."""
+    import torch
+    from coflux import abi
+    nx, ny, nz, h = 360, 140, 10, 4
+    grid = cm.LatitudeLongitudeGrid(size=(nx, ny, nz), halo=(h, h, h), latitude=(-70, 70), z=(-3000, 0))
+    state = syn.ocean_state(nx, ny, h, h)
+    snaps = syn.jra55_snapshots(4)
+    out = {}
+    for path in ("exact", "certified"):
+        ocean = cm.ocean_simulation(grid)
+        cm.set_surface(ocean, T=state["T"], S=state["S"], u=state["u"], v=state["v"], mask=state["mask"])
+        atmosphere = cm.JRA55PrescribedAtmosphere(snaps)
+        itf = cm.ComponentInterfaces(atmosphere, ocean, solver_path=path)
+        coupled = cm.OceanSeaIceModel(ocean, atmosphere=atmosphere, interfaces=itf)
+        assert itf.context.solver_iteration_path() == (abi.SOLVER_PATH_CERTIFIED if path == "certified" else abi.SOLVER_PATH_EXACT)
+        cm.run(cm.Simulation(coupled, dt=30 * cm.minutes, stop_iteration=5))
+        f = itf.atmosphere_ocean_interface.fluxes
+        out[path] = {k: getattr(f, k).cpu().numpy().copy() for k in ("sensible_heat", "latent_heat", "water_vapor", "x_momentum", "y_momentum")}
+        itf.context.close()
+    for k, scale in (("sensible_heat", 1.0), ("latent_heat", 1.0), ("water_vapor", 1e-6), ("x_momentum", 1e-3), ("y_momentum", 1e-3)):
+        a, b = out["certified"][k], out["exact"][k]
+        err = np.abs(a - b) / np.maximum(np.abs(b), scale)
+        assert err.max() <= 1e-6, (k, float(err.max()))
+        assert err.max() > 0, k     # (it IS another path)
