@@ -238,3 +238,40 @@ def test_certified_path_needs_a_reference_that_stops_on_its_drift():
         b = run_gpu(case, params)
         for k in a["fluxes"]:
             np.testing.assert_array_equal(a["fluxes"][k], b["fluxes"][k], err_msg=k)
+
+
+def test_certified_path_on_a_stale_chunk_table():
+    """A mask rewritten in place sends every workgroup through the classification path, range piece by range piece — the
+    exact-path queue and its counters are re-armed per piece.  Results must be what a fresh context gives, bit for bit
+    (certified and exact-path cells alike), through: almost-all-land → all-ocean (the lists overflow), then the real mask."""
+    params = ic.flux_params(ic.SimilarityTheoryFluxes())
+    nx, ny, h = 300, 64, 4
+    case = util.build_case(nx, ny, h, h)
+
+    def fresh(mask_np):
+        c2 = dict(case, ocean=dict(case["ocean"], mask=mask_np))
+        return run_gpu(c2, params, options=CERTIFIED)["fluxes"]
+
+    ctx = FluxContext(nx, ny, h, h, params)
+    ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
+    dev = ctx.to_device
+    src = {k: dev(v) for k, v in case["src"].items()}
+    w = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in case["weights"].items()}
+    atmos = ctx.field_set(EXCHANGE_NAMES)
+    ctx.interpolate_atmosphere_state(src, w, atmos, 0, 1, 0.37)
+    ocean = {k: dev(case["ocean"][k]) for k in ("T", "S", "u", "v", "mask")}
+    mostly_land = np.zeros_like(case["ocean"]["mask"])
+    mostly_land[::7, ::5] = 1
+    seen_exact = False
+    for mask_np in (mostly_land, np.ones_like(mostly_land), case["ocean"]["mask"]):
+        ocean["mask"].copy_(torch.from_numpy(mask_np))            # same pointer: the chunk table of the first call is stale
+        fluxes = ctx.field_set(FLUX_NAMES, FLUX_OPTIONAL)
+        fluxes["iterations"] = ctx.zeros(torch.int32)
+        ctx.compute_atmosphere_ocean_fluxes(ocean, atmos, fluxes)
+        ctx.sync()
+        want = fresh(mask_np)
+        for k in want:
+            np.testing.assert_array_equal(fluxes[k].cpu().numpy(), want[k], err_msg=k)
+        seen_exact |= bool(np.any(want["iterations"] & abi.CERTIFIED_EXACT_FLAG))
+    assert seen_exact
+    ctx.close()
