@@ -726,7 +726,9 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
                     c.alpha_g = alpha * P.inv_g;
                     Ts = S.top_temperature[k] + Ice.T_offset;
                     // CF_OPT_ICE_FREE_CELLS = zero: open water (ℵ = 0 and hᵢ = 0) has no atmosphere–sea-ice interface
+#ifndef CF_NO_ICE_FREE_OPTION  // (A/B builds: what the option's test costs the default mode — nothing measurable)
                     if (Ice.ice_free_zero != 0.0 && S.concentration) ice_free = S.concentration[k] == 0.0 && S.thickness[k] == 0.0;
+#endif
                 }
                 Scales s{0.0, 0.0, 0.0, 0, 0};
                 const bool solve = in_range && !ice_free;
