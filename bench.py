@@ -169,15 +169,27 @@ def oracle_reference(case_np, params, nx, ny, h):
                 net={k: net[k] for k in ("u", "v", "T", "S", "shortwave_surface_flux")})
 
 
-def measured_parity(ctx, ref, dev_case, nx, ny, h):
+def measured_parity(ctx, ref, dev_case, nx, ny, h, shares=None):
     """One cf_update_state on the inputs the CPU baseline ran on (time fraction 0.37, snapshot levels 0/1), compared
     with the oracle's outputs of that leg: worst |Δ| / max(|ref|, field scale) per field over interior + ring (fluxes)
     / interior (net fluxes).  The oracle is the checker here, never the thing measured."""
     import numpy as np
     from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, NET_NAMES
+    import torch
+    from coflux import abi
     atmos, fl, net = ctx.field_set(EXCHANGE_NAMES), ctx.field_set(FLUX_NAMES), ctx.field_set(NET_NAMES)
+    if shares is not None:  # (the diagnostic output: which cells the certified path sent down the exact one)
+        fl["iterations"] = torch.zeros_like(fl["temperature"], dtype=torch.int32)
     ctx.update_state(dev_case["src"], dev_case["weights"], dev_case["ocean"], atmos, fl, net, time_fraction=0.37)
     ctx.sync()
+    if shares is not None:
+        it = fl.pop("iterations").cpu().numpy()
+        solved = it > 0
+        exact = (it & abi.CERTIFIED_EXACT_FLAG) != 0
+        shares["cells_solved"] = int(solved.sum())
+        shares["exact_path_share"] = float(exact.sum() / max(1, solved.sum()))
+        shares["mean_map_evaluations_certified_cells"] = float(it[solved & ~exact].mean()) if (solved & ~exact).any() else None
+        shares["mean_trips_exact_path_cells"] = float((it[exact] & 0xff).mean()) if exact.any() else None
     out = {}
     W1 = (slice(h - 1, h + ny + 1), slice(h - 1, h + nx + 1))
     W0 = (slice(h, h + ny), slice(h, h + nx))
@@ -560,16 +572,18 @@ def main():
             path_results["certified"] = timed(best)
             path_per_rank["certified"] = per_rank.get(best)
             ref_rank = oracle_reference(dict(ocean=ocean_np[0], src=src_np, weights=w_np), params, nx, ny, h)
-            worst = measured_parity(ctx, ref_rank, dict(src=src, weights=w, ocean=states[0]), nx, ny, h)
+            shares = {}
+            worst = measured_parity(ctx, ref_rank, dict(src=src, weights=w, ocean=states[0]), nx, ny, h, shares=shares)
             # decided on EVERY field parity_measured reports — the six flux fields (the north star's statement) and the net
-            # fluxes assembled from them.  J_S ∝ F_v − P can cancel to nothing, so its error relative to its own small floor
-            # is not bounded by the fields' budget: with today's floors that keeps `value` on the exact path
+            # fluxes assembled from them.  (J_S ∝ F_v − P can cancel to nothing: the certificate bounds the vapour flux against
+            # |F_v − P| as well, coflux_certified.hpp::CertNetSalt.  The face stresses average two cells' ρτ and can cancel too —
+            # nothing bounds that per cell; it is measured here, on every rank, and decides with the rest)
             six = max(v for k, v in worst.items() if k.startswith("fluxes."))
             flag = torch.tensor([max(worst.values()), six], dtype=torch.float64, device=coll_dev)
             if world > 1:
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             path_parity["certified"] = dict(max_over_ranks=float(flag[0].item()), max_six_flux_fields_over_ranks=float(flag[1].item()),
-                                            worst_scaled_error_rank0=worst,
+                                            worst_scaled_error_rank0=worst, exact_path_cells_rank0=shares,
                                             metric="|got - oracle exact path| / max(|oracle|, field scale), one cf_update_state per rank")
             if float(flag[0].item()) <= 1e-6 and path_results["certified"][0] < path_results["exact"][0]:
                 chosen = "certified"

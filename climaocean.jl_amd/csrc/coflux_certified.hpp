@@ -19,8 +19,11 @@
 //     |d_u| + (|Δθ| + |Δq|)|d_χ| < tol; in the linear regime x_n − x★ = J (J − I)⁻¹ d with J the map's Jacobian at the
 //     fixed point, which the last two secant pairs give for free.  The bound is the maximum of the flux error over all
 //     drifts the stop rule admits, times a safety factor for the secant Jacobian's accuracy;
-//   * lanes whose bound exceeds the budget (≈ 1 % at 8e-7: near-neutral cells, where the absolute drift test leaves χ
-//     loosely determined, and dead-calm cells), lanes without a usable secant model and lanes that have not converged in
+//   * a seventh term holds the vapour flux to budget · max(|F_v − M_p|, floor) as well (CertNetSalt below): the net
+//     salinity flux J_S ∝ F_v − M_p can cancel to nothing, and an error bounded relative to |F_v| alone then shows in it
+//     amplified (measured: 1.8e-6 of J_S's own scale without the term, 5.4e-7 with it; it doubles the uncertified share);
+//   * lanes whose bound exceeds the budget (≈ 2 % at 8e-7: near-neutral cells, where the absolute drift test leaves χ
+//     loosely determined, dead-calm cells, cells whose evaporation nearly cancels their precipitation), lanes without a usable secant model and lanes that have not converged in
 //     `cert_max_evals` evaluations are NOT certified: the caller sends them down the exact path (mo_iterate_lean, the
 //     reference's own iteration) — never a per-wave decision, a cell's result does not depend on its neighbours.
 // Per-lane results are a pure function of the cell's inputs (no state carried between calls).
@@ -37,10 +40,24 @@ constexpr int CERT_EXACT_FLAG = 0x100;
 constexpr double CERT_ACCEPT = 0x1p-23;
 constexpr int CERT_MAX_EVALS = 10;
 
+// Floor of the net salinity flux J_S in the certificate's seventh term (m s⁻¹ psu; the parity metric's scale of that field,
+// tests/util.py::FIELD_SCALE["S"], bench.py::PARITY_SCALE)
+constexpr float CERT_JS_FLOOR = 1e-7f;
+
+// What the launch knows of the cell's net salinity flux J_S = −S (F_v − M_p)/ρ_f (compute_net_ocean_fluxes!): evaporation can
+// cancel precipitation, and the vapour flux's own budget, relative to |F_v|, then says nothing about J_S.  With the
+// precipitation at hand (the launch that assembles the net fluxes has it) the certificate also bounds the vapour flux's error
+// by budget · max(|F_v − M_p|, floor_v), floor_v = CERT_JS_FLOOR ρ_f / S.  FP32: it is a threshold, not a result.
+struct CertNetSalt {
+    float Mp = 0.f;                            // rain + snow, kg m⁻² s⁻¹ (positive down)
+    float floor_v = __builtin_inff();          // +inf: the term is off (no net fluxes assembled by this launch)
+};
+
 // All 64 lanes of a wave must call this together.  `active` lanes solve; on return `need_exact` is set for the active
 // lanes that are not certified (their Scales are meaningless).  Scales.it = evaluations of the map.
 template <bool COARE>
-__device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, const LeanCell& c, const double* tab, bool active, bool& need_exact) {
+__device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, const LeanCell& c, const double* tab, bool active, bool& need_exact,
+                                                       const CertNetSalt ns = CertNetSalt{}) {
     const double* logt = tab + LOG_OFFSET;
     const double B = __builtin_fma(c.dtheta, c.bth, c.bqq * c.dq);
     // ---- first guess: the neutral profile of THIS cell, then an effective stability correction ----
@@ -239,6 +256,8 @@ __device__ __forceinline__ Scales mo_iterate_certified(const LoopParams& L, cons
         bound = fmaxf(bound, (kd_c * eq) * __builtin_amdgcn_rcpf(fmaxf(kd_c * ux, 1.f)));
         bound = fmaxf(bound, (kd_v * eq) * __builtin_amdgcn_rcpf(fmaxf(kd_v * ux, 1.f)));
         bound = fmaxf(bound, (kd_f * eq) * __builtin_amdgcn_rcpf(fmaxf(kd_f * ux, 1e-6f)));
+        // the net salinity flux: F_v = −ρ u★ χ Δq against the precipitation it may cancel
+        bound = fmaxf(bound, (kd_f * eq) * __builtin_amdgcn_rcpf(fmaxf(fabsf(__builtin_fmaf(rho * dq, ux, ns.Mp)), ns.floor_v)));
         certified = done && !failed && okJ && rho_j < 0.6f && bound <= (float)L.cert_budget;  // (NaN anywhere: not certified)
     }
     need_exact = active && !certified;

@@ -125,6 +125,9 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 // and works it off as one batch of the exact iteration (mo_iterate_lean) — compaction: sixteen batches' cells in one —;
 // cells that fail their certificate after the close, entries beyond the queue's capacity, and a workgroup's first
 // uncertified cells when its list is already handed out run the exact iteration in their own batch at once.
+#ifndef CF_CERT_NET_SALT
+#define CF_CERT_NET_SALT 1  // (0: A/B builds without the certificate's net-salinity term)
+#endif
 template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false, bool CERT = false>
 __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
     using Geo = LeanGeom<BLOCK>;
@@ -456,12 +459,25 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             if (start >= limit) break;
             const int q = start + lane;
             const bool in_range = q < limit;
+            double Mp_now = 0.0;
+            const double raw_So = raw.So;
+            if constexpr (CERT && CF_CERT_NET_SALT) {
+                if (!straggling) Mp_now = FUSE_INTERP ? raw.Mp : gload(opaque(K)->E.Mp, (unsigned)cell_of(start) * 8u);
+            }
             // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
             const LeanCell c = lean_prologue(P, L.kappa, tab, raw.ua, raw.va, raw.Ta, raw.pa, raw.qa, 0.5 * (raw.u0 + raw.u1),
                                              0.5 * (raw.v0 + raw.v1), raw.To, raw.So);
             // the interface temperature does not depend on the iteration: written now, not carried across it
             if (in_range) gstore(opaque(K)->F.Ts, (unsigned)cell_of(start) * 8u, c.Ts - T_offset);
             const double Qs_kept = raw.Qs, Ql_kept = raw.Ql, Mp_kept = raw.Mp;  // (dead unless FUSE_INTERP)
+            CertNetSalt net_salt;
+            if constexpr (CERT && CF_CERT_NET_SALT) {
+                // J_S is assembled from the vapour flux (by this launch's epilogue or by net_cell_kernel): the certificate is
+                // told what it may cancel against — in every certified launch, so that a cell's bits do not depend on the schedule
+                // (two FP32 registers across the iteration; the precipitation is read again, in FP64, where J_S is assembled)
+                net_salt.Mp = (float)Mp_now;
+                net_salt.floor_v = CERT_JS_FLOOR * __builtin_amdgcn_rcpf((float)raw_So * (float)P.rho_f_inv);
+            }
 #if CF_LEAN_PREFETCH
             int next;
             if constexpr (CERT) next = straggling ? start + 64 : claim();
@@ -480,7 +496,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                     // lifetime beside the exact iteration's and the batch loop's they do not fit the scalar registers —
                     // 36 v_readlane per trip of the iteration were measured that way)
                     const LoopParams Lc = kread(&opaque(K)->L);
-                    s = mo_iterate_certified<COARE>(Lc, c, tab, in_range, exact);
+                    s = mo_iterate_certified<COARE>(Lc, c, tab, in_range, exact, net_salt);
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(exact);
                     // (a workgroup's FIRST uncertified cells, met when its list is already handed out: the exact iteration at once,
                     // from the registers they are in — a queue of one or two cells would cost the workgroup a lone wave's reload,

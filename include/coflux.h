@@ -316,7 +316,7 @@ typedef struct cf_interp_weights {
  * Lifecycle
  * ---------------------------------------------------------------------------------------- */
 int cf_version(void);
-/* The first 16 hex digits of the sha256 over the library's sources (csrc/*.{hip,cpp,hpp,h} and this header, in sorted
+/* The first 16 hex digits of the sha256 over the library's sources (csrc/ *.hip, *.cpp, *.hpp, *.h and this header, in sorted
  * order) as they were when it was built: a host binding compares it with the tree it ships with and refuses a stale build. */
 const char* cf_build_stamp(void);
 /* Creates a context bound to HIP device `device`.  Fails (CF_ERR_NODEVICE) when there is no GPU. */
@@ -395,11 +395,15 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * Anderson(2) steps (4–6 evaluations per cell instead of 8–20), and a per-cell CERTIFICATE that
                                    * the fixed point lies within CF_OPT_CERTIFIED_BUDGET of where the reference's stop rule would
                                    * have left its iterate, in the metric |Δ flux| ≤ budget · max(|flux|, floor) with the floors
-                                   * 1 W m⁻² (sensible, latent heat), 1e-6 kg m⁻² s⁻¹ (water vapour), 1e-3 N m⁻² (ρτx, ρτy).  The
+                                   * 1 W m⁻² (sensible, latent heat), 1e-6 kg m⁻² s⁻¹ (water vapour), 1e-3 N m⁻² (ρτx, ρτy) — and,
+                                   * because the net salinity flux J_S = −S (F_v − M_p)/ρ_f can cancel to nothing, the vapour flux also
+                                   * within budget · max(|F_v − M_p|, 1e-7 ρ_f / S) of the exact path's (M_p: the interpolated rain + snow),
+                                   * which holds J_S of open water to budget · max(|J_S|, 1e-7 m s⁻¹ psu).  The
                                    * bound is the worst case over every last drift the stop rule admits, from the map's Jacobian at
-                                   * the fixed point (csrc/coflux_certified.hpp).  Cells that cannot be certified (≈ 1 % at the default
+                                   * the fixed point (csrc/coflux_certified.hpp).  Cells that cannot be certified (≈ 2 % at the default
                                    * budget: near-neutral and dead-calm cells, where an absolute drift tolerance leaves the stopped
-                                   * iterate loosely determined) are solved by the exact path inside the same launch, so that EVERY
+                                   * iterate loosely determined — half of them — and cells whose evaporation all but cancels their
+                                   * precipitation) are solved by the exact path inside the same launch, so that EVERY
                                    * cell is within the budget of the exact path's result.  Decisions are per cell: a result never
                                    * depends on which cells share its wave, chunk or rank.  Applies where the round-3 ocean kernel
                                    * runs in its narrow geometry under the convergence stop rule with tolerance ≥ 1e-9 and maxiter ≥ 40 (cf_solver_iteration_path tells);

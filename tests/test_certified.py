@@ -83,6 +83,25 @@ def test_quarter_degree_surface_certified_against_the_exact_oracle(config):
     assert max(worst[k] for k in SIX) <= 8.5e-7
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_net_salinity_flux_is_certified_against_the_precipitation(fused):
+    """J_S = −S (F_v − M_p)/ρ_f: evaporation can cancel precipitation, so the certificate also bounds the vapour flux's
+    error relative to max(|F_v − M_p|, 1e-7 ρ_f / S) (coflux_certified.hpp::CertNetSalt).  Open water (no ice cover, no
+    ice–ocean salt flux in the sum): the net salinity flux is then within the plain 1e-6 · max(|J_S|, 1e-7) of the exact
+    path — fused epilogue and net_cell_kernel alike — and so is everything else."""
+    params = ic.flux_params(ic.SimilarityTheoryFluxes())
+    case = util.build_case(1440, 280, 5, 5)
+    got = run_gpu(case, params, fused=fused, options=CERTIFIED)
+    ref = run_oracle(case, params)
+    worst, share = compare_certified(case, got, ref, label=f"1440x280 open water, fused={fused}")
+    W = lambda a: util.window(a, 5, 5, 1440, 280, 0)
+    for k in ("T", "S"):
+        r = W(ref["net"][k])
+        e = float((np.abs(W(got["net"][k]) - r) / np.maximum(np.abs(r), util.FIELD_SCALE[k])).max())
+        print(f"[certified] net.{k} plain scaled error {e:.2e}")
+        assert e <= TOL_CERTIFIED, (k, e)
+
+
 def test_config5_sixth_degree_surface_certified():
     nx, ny, h = 2160, 1080, 7
     params = ic.flux_params(ic.corrected_atmosphere_ocean_fluxes(), velocity_difference=ic.RelativeVelocity())
