@@ -512,13 +512,21 @@ def main():
 
     settle, per_rank = {}, {}
 
-    def timed(name):
+    PATH_CODE = {"exact": abi.SOLVER_PATH_EXACT, "certified": abi.SOLVER_PATH_CERTIFIED}
+    SWITCH_STEPS = 4   # untimed steps after a change of CF_OPT_SOLVER_PATH inside the repetition loop
+
+    def timed(name, paths):
+        """Times `steps` steps `reps` times for every solver path in `paths` on halo backend `name`.  With two paths the
+        repetitions INTERLEAVE (exact, certified, exact, certified, …): the paths differ by 3 %, a device drifts by as much
+        within a second of running, and whichever is timed second would carry the drift (measured: the same path 0.0825 →
+        0.0845 ms over three consecutive runs of this script on one box; profiles/r05_experiments.md)."""
         sched = schedule_for(name)
         # Clocks first: a cold device needs tens of milliseconds of work before it holds its sustained clock, and a
         # 20-step region is 3 ms.  Untimed steps until ≈ 0.15 s have passed, then the W warm-up steps the caller asked
         # for, then exactly K timed steps — so that --steps 20 and --steps 1000 measure the same machine state.
         # (every rank must run the SAME number of steps — the halo rows pair up step by step — so the ranks agree on
         # when to stop: all of them have been busy for 0.15 s)
+        ctx.set_option(abi.OPT_SOLVER_PATH, PATH_CODE[paths[0]])
         done, t_start = 0, time.perf_counter()
         while True:
             run_steps(name, sched, done, 50)
@@ -533,62 +541,81 @@ def main():
                 break
         settle[name] = done
         run_steps(name, sched, done, warmup)
-        first, samples, by_rank = done + warmup, [], []
+        first = done + warmup
+        samples, by_rank = {q: [] for q in paths}, {q: [] for q in paths}
+        switches = 0
         for _ in range(reps):
-            barrier()
-            t0 = time.perf_counter()
-            run_steps(name, sched, first, steps)
-            barrier()
-            dt = time.perf_counter() - t0
-            if world > 1:
-                every = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
-                dist.all_gather(every, torch.tensor([dt], dtype=torch.float64, device=coll_dev))
-                by_rank.append([float(x.item()) for x in every])
-                dt = max(by_rank[-1])           # the MAX over ranks is the step time of the job
-            samples.append(dt)
-            first += steps
-        med = statistics.median(samples)
-        per_rank[name] = by_rank[samples.index(med)] if by_rank and med in samples else None
-        return med, samples, sched, first
-
-    results = {}
-    for name in (list(exchangers) or ["none"]):
-        results[name] = timed(name)
-    best = min(results, key=lambda k: results[k][0])
+            for q in paths:
+                if len(paths) > 1:
+                    ctx.set_option(abi.OPT_SOLVER_PATH, PATH_CODE[q])
+                    run_steps(name, sched, first, SWITCH_STEPS)
+                    first += SWITCH_STEPS
+                    switches += 1
+                barrier()
+                t0 = time.perf_counter()
+                run_steps(name, sched, first, steps)
+                barrier()
+                dt = time.perf_counter() - t0
+                if world > 1:
+                    every = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+                    dist.all_gather(every, torch.tensor([dt], dtype=torch.float64, device=coll_dev))
+                    by_rank[q].append([float(x.item()) for x in every])
+                    dt = max(by_rank[q][-1])           # the MAX over ranks is the step time of the job
+                samples[q].append(dt)
+                first += steps
+        switch_steps[name] = switches * SWITCH_STEPS
+        out = {}
+        for q in paths:
+            med = statistics.median(samples[q])
+            out[q] = (med, samples[q], sched, first,
+                      by_rank[q][samples[q].index(med)] if by_rank[q] and med in samples[q] else None)
+        return out
 
     # ---- the two solver paths (CF_OPT_SOLVER_PATH) ---------------------------------------------------------------------
-    # `results` above ran the path the command line asked for (auto: the exact one).  With auto the certified path is timed
-    # on the same schedule and halo backend, checked against the CPU oracle on THIS rank's surface (every rank, so that all
-    # ranks take the same decision at any N), and used for `value` only if every field is within 1e-6 and it is faster.
+    # The command line's path (auto: the exact one) is timed on every verified halo backend.  With auto the certified path
+    # is timed beside it, interleaved repetition by repetition on the same schedule and backend, checked against the CPU
+    # oracle on THIS rank's surface (every rank, so that all ranks take the same decision at any N), and used for `value`
+    # only if every field is within 1e-6 and its median is the smaller one.
     first_path = "certified" if a.solver_path == "certified" else "exact"
+    ctx.set_option(abi.OPT_SOLVER_PATH, PATH_CODE[first_path])
     if first_path == "certified" and ctx.solver_iteration_path() != abi.SOLVER_PATH_CERTIFIED:
         first_path = "exact"    # (the option does not apply to this formulation / geometry: the exact path ran)
-    path_results = {first_path: results[best]}
-    path_per_rank = {first_path: per_rank.get(best)}
-    path_parity, chosen = {}, first_path
-    if a.solver_path == "auto" and a.config == "ocean" and not tripolar:
+    paths = [first_path]
+    if a.solver_path == "auto" and a.config == "ocean":
         ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
         if ctx.solver_iteration_path() == abi.SOLVER_PATH_CERTIFIED:
-            path_results["certified"] = timed(best)
-            path_per_rank["certified"] = per_rank.get(best)
-            ref_rank = oracle_reference(dict(ocean=ocean_np[0], src=src_np, weights=w_np), params, nx, ny, h)
-            shares = {}
-            worst = measured_parity(ctx, ref_rank, dict(src=src, weights=w, ocean=states[0]), nx, ny, h, shares=shares)
-            # decided on EVERY field parity_measured reports — the six flux fields (the north star's statement) and the net
-            # fluxes assembled from them.  (J_S ∝ F_v − P can cancel to nothing: the certificate bounds the vapour flux against
-            # |F_v − P| as well, coflux_certified.hpp::CertNetSalt.  The face stresses average two cells' ρτ and can cancel too —
-            # nothing bounds that per cell; it is measured here, on every rank, and decides with the rest)
-            six = max(v for k, v in worst.items() if k.startswith("fluxes."))
-            flag = torch.tensor([max(worst.values()), six], dtype=torch.float64, device=coll_dev)
-            if world > 1:
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            path_parity["certified"] = dict(max_over_ranks=float(flag[0].item()), max_six_flux_fields_over_ranks=float(flag[1].item()),
-                                            worst_scaled_error_rank0=worst, exact_path_cells_rank0=shares,
-                                            metric="|got - oracle exact path| / max(|oracle|, field scale), one cf_update_state per rank")
-            if float(flag[0].item()) <= 1e-6 and path_results["certified"][0] < path_results["exact"][0]:
-                chosen = "certified"
-        if chosen != "certified":
-            ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_EXACT)
+            paths.append("certified")
+        ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_EXACT)
+    switch_steps = {}
+    results = {}
+    for name in (list(exchangers) or ["none"]):
+        results[name] = timed(name, paths)
+    best = min(results, key=lambda k: results[k][first_path][0])
+    path_results = {q: results[best][q][:4] for q in paths}
+    path_per_rank = {q: results[best][q][4] for q in paths}
+    for name in results:
+        per_rank[name] = results[name][first_path][4]
+    results = {name: results[name][first_path][:4] for name in results}   # (halo_paths_ms_per_step reads these)
+    path_parity, chosen = {}, first_path
+    if "certified" in paths and first_path == "exact":
+        ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
+        ref_rank = oracle_reference(dict(ocean=ocean_np[0], src=src_np, weights=w_np), params, nx, ny, h)
+        shares = {}
+        worst = measured_parity(ctx, ref_rank, dict(src=src, weights=w, ocean=states[0]), nx, ny, h, shares=shares)
+        # decided on EVERY field parity_measured reports — the six flux fields (the north star's statement) and the net
+        # fluxes assembled from them.  (J_S ∝ F_v − P can cancel to nothing: the certificate bounds the vapour flux against
+        # |F_v − P| as well, coflux_certified.hpp::CertNetSalt.  The face stresses average two cells' ρτ and can cancel too —
+        # nothing bounds that per cell; it is measured here, on every rank, and decides with the rest)
+        six = max(v for k, v in worst.items() if k.startswith("fluxes."))
+        flag = torch.tensor([max(worst.values()), six], dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        path_parity["certified"] = dict(max_over_ranks=float(flag[0].item()), max_six_flux_fields_over_ranks=float(flag[1].item()),
+                                        worst_scaled_error_rank0=worst, exact_path_cells_rank0=shares,
+                                        metric="|got - oracle exact path| / max(|oracle|, field scale), one cf_update_state per rank")
+        if float(flag[0].item()) <= 1e-6 and path_results["certified"][0] < path_results["exact"][0]:
+            chosen = "certified"
+    ctx.set_option(abi.OPT_SOLVER_PATH, PATH_CODE[chosen])
     elapsed, samples, sched, next_step = path_results[chosen]
     next_step = max(v[3] for v in path_results.values())
 
@@ -710,8 +737,11 @@ def main():
                                halo_rows=ring_rows if world > 1 else 0, pipelined_interpolation=pipeline,
                                pipeline_mode=mode,
                                step_loop="cf_time_steps (C)" if (a.config == "ocean" and best != "torch") else "host"),
-                   settle_steps=settle.get(best), untimed_steps=(settle.get(best) or 0) + warmup,
-                   repetitions=reps, ms_per_step_samples=[s / steps * 1e3 for s in samples],
+                   settle_steps=settle.get(best), untimed_steps=(settle.get(best) or 0) + warmup + (switch_steps.get(best) or 0),
+                   repetitions=reps,
+                   repetition_order=("interleaved: " + ", ".join(paths) + f" per repetition, {SWITCH_STEPS} untimed steps after each switch"
+                                     if len(paths) > 1 else None),
+                   solver_paths_ms_per_step_samples={k: [t / steps * 1e3 for t in v[1]] for k, v in path_results.items()}, ms_per_step_samples=[s / steps * 1e3 for s in samples],
                    ms_per_step_spread=[min(samples) / steps * 1e3, max(samples) / steps * 1e3],
                    ms_per_step_by_rank=([t / steps * 1e3 for t in path_per_rank[chosen]] if path_per_rank.get(chosen) else None),
                    solver_paths_ms_per_step={k: v[0] / steps * 1e3 for k, v in path_results.items()},
