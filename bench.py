@@ -583,7 +583,10 @@ def main():
     paths = [first_path]
     if a.solver_path == "auto" and a.config == "ocean":
         ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
-        if ctx.solver_iteration_path() == abi.SOLVER_PATH_CERTIFIED:
+        applies = torch.tensor([1 if ctx.solver_iteration_path() == abi.SOLVER_PATH_CERTIFIED else 0], device=coll_dev)
+        if world > 1:   # every rank runs the same sequence of timed regions (their barriers pair up): all or none
+            dist.all_reduce(applies, op=dist.ReduceOp.MIN)
+        if bool(applies.item()):
             paths.append("certified")
         ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_EXACT)
     switch_steps = {}
