@@ -237,7 +237,10 @@ def main():
     default_protocol = a.steps is None
     steps = a.steps if a.steps is not None else 1000
     warmup = a.warmup if a.warmup is not None else 50
-    reps = a.repetitions if a.repetitions is not None else (5 if default_protocol else 3)   # (3 × K steps cost milliseconds)
+    # --steps K: at least 3 repetitions of exactly K steps, more while they stay inside ≈ 30 ms per solver path (K = 20: 9
+    # regions of 1.7 ms) — a short region is exposed to whatever the host does for a few hundred microseconds (one evidence run
+    # read 0.085, 0.095, 0.096 ms per step in three consecutive 20-step regions whose kernels ran at their usual 76 µs)
+    reps = a.repetitions if a.repetitions is not None else (5 if default_protocol else (max(3, min(9, int(0.030 / (steps * 0.085e-3)))) | 1))   # (odd: the median is one of the samples)
 
     h = a.halo
     if a.scaling == "weak":
@@ -567,8 +570,8 @@ def main():
         out = {}
         for q in paths:
             med = statistics.median(samples[q])
-            out[q] = (med, samples[q], sched, first,
-                      by_rank[q][samples[q].index(med)] if by_rank[q] and med in samples[q] else None)
+            nearest = min(range(len(samples[q])), key=lambda n: abs(samples[q][n] - med))   # (even counts: the sample next to the median)
+            out[q] = (med, samples[q], sched, first, by_rank[q][nearest] if by_rank[q] else None)
         return out
 
     # ---- the two solver paths (CF_OPT_SOLVER_PATH) ---------------------------------------------------------------------
