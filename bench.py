@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1000, median of 5 repetitions)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 50)")
     ap.add_argument("--repetitions", type=int, default=None, help="timed repetitions of K steps; the median is reported")
+    ap.add_argument("--ao-chunk", type=int, default=0, help="CF_OPT_AO_CHUNK (0 = the library's plan): wet cells per solver workgroup, experiments")
     ap.add_argument("--nx", type=int, default=1440)
     ap.add_argument("--ny", type=int, default=560)
     ap.add_argument("--halo", type=int, default=7)  # README.md:58 halo=(7,7,7)
@@ -289,6 +290,8 @@ def main():
     ctx = FluxContext(nx, ny, h, h, params, ring=1, device=local_rank)
     if a.trip_hints != 2:
         ctx.set_option(abi.OPT_TRIP_HINTS, a.trip_hints)
+    if a.ao_chunk:
+        ctx.set_option(abi.OPT_AO_CHUNK, a.ao_chunk)
     ctx.set_option(abi.OPT_CERTIFIED_BUDGET, a.certified_budget)
     if a.solver_path == "certified":
         ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
