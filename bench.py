@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1000, median of 5 repetitions)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 50)")
     ap.add_argument("--repetitions", type=int, default=None, help="timed repetitions of K steps; the median is reported")
+    ap.add_argument("--latency-layout", choices=("auto", "never", "always"), default="auto",
+                    help="CF_OPT_LATENCY_LAYOUT: the exact path's kernels for one or two waves per SIMD (auto: chunk plans of at most two workgroups per CU)")
     ap.add_argument("--ao-chunk", type=int, default=0, help="CF_OPT_AO_CHUNK (0 = the library's plan): wet cells per solver workgroup, experiments")
     ap.add_argument("--nx", type=int, default=1440)
     ap.add_argument("--ny", type=int, default=560)
@@ -292,6 +294,8 @@ def main():
         ctx.set_option(abi.OPT_TRIP_HINTS, a.trip_hints)
     if a.ao_chunk:
         ctx.set_option(abi.OPT_AO_CHUNK, a.ao_chunk)
+    if a.latency_layout != "auto":
+        ctx.set_option(abi.OPT_LATENCY_LAYOUT, {"never": 0, "always": 2}[a.latency_layout])
     ctx.set_option(abi.OPT_CERTIFIED_BUDGET, a.certified_budget)
     if a.solver_path == "certified":
         ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)

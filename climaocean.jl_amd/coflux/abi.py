@@ -26,7 +26,7 @@ MASK_NONE, MASK_U8, MASK_BOTTOM_HEIGHT = 0, 1, 2
 ALBEDO_CONSTANT, ALBEDO_LATITUDE_DEPENDENT = 0, 1
 OPT_SOLVER, OPT_INTERP_TILE_CAP, OPT_MAX_BLOCKS, OPT_TRIP_HINTS, OPT_AO_CHUNK, OPT_PROFILE_STRIDE, OPT_FUSED_NET = 0, 1, 2, 3, 4, 5, 6
 OPT_ICE_ORBIT_SHORTCUT, OPT_FUSED_INTERP, OPT_MERGED_PREFETCH = 7, 8, 9
-OPT_SOLVER_PATH, OPT_CERTIFIED_BUDGET, OPT_ICE_FREE_CELLS = 10, 11, 12
+OPT_SOLVER_PATH, OPT_CERTIFIED_BUDGET, OPT_ICE_FREE_CELLS, OPT_LATENCY_LAYOUT = 10, 11, 12, 13
 ICE_FREE_ITERATE, ICE_FREE_ZERO = 0, 1
 PIPELINE_WITHIN_CALL, PIPELINE_CONTINUING = 1, 2   # cf_run_schedule.pipeline
 SOLVER_PATH_EXACT, SOLVER_PATH_CERTIFIED = 0, 1      # how the Monin–Obukhov fixed point is reached (include/coflux.h)
@@ -208,7 +208,7 @@ EXPORTED_SYMBOLS = (
     "cf_interpolate_land_freshwater", "cf_set_land_freshwater", "cf_materialize_salinity_restoring",
     "cf_window_create", "cf_window_destroy", "cf_window_host_buffer", "cf_window_wait_slot", "cf_window_commit",
     "cf_window_upload", "cf_window_find", "cf_window_source",
-    "cf_ensure_chunk_table", "cf_solver_path", "cf_solver_iteration_path", "cf_comm_count", "cf_build_stamp", "cf_discard_prefetched_atmosphere_state",
+    "cf_ensure_chunk_table", "cf_solver_path", "cf_solver_iteration_path", "cf_solver_latency_layout", "cf_comm_count", "cf_build_stamp", "cf_discard_prefetched_atmosphere_state",
 )
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -267,6 +267,7 @@ def load_library(path=None):
     lib.cf_set_stream.argtypes = [vp, vp]
     lib.cf_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.cf_solver_iteration_path.argtypes = [vp, C.POINTER(C.c_int)]
+    lib.cf_solver_latency_layout.argtypes = [vp, C.POINTER(C.c_int)]
     lib.cf_discard_prefetched_atmosphere_state.argtypes = [vp]
     lib.cf_comm_count.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.cf_debug_eval.argtypes = [vp, C.c_int, C.c_int, vp, vp]

@@ -310,6 +310,13 @@ class FluxContext:
         self._check(self.lib.cf_solver_iteration_path(self._h, C.byref(path)), "cf_solver_iteration_path")
         return path.value
 
+    def solver_latency_layout(self):
+        """True when the exact path's launch would take the kernels laid out for one or two waves per SIMD
+        (CF_OPT_LATENCY_LAYOUT; valid once the chunk table is built)."""
+        layout = C.c_int()
+        self._check(self.lib.cf_solver_latency_layout(self._h, C.byref(layout)), "cf_solver_latency_layout")
+        return bool(layout.value)
+
     def time_copy(self, nbytes, launches=20):
         a = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)
         b = torch.empty_like(a)

@@ -450,6 +450,7 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         ctx->launch.max_blocks = ((4 * prop.multiProcessorCount + 7) / 8) * 8;
         ctx->launch.cu_count = prop.multiProcessorCount;
+        ctx->launch.latency_layout = 1;  // CF_OPT_LATENCY_LAYOUT: automatic
     }
     ctx->stream = ctx->own_stream;
     *out = ctx;
@@ -564,6 +565,10 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
         case CF_OPT_SOLVER_PATH:
             if (value != CF_SOLVER_PATH_EXACT && value != CF_SOLVER_PATH_CERTIFIED) return fail(ctx, CF_ERR_INVALID, "solver path %d: 0 (exact) or 1 (certified)", value);
             ctx->launch.certified = value;
+            return CF_OK;
+        case CF_OPT_LATENCY_LAYOUT:
+            if (value < 0 || value > 2) return fail(ctx, CF_ERR_INVALID, "latency layout %d: 0 (never), 1 (automatic), 2 (always)", value);
+            ctx->launch.latency_layout = value;
             return CF_OK;
         case CF_OPT_CERTIFIED_BUDGET:
             if (value < 50 || value > 1000000) return fail(ctx, CF_ERR_INVALID, "certified budget %d: 50 … 1000000 (units of 1e-9)", value);
@@ -744,6 +749,14 @@ int cf_solver_iteration_path(cf_ctx* ctx, int* path) {
     LaunchCfg L = ctx->launch;
     if (narrow_pending) L.ao_wide = 0;
     *path = lean && !wide_pending && lean_certified_applies(L, ctx->fast, fused_interp) ? CF_SOLVER_PATH_CERTIFIED : CF_SOLVER_PATH_EXACT;
+    return CF_OK;
+}
+
+int cf_solver_latency_layout(cf_ctx* ctx, int* layout) {
+    if (!ctx || !layout) return fail(ctx, CF_ERR_INVALID, "cf_solver_latency_layout: bad arguments");
+    const bool lean = ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
+    const bool fused_interp = net_fluxes_fused(ctx) && ctx->fused_interp != 0 && !ctx->launch.ao_wide;
+    *layout = lean && ctx->chunk_valid && lean_line_applies(ctx->launch, ctx->fast, ctx->dev.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC, fused_interp) ? 1 : 0;
     return CF_OK;
 }
 

@@ -41,7 +41,11 @@ struct LaunchCfg {
     const int* d_lean_info;     // per chunk: wet cells listed, fingerprint of the wet set (x, y), 0
     int lean_hints;             // 1: the lean ocean kernel re-orders its lists by trip count at the end of every call
     int certified;              // CF_OPT_SOLVER_PATH: 1 = the certified reduced-iteration solve wherever it applies (lean_certified_applies)
+    int latency_layout;         // CF_OPT_LATENCY_LAYOUT: 0 never, 1 automatic (COARE profile on chunk plans of at most two workgroups per CU), 2 always
 };
+
+// the exact path's kernels for one or two waves per SIMD (coflux_solver_slab.hip) carry this launch
+bool lean_line_applies(const LaunchCfg& L, const LoopParams& C, bool coare, bool fused_interp = false);
 
 // CF_SOLVER_PATH_CERTIFIED runs in the lean ocean kernel's narrow geometry under the convergence stop rule, with index-ordered
 // lists and without the interpolation fused into the prologue; everywhere else the exact path runs.

@@ -278,6 +278,92 @@ __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const Lea
     return Scales{us, moved ? chi * c.dtheta : 1e-4, moved ? chi * c.dq : 1e-4, it, it};
 }
 
+// The same iteration laid out for ONE WAVE PER SIMD (a latitude slab of a strongly scaled run): there a wave
+// issues a dependent VALU instruction every ≈ 9 cycles and an independent one every ≈ 4 (scratch/ubench_lat.hip), so what
+// counts is how much of a trip is one basic block that tools/gcn_sched.py can re-order for latency after register
+// allocation (values local to the block renamed into the registers a 256-VGPR kernel has to spare).  Same arithmetic as
+// mo_iterate_lean, expression for expression — results are bitwise the same (tests/test_slab_line.py) —; what differs is
+// control flow only: the first trip (general expressions from θ★ = q★ = 1e-4) is peeled off, and the gustiness term is
+// unconditional.  Precondition beyond mo_iterate_lean's: β_gust ≠ 0 (every SimilarityTheoryFluxes preset of the reference).
+template <bool COARE, bool FIRST>
+__device__ __forceinline__ void mo_lean_line_step(const LoopParams& L, const LeanCell& c, const double* tab, const double* logt, double B,
+                                                  double S, double log_A_q, double& us, double& ius, double& chi, double& kb,
+                                                  double& drift) {
+    const double inv_L = kb * (ius * ius);
+    const double lu = vmin_u(__builtin_fma(c.alpha_g * us, us, c.lam_nu * ius), L.lm_m);
+    const LogHalf half_u = flog_pos_begin(logt, lu);
+    const LogHalf half_q = flog_pos_begin(logt, lu * us * c.inv_nu_q);
+    const PsiArg ah = psi_arg_x(__builtin_fma(L.x_scale, fabs(inv_L), 1.0), kb < 0.0);
+    double U, rU;
+    {
+        const double w = fmax(-(us * kb) * L.gust_c, 1e-18);
+        sqrt_rsqrt_lean(c.dU2 + vmax_u(pow23_lean(w), L.min_gust2), U, rU);
+    }
+    const double2 ps = psi_eval_pair(tab, ah);
+    const double log_lu = flog_lean_end(half_u);
+    const double log_lq = vmin_u(__builtin_fma(-L.b_q, flog_lean_end(half_q), log_A_q), L.log_lm_q);
+    double Du = (L.log_h - log_lu) - ps.x;
+    double Dq = (L.log_h - log_lq) - ps.y;
+    if constexpr (!COARE) {
+        const double zu = lu * inv_L, zq = fexp_lean(tab, log_lq) * inv_L;
+        double2 pl;
+        if (fabs(zu) < SMALL_Z0 && fabs(zq) < SMALL_Z0) {
+            asm volatile("" ::: "memory");
+            pl = psi_small_mh(tab, inv_L < 0.0, zu, zq);
+        } else {
+            asm volatile("" ::: "memory");
+            pl = psi_eval_two(tab, psi_arg(zu), psi_arg(zq));
+        }
+        Du += pl.x;
+        Dq += pl.y;
+    }
+    Du = vmax_u(Du, L.profile_floor);
+    Dq = vmax_u(Dq, L.profile_floor);
+    const double r = frcp1(Du * Dq);
+    const double kU = L.kappa * U, rDq = r * Dq, rDu = r * Du;
+    ius = (Du * rU) * L.two_inv_kappa;
+    const double d_u = __builtin_fma(kU, rDq, -us);
+    double kU_after = kU;
+    asm("" : "+v"(kU_after) : "v"(d_u));
+    us = kU_after * rDq;
+    if constexpr (FIRST) {
+        chi = L.kappa * rDu;
+        drift = fabs(d_u) + fabs(chi * c.dtheta - 1e-4) + fabs(chi * c.dq - 1e-4);
+    } else {
+        const double d_c = __builtin_fma(L.kappa, rDu, -chi);
+        chi = L.kappa * rDu;
+        drift = __builtin_fma(fabs(d_c), S, fabs(d_u));
+    }
+    kb = chi * B;
+}
+
+template <bool COARE>
+__device__ __forceinline__ Scales mo_iterate_lean_line(const LoopParams& L, const LeanCell& c, const double* tab, bool active) {
+    const double* logt = tab + LOG_OFFSET;
+    const double B = __builtin_fma(c.dtheta, c.bth, c.bqq * c.dq), S = fabs(c.dtheta) + fabs(c.dq);
+    double us = 1e-4, ius = 1e4, chi = 0.0, kb = __builtin_fma(1e-4, c.bth, c.bqq * 1e-4);
+    double drift = __builtin_inf();
+    int it = 0;
+    double log_A_q = L.log_A_q;
+    asm("" : "+v"(log_A_q));
+    if (L.maxiter > 0 && __builtin_amdgcn_ballot_w64(active) != 0ull) {
+        if (active) {
+            mo_lean_line_step<COARE, true>(L, c, tab, logt, B, S, log_A_q, us, ius, chi, kb, drift);
+            it = 1;
+        }
+        for (int trip = 1;; ++trip) {
+            const bool go = active && !(drift < L.tol);
+            if (trip >= L.maxiter || __builtin_amdgcn_ballot_w64(go) == 0ull) break;
+            if (go) {
+                mo_lean_line_step<COARE, false>(L, c, tab, logt, B, S, log_A_q, us, ius, chi, kb, drift);
+                ++it;
+            }
+        }
+    }
+    const bool moved = it > 0;
+    return Scales{us, moved ? chi * c.dtheta : 1e-4, moved ? chi * c.dq : 1e-4, it, it};
+}
+
 // ---------------------------------------------------------------------------------------------
 // Atmosphere–sea-ice interface on the lean primitives (SOLVER_SEAICE with constant roughness lengths and U_G,min > 0:
 // corrected_/ncar_atmosphere_sea_ice_fluxes, omip_simulation.jl:62-69,105-113).  The same iteration as ice_iterate

@@ -51,6 +51,9 @@ struct LeanArgs {
 };
 typedef const LeanArgs __attribute__((address_space(4)))* LeanArgsPtr;
 
+// coflux_solver_slab.hip: the exact path's kernels in the one-wave-per-SIMD layout (COARE × plain / fused net fluxes / + tail workgroups)
+hipError_t launch_ao_lean_line(hipStream_t st, bool coare, bool fuse, bool tail, int blocks, const LeanArgs& A);
+
 __device__ __forceinline__ LeanArgsPtr opaque(LeanArgsPtr p) {
     asm volatile("" : "+s"(p));
     return p;
@@ -128,7 +131,9 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 #ifndef CF_CERT_NET_SALT
 #define CF_CERT_NET_SALT 1  // (0: A/B builds without the certificate's net-salinity term)
 #endif
-template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false, bool CERT = false>
+// LINE: the iteration in its one-wave-per-SIMD layout (mo_iterate_lean_line; coflux_solver_slab.hip builds those kernels
+// through tools/gcn_sched.py); bitwise the same results.
+template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false, bool CERT = false, bool LINE = false>
 __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
     using Geo = LeanGeom<BLOCK>;
     constexpr int CHUNK = Geo::CHUNK;
@@ -524,7 +529,8 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                     }
                 }
             } else {
-                s = mo_iterate_lean<COARE>(L, c, tab, in_range);
+                if constexpr (LINE) s = mo_iterate_lean_line<COARE>(L, c, tab, in_range);
+                else s = mo_iterate_lean<COARE>(L, c, tab, in_range);
             }
 #ifdef CF_LEAN_STAMPS
             stamp_iter += __builtin_readcyclecounter() - t_it;

@@ -112,6 +112,18 @@ bool lean_certified_applies(const LaunchCfg& L, const LoopParams& C, bool fused_
            C.cert_max_evals > 2 && C.tol >= 1e-9 && C.maxiter >= 40;
 }
 
+bool lean_line_applies(const LaunchCfg& L, const LoopParams& C, bool coare, bool fused_interp) {
+    // (two workgroups of 256 VGPRs per lane fill a CU: a plan with more would run in rounds; β_gust ≠ 0 is the layout's
+    // precondition — mo_iterate_lean_line —; the certified path has its own kernels)
+    if (L.latency_layout == 0 || C.specialization != SOLVER_OCEAN_LEAN || L.ao_wide || fused_interp || C.beta_gust == 0.0) return false;
+    if (lean_certified_applies(L, C, fused_interp)) return false;
+    // automatic: where it is measured to pay — the COARE profile, whose trip is ONE basic block (1440×70: 24.3 → 22.0 µs per
+    // step); with the plain logarithmic profile the slowest waves are the ones that take the general ψ at the roughness
+    // lengths behind a per-lane branch, and a lone wave issues that block no faster re-ordered (27.3 µs either way,
+    // profiles/r05_experiments.md §9)
+    return L.latency_layout == 2 || (coare && L.cu_count > 0 && L.n_chunks <= 2 * L.cu_count);
+}
+
 // the argument block of one ocean solve (everything but the tail workgroups' and the fused interpolation's descriptors)
 static hipError_t fill_lean_args(const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G, const cf_ocean_surface* o,
                                  const cf_exchange_fields* e, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
@@ -184,6 +196,7 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
         A.tail_rows = tail_rows;
         A.tail_cap = L.interp_cap;
         A.tail_pos = tail_pos < 0 || tail_pos > L.n_chunks ? L.n_chunks : tail_pos;
+        if (lean_line_applies(L, C, coare)) return launch_ao_lean_line(st, coare, true, true, L.n_chunks + tail_blocks, A);
         if (cert) {
             if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK, true, false, true, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
             else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK, true, false, true, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
@@ -209,6 +222,8 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
         } else {
             if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK_WIDE, false); else CF_LEAN_LAUNCH(false, AO_BLOCK_WIDE, false);
         }
+    } else if (lean_line_applies(L, C, coare)) {
+        return launch_ao_lean_line(st, coare, net != nullptr, false, L.n_chunks, A);
     } else if (cert) {
 #define CF_CERT_LAUNCH(COARE_, FUSE_) \
     hipLaunchKernelGGL((ao_lean_kernel<COARE_, AO_BLOCK, FUSE_, false, false, true>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A)

@@ -206,6 +206,21 @@ def parse_inst(line):
 LABEL = re.compile(r"^[.\w$]+:")
 
 
+def matching_functions(lines, sub):
+    return [re.match(r"^(_Z\w+):", l).group(1) for l in lines if re.match(r"^_Z\w+:", l) and sub in l]
+
+
+def next_free_vgpr(lines, fn):
+    inside = False
+    for l in lines:
+        s_ = l.strip()
+        if s_.startswith(".amdhsa_kernel "):
+            inside = s_.split()[1] == fn
+        elif inside and s_.startswith(".amdhsa_next_free_vgpr"):
+            return int(s_.split()[1])
+    raise SystemExit(f"no kernel descriptor for {fn}")
+
+
 def find_function(lines, sub):
     start = end = None
     for i, l in enumerate(lines):
@@ -280,6 +295,168 @@ def build_dag(insts):
         for r in ins.uses:
             last_uses[r].append(i)
     return preds
+
+
+# ---------------------------------------------------------------------------------------------
+# register renaming inside a piece (round 5): after register allocation the temporaries share so few registers that
+# write-after-read / write-after-write dependences pin the compiler's order (round 4: 987 -> 846 modelled ticks with
+# the allocated registers, 595 with unlimited renaming).  A kernel variant that is only launched with one wave per
+# SIMD may use up to 512 VGPRs, so every VALUE that is born and dies inside a piece gets registers of its own from a
+# pool above the function's own.  Same instructions, same operand values, same results bit for bit.
+# ---------------------------------------------------------------------------------------------
+VREG_TOKEN = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def vregs_in(tok):
+    out = []
+    for m in VREG_TOKEN.finditer(tok):
+        if m.group(3) is not None:
+            out.append(int(m.group(3)))
+        else:
+            out.extend(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def operand_layout(ins):
+    """(op, operands, index set of DEF operands) for an instruction the renamer understands, else None"""
+    code = ins.text.split(";")[0].rstrip()
+    m = re.match(r"(\s*)(\S+)\s*(.*)", code)
+    op, rest = m.group(2), m.group(3)
+    ops = split_operands(rest)
+    if op.startswith("ds_read"):
+        return op, ops, {0}
+    if op.startswith("v_cmp"):
+        return op, ops, set()          # operand 0 is an SGPR pair / vcc
+    if op.startswith("v_"):
+        return op, ops, {0}
+    if op.startswith("s_"):
+        return op, ops, set()          # (no VGPR operands)
+    return None
+
+
+def rename_piece(insts, pool_lo, pool_hi):
+    """rewrites ins.text / ins.defs / ins.uses in place; returns the number of webs renamed"""
+    parent = []
+    web_regs = []      # value id -> set of original registers its def covers
+    pinned = set()
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    def union(a, b):
+        a, b = find(a), find(b)
+        if a != b:
+            parent[b] = a
+
+    reach = {}         # original VGPR number -> value id now in it (absent: live-in)
+    plan = []          # per instruction: None or (op, ops, [per operand: list of (reg, value id or None)])
+    for ins in insts:
+        if ins.comment_only or ins.op in ("s_waitcnt", "s_nop", ""):
+            plan.append(None)
+            continue
+        lay = operand_layout(ins)
+        if lay is None:
+            return 0
+        op, ops, def_idx = lay
+        per = [None] * len(ops)
+        tied = bool(FMAC.match(op))
+        # uses first (they see the values BEFORE this instruction's definitions)
+        for k, tok in enumerate(ops):
+            if k in def_idx and not tied:
+                continue
+            regs = vregs_in(tok)
+            ids = [reach.get(r) for r in regs]
+            per[k] = list(zip(regs, ids))
+            live = [v for v in ids if v is not None]
+            for v in live[1:]:
+                union(live[0], v)
+            if live and len(live) != len(ids):
+                pinned.add(live[0])    # a tuple that mixes live-in registers with local values
+        for k in def_idx:
+            regs = vregs_in(ops[k])
+            v = len(parent)
+            parent.append(v)
+            web_regs.append(set(regs))
+            if tied:
+                for r, old in per[k]:
+                    if old is None:
+                        pinned.add(v)
+                    else:
+                        union(old, v)
+            per[k] = [(r, v) for r in regs]
+            for r in regs:
+                reach[r] = v
+        plan.append((op, ops, per))
+    for r, v in reach.items():
+        pinned.add(v)                  # whatever a register holds at the end of the piece may be read later
+    webs = defaultdict(set)
+    bad = set()
+    for v in range(len(parent)):
+        webs[find(v)] |= web_regs[v]
+    for v in pinned:
+        bad.add(find(v))
+    # allocation: every renamed web gets a fresh contiguous range with the parity of its original one
+    nxt = pool_lo
+    mapping = {}                       # web root -> (orig lo, new lo)
+    for root in sorted(webs):
+        if root in bad:
+            continue
+        regs = sorted(webs[root])
+        if not regs:
+            continue
+        lo, hi = regs[0], regs[-1]
+        if hi - lo + 1 != len(regs):
+            continue
+        base = nxt
+        if len(regs) > 1 or True:
+            if (base ^ lo) & 1:
+                base += 1
+        if base + len(regs) - 1 > pool_hi:
+            continue
+        mapping[root] = (lo, base)
+        nxt = base + len(regs)
+    if not mapping:
+        return 0
+
+    def new_reg(r, v):
+        if v is None:
+            return r
+        root = find(v)
+        if root not in mapping:
+            return r
+        lo, base = mapping[root]
+        return base + (r - lo)
+
+    for ins, pl in zip(insts, plan):
+        if pl is None:
+            continue
+        op, ops, per = pl
+        new_ops = []
+        for tok, regs in zip(ops, per):
+            if not regs:
+                new_ops.append(tok)
+                continue
+            it = iter(regs)
+
+            def sub(m):
+                if m.group(3) is not None:
+                    r, v = next(it)
+                    return f"v{new_reg(r, v)}"
+                a, b = int(m.group(1)), int(m.group(2))
+                got = [new_reg(*next(it)) for _ in range(a, b + 1)]
+                assert got == list(range(got[0], got[0] + len(got))), (ins.text, got)
+                return f"v[{got[0]}:{got[-1]}]"
+            new_ops.append(VREG_TOKEN.sub(sub, tok))
+        comment = ins.text.split(";", 1)[1] if ";" in ins.text else None
+        text = "\t" + op + " " + ", ".join(new_ops)
+        ins.text = text
+        ins.raw_lines = [text]
+        re_parsed = parse_inst(text)
+        ins.defs, ins.uses = re_parsed.defs, re_parsed.uses
+    return len(mapping)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -406,7 +583,7 @@ def emit(order, insts, preds, entry_waitcnt):
             if insts[p].is_lds and p in lds_issued:
                 need = max(need, lds_issued.index(p))
         if need >= waited_upto:
-            outstanding_allowed = len(lds_issued) - 1 - need
+            outstanding_allowed = min(15, len(lds_issued) - 1 - need)   # (the counter has four bits)
             out.append(f"\ts_waitcnt lgkmcnt({outstanding_allowed})")
             emitted.append(None)
             waited_upto = need + 1
@@ -436,7 +613,10 @@ def emit(order, insts, preds, entry_waitcnt):
     return out
 
 
-def process(lines, fn_sub, must_contain, report, min_len=12):
+NO_REORDER = False
+
+
+def process(lines, fn_sub, must_contain, report, min_len=12, pool=None):
     lo, hi = find_function(lines, fn_sub)
     pieces = straight_pieces(lines, lo, hi)
     new_lines = list(lines)
@@ -460,17 +640,50 @@ def process(lines, fn_sub, must_contain, report, min_len=12):
         preds = build_dag(insts)
         base_order = list(range(len(insts)))
         before = simulate(base_order, insts, preds)
-        order = list_schedule(insts, preds)
+        renamed = 0
+        if pool:
+            renamed = rename_piece(insts, pool[0], pool[1])
+            if renamed:
+                preds = build_dag(insts)
+        order = base_order if NO_REORDER else list_schedule(insts, preds)
         after = simulate(order, insts, preds)
-        if after >= before:
+        if after >= before and not (renamed and NO_REORDER):
             continue
         text = emit(order, insts, preds, entry)
-        edits.append((a, b, text, before, after, len(real)))
-    for a, b, text, before, after, nreal in sorted(edits, reverse=True):
+        edits.append((a, b, text, before, after, len(real), renamed))
+    for a, b, text, before, after, nreal, renamed in sorted(edits, reverse=True):
         new_lines[a:b] = text
         if report:
-            print(f"  lines {a}-{b}: {nreal} instructions, modelled lone-wave cycles {before} -> {after}", file=sys.stderr)
+            print(f"  lines {a}-{b}: {nreal} instructions, modelled lone-wave cycles {before} -> {after} ({renamed} values renamed)", file=sys.stderr)
     return new_lines, edits
+
+
+def set_vgpr_count(lines, fn_sub, n):
+    """the .amdhsa_kernel block and the metadata entry of every kernel whose name contains fn_sub"""
+    out = list(lines)
+    in_desc = False
+    in_meta = False
+    for i, l in enumerate(out):
+        s_ = l.strip()
+        if s_.startswith(".amdhsa_kernel "):
+            in_desc = fn_sub in s_
+        elif s_.startswith(".end_amdhsa_kernel"):
+            in_desc = False
+        elif in_desc and s_.startswith(".amdhsa_next_free_vgpr"):
+            out[i] = f"\t\t.amdhsa_next_free_vgpr {n}"
+        elif in_desc and s_.startswith(".amdhsa_accum_offset"):
+            out[i] = f"\t\t.amdhsa_accum_offset {n}"
+        if s_.startswith(".name:") or s_.startswith("- .agpr_count:"):
+            pass
+        if s_.startswith(".name:"):
+            in_meta = fn_sub in s_
+        if s_.startswith(".symbol:"):
+            in_meta_sym = fn_sub in s_
+        if s_.startswith(".vgpr_count:"):
+            # metadata entries list .name before .vgpr_count (alphabetical keys: .name < .vgpr_count)
+            if in_meta:
+                out[i] = re.sub(r"\d+", str(n), l)
+    return out
 
 
 if __name__ == "__main__":
@@ -480,10 +693,35 @@ if __name__ == "__main__":
     ap.add_argument("--function", action="append", required=True)
     ap.add_argument("--blocks-with", default="")
     ap.add_argument("--report", action="store_true")
+    ap.add_argument("--rename", default="", help="LO:HI — VGPRs the function does not use, for values local to a piece (LO = auto: the kernel's own next_free_vgpr)")
+    ap.add_argument("--no-reorder", action="store_true", help="rename only: the compiler's order (A/B)")
+    ap.add_argument("--latency-scale", type=float, default=1.0, help="multiplies the model's VALU result latencies (A/B)")
+    ap.add_argument("--all-matching", action="store_true", help="every function whose name contains a --function string")
+    ap.add_argument("--vgprs", type=int, default=0, help="rewrite the kernel descriptors' VGPR counts (next_free_vgpr, accum_offset, .vgpr_count)")
     a = ap.parse_args()
+    if a.latency_scale != 1.0:
+        for k, (iss, lat) in list(MODEL.items()):
+            if k not in ("lds", "nop", "salu"):
+                MODEL[k] = (iss, int(round(lat * a.latency_scale)))
+    globals()["NO_REORDER"] = a.no_reorder
     lines = open(a.src).read().split("\n")
-    for fn in a.function:
+    fns = a.function
+    if a.all_matching:
+        fns = [f for sub in a.function for f in matching_functions(lines, sub)]
+        if not fns:
+            raise SystemExit(f"no function matches {a.function}")
+    for fn in fns:
         if a.report:
             print(fn, file=sys.stderr)
-        lines, _ = process(lines, fn, a.blocks_with, a.report)
+        pool = None
+        if a.rename:
+            lo, hi = a.rename.split(":")
+            lo = next_free_vgpr(lines, fn) if lo == "auto" else int(lo)
+            lo += lo & 1
+            pool = (lo, int(hi))
+            if a.report:
+                print(f"  rename pool v{lo}..v{hi}", file=sys.stderr)
+        lines, _ = process(lines, fn, a.blocks_with, a.report, pool=pool)
+        if a.vgprs:
+            lines = set_vgpr_count(lines, fn, a.vgprs)
     open(a.dst, "w").write("\n".join(lines))

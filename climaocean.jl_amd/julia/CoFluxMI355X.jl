@@ -135,6 +135,7 @@ sync(b) = check(b.ctx, ccall((:cf_sync, libcoflux), Cint, (Ptr{Cvoid},), b.ctx))
 # every cell within `budget` — default 8e-7, in the flux metric of coflux.h — of the exact path's result).
 const CF_OPT_SOLVER_PATH = Cint(10)
 const CF_OPT_CERTIFIED_BUDGET = Cint(11)
+const CF_OPT_LATENCY_LAYOUT = Cint(13)   # 0 never, 1 automatic (default), 2 always: the exact path's kernels for one or two waves per SIMD
 set_option!(b, option, value) = check(b.ctx, ccall((:cf_set_option, libcoflux), Cint, (Ptr{Cvoid}, Cint, Cint), b.ctx, option, value))
 function set_solver_path!(b, path::Symbol; budget = 8e-7)
     path in (:exact, :certified) || throw(ArgumentError("solver path must be :exact or :certified"))
@@ -144,6 +145,8 @@ function set_solver_path!(b, path::Symbol; budget = 8e-7)
 end
 solver_iteration_path(b) = (p = Ref{Cint}(0); check(b.ctx, ccall((:cf_solver_iteration_path, libcoflux), Cint, (Ptr{Cvoid}, Ref{Cint}), b.ctx, p));
                             p[] == 1 ? :certified : :exact)
+
+solver_latency_layout(b) = (p = Ref{Cint}(0); check(b.ctx, ccall((:cf_solver_latency_layout, libcoflux), Cint, (Ptr{Cvoid}, Ref{Cint}), b.ctx, p)); p[] == 1)
 
 # ---- the three functions of update_state! ------------------------------------------------------
 # Each body is ONE ccall; these are the methods a maintainer adds for

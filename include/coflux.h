@@ -427,6 +427,16 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * fluxes and the net sea-ice fluxes of ice-free cells differ (they weight nothing: ℵ = 0).  Which of
                                    * the two upstream does is one of the forks julia/oracle_dump.jl records. */
 #define CF_ICE_FREE_ITERATE 0
+#define CF_OPT_LATENCY_LAYOUT 13   /* which kernels carry the EXACT path of the SimilarityTheoryFluxes ocean solve when a launch leaves every
+                                   * SIMD with one or two waves (a latitude slab of a strongly scaled run, a small surface):
+                                   * 1 (default, automatic): with the COARE similarity profile (`:corrected`), chunk plans of at most two
+                                   * workgroups per CU take the kernels of coflux_solver_slab.hip — the same iteration laid out in big
+                                   * basic blocks and re-scheduled for latency after register allocation (csrc/tools/gcn_sched.py):
+                                   * 1440×70 steps in 22.0 instead of 24.3 µs; 0: never; 2: always (measurements: with three waves
+                                   * per SIMD the layout buys nothing and costs occupancy, and with the plain logarithmic profile the
+                                   * slowest waves sit in the per-lane branch to the general ψ at the roughness lengths, which a lone
+                                   * wave issues no faster re-ordered).  Results are the same bits in every mode (tests/test_slab_line.py).  Needs gustiness_parameter != 0 (every
+                                   * SimilarityTheoryFluxes preset of the reference); other parameter sets keep the production kernels. */
 #define CF_ICE_FREE_ZERO 1
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path on LDS-tabulated ψ / log / exp.  Accuracy of the tabulated primitives
                                against libm (tests/test_gpu_parity.py::test_device_primitives_accuracy): ψ_m, ψ_h ≤ 5e-12 of
@@ -445,6 +455,10 @@ int cf_set_option(cf_ctx* ctx, int option, int value);
 /* *path = CF_SOLVER_PATH_* that cf_compute_atmosphere_ocean_fluxes / cf_update_state would run with the current
  * options, flux parameters and chunk geometry (the certified path falls back to the exact one where it does not apply). */
 int cf_solver_iteration_path(cf_ctx* ctx, int* path);
+/* *layout = 1 when the ocean solve's EXACT path would be carried by the kernels laid out for one or two waves per SIMD
+ * (CF_OPT_LATENCY_LAYOUT; coflux_solver_slab.hip) with the current options, flux parameters and the chunk table as built
+ * (cf_ensure_chunk_table first: the automatic mode looks at its workgroup count), else 0.  A measurement aid.         */
+int cf_solver_latency_layout(cf_ctx* ctx, int* layout);
 /* Self-test hook: y[k] = f(x[k]) with the device primitives the solver uses
  * (f: 0 log, 1 exp, 2 cbrt, 3 sqrt, 4 1/x, 5 ψ_m(ζ), 6 ψ_h(ζ)); d_x, d_y device pointers.        */
 int cf_debug_eval(cf_ctx* ctx, int function, int n, const double* d_x, double* d_y);

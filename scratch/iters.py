@@ -24,6 +24,7 @@ for name, mk in (("default", lambda: ic.SimilarityTheoryFluxes()), ("corrected",
         else:
             ctx.set_flux_params(P)
         if os.environ.get("SOLVER"): ctx.set_option(abi.OPT_SOLVER, int(os.environ["SOLVER"]))
+        if os.environ.get("LAYOUT"): ctx.set_option(abi.OPT_LATENCY_LAYOUT, int(os.environ["LAYOUT"]))
         if os.environ.get("HINTS"): ctx.set_option(abi.OPT_TRIP_HINTS, int(os.environ["HINTS"]))
         res[n] = round(min(ctx.time_stage(abi.STAGE_AO_FLUXES, 20, ocean=ocean, atmos=atmos, fluxes=fluxes) for _ in range(3)) * 1e3, 1)
     print(name, json.dumps(res))

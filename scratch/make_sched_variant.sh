@@ -11,8 +11,8 @@ LL=/opt/rocm/lib/llvm/bin
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value"
 T=/tmp/_sched_$TAG; mkdir -p $T
 hipcc $FL -S --cuda-device-only -o $T/lean.s coflux_solver_lean.hip
-FN=$(grep -o "^_ZN6coflux14ao_lean_kernelILb[01]ELi256ELb[01]ELb0EEEvNS_8LeanArgsE" $T/lean.s | sort -u | sed 's/^/--function /')
-python3 $ROOT/scratch/gcn_sched.py $T/lean.s $T/lean_sched.s $FN --report "$@" 2> $T/report.txt
+FN=$(grep -o "^_ZN6coflux14ao_lean_kernelILb[01]ELi256E[A-Za-z0-9]*EEvNS_8LeanArgsE" $T/lean.s | sort -u | sed 's/^/--function /')
+python3 $ROOT/climaocean.jl_amd/csrc/tools/gcn_sched.py $T/lean.s $T/lean_sched.s $FN --report "$@" 2> $T/report.txt
 $LL/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $T/lean_sched.s -o $T/lean_dev.o
 $LL/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $T/lean.hsaco $T/lean_dev.o
 $LL/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$T/lean.hsaco -output=$T/lean.hipfb
