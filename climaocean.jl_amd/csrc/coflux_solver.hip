@@ -199,7 +199,28 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
     } else if (need <= 3 * cap(256)) {
         // small surface (a slab of a strongly scaled run): every chunk resident at once, one batch per wave — the
         // kernel is as long as its slowest batch, so nothing may queue behind anything
-        add_round(256, chunks(need, 256), true);
+        //
+        // More chunks than CUs, at most twice as many (a 1440×70 latitude slab: 292 on 256): the workgroups of the second
+        // dispatch layer share a CU — and its one LDS pipe, which eight waves' scattered table reads saturate (a trip's ≈ 20
+        // reads of 1 KB per wave) — with an older workgroup that is served first: their waves ran 0.82 instead of 0.59 µs per
+        // trip and ended the kernel 6 µs after the first layer (per-wave stamps, profiles/r05_experiments.md §10; issue
+        // priority does not change it).  So the second layer is cut into the SMALLEST pieces that still give every CU at
+        // most one of them — 64 wet cells = one working wave where the excess allows: a CU then carries five working
+        // waves instead of eight.  (COFLUX_SLAB_SPLIT=0 with COFLUX_EXPERIMENTS=1: the uniform plan, for A/B runs.)
+        const long n256 = chunks(need, 256);
+        int w2 = 256;
+        if (n256 > layer && n256 <= 2L * layer) {
+            static const bool split = [] { const char* e = experiment_knob("COFLUX_SLAB_SPLIT"); return !(e && e[0] == '0'); }();
+            const long excess = need - cap(256);
+            if (split)
+                for (w2 = 64; w2 < 256 && chunks(excess, w2) > layer; w2 += 64) {}
+        }
+        if (w2 < 256) {
+            add_round(256, layer, false);
+            add_round(w2, chunks(need - cap(256), w2), true);
+        } else {
+            add_round(256, n256, true);
+        }
     } else if (need <= cap(512)) {
         // (never reached behind the branch above; uniform 512-cell chunks on half a surface were measured: 1440×280 steps
         // in 71.6 µs with them, 65.5 µs with the layered plan below)
@@ -269,7 +290,8 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
     return hipGetLastError();
 }
 
-int chunk_table_capacity(int ncells) { return (int)(((long)ncells * AO_WET_COST) / (256L * AO_WET_COST)) + 16; }
+// (+ 320: a small surface's second dispatch layer may be cut into up to one 64-cell chunk per CU, plan_chunk_rounds)
+int chunk_table_capacity(int ncells) { return (int)(((long)ncells * AO_WET_COST) / (256L * AO_WET_COST)) + 16 + 320; }
 int chunk_sums_capacity(int ncells) { return (ncells + CT_CELLS - 1) / CT_CELLS + 1; }
 
 // ---------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "climaocean.jl_amd"))
 import numpy as np, torch
 from coflux import abi, synthetic as syn, interface_computations as ic
 from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, FluxContext
-nx, ny, h = 1440, 560, 7
+nx, ny, h = 1440, int(os.environ.get('NY', 560)), 7
 ocean_np = syn.ocean_state(nx, ny, h, h); src_np = syn.jra55_snapshots(2)
 fi, fj, phi = syn.latlon_fractional_indices(nx, ny, h, h)
 cfgs = sys.argv[1:] or ["default", "fixed0", "fixed12"]
@@ -57,6 +57,8 @@ for label in cfgs:
     row("end phase (retire / sort)", D(5, 4))
     row("wave lifetime", D(5, 0))
     for lo, hi in ((0, 256), (256, 512), (512, NWG)):
+        if lo >= NWG: continue
+        hi = min(hi, NWG)
         sel = np.repeat((np.arange(NWG) >= lo) & (np.arange(NWG) < hi), WPG)
         wg_life = (raw[sel, 5].reshape(-1, WPG).max(axis=1) - raw[sel, 0].reshape(-1, WPG).min(axis=1)) / tick
         nb = np.maximum(raw[sel, 7], 1)
@@ -65,6 +67,8 @@ for label in cfgs:
     wg_life_all = (raw[:, 5].reshape(-1, WPG).max(axis=1) - raw[:, 0].reshape(-1, WPG).min(axis=1)) / tick
     wg_trips = trips.reshape(-1, WPG).sum(axis=1)
     for lo, hi in ((0, 256), (256, 512), (512, NWG)):
+        if lo >= NWG: continue
+        hi = min(hi, NWG)
         L_, T_ = wg_life_all[lo:hi], wg_trips[lo:hi]
         print(f"   blockIdx {lo:3d}-{hi:3d}: lifetime p50 {np.percentile(L_,50):.1f} p90 {np.percentile(L_,90):.1f} p99 {np.percentile(L_,99):.1f} max {L_.max():.1f};"
               f" batch-trips per workgroup p10 {np.percentile(T_,10):.0f} p50 {np.percentile(T_,50):.0f} p90 {np.percentile(T_,90):.0f} max {T_.max():.0f};"
@@ -76,4 +80,12 @@ for label in cfgs:
         cu_end = np.maximum.reduce([wg_life_all[0:n], wg_life_all[256:256 + n], wg_life_all[512:512 + n]])
         print(f"   per CU slot (b, b+256, b+512): total batch-trips p10 {np.percentile(cu_tr,10):.0f} p50 {np.percentile(cu_tr,50):.0f} p90 {np.percentile(cu_tr,90):.0f} max {cu_tr.max():.0f};"
               f" latest end p50 {np.percentile(cu_end,50):.1f} p90 {np.percentile(cu_end,90):.1f} max {cu_end.max():.1f}; corr {np.corrcoef(cu_tr, cu_end)[0,1]:.2f}")
+    if os.environ.get("PERTRIP"):
+        wtr = trips; it_us = raw[:, 6] / tick
+        for lo, hi in ((0, 256), (256, NWG)):
+            sel = np.repeat((np.arange(NWG) >= lo) & (np.arange(NWG) < hi), WPG) & (wtr > 0)
+            if sel.any():
+                pt = it_us[sel] / wtr[sel]
+                print(f"   blockIdx {lo}-{hi}: waves {int(sel.sum())}; us per trip inside the iteration: p10 {np.percentile(pt,10):.3f} p50 {np.percentile(pt,50):.3f} p90 {np.percentile(pt,90):.3f} max {pt.max():.3f}; "
+                      f"wave trips p50 {np.percentile(wtr[sel],50):.0f} max {wtr[sel].max():.0f}; batch phase minus iteration p50 {np.percentile((D(4,3)-it_us)[sel],50):.2f} us; start phase p50 {np.percentile(D(3,0)[sel],50):.2f}")
     ctx.close()
