@@ -58,3 +58,11 @@ import json,sys
 d=json.load(open('$OUT/$f.json')); r=d['roofline']
 print('$f', 'ms/step %.4f'%d['ms_per_step'], 'value %.3e'%d['value'], 'ao %.4f frac %.4f sorted %s'%(r['avg_launch_ms'], r['frac'], r.get('avg_launch_ms_batches_sorted_by_trip_hints')), 'cpu', (d.get('cpu_baseline') or {}).get('value'), 'parity', (d.get('parity_measured') or {}).get('max'))"; done
 head -8 $OUT/kernel_stats.csv | cut -c1-160
+# the 1/8 slab, both ocean presets, with and without the latency layout / the split second layer (A/B on this box)
+for cfg in default corrected; do
+  python bench.py --ny 70 --flux-configuration $cfg --no-cpu-baseline > $OUT/bench_slab70_$cfg.json 2>> $OUT/bench.err
+  python bench.py --ny 70 --flux-configuration $cfg --latency-layout never --no-cpu-baseline > $OUT/bench_slab70_${cfg}_layout_never.json 2>> $OUT/bench.err
+  COFLUX_EXPERIMENTS=1 COFLUX_SLAB_SPLIT=0 python bench.py --ny 70 --flux-configuration $cfg --latency-layout never --no-cpu-baseline > $OUT/bench_slab70_${cfg}_round4_plan.json 2>> $OUT/bench.err
+done
+python bench.py --ny 140 --flux-configuration corrected --no-cpu-baseline > $OUT/bench_slab140_corrected.json 2>> $OUT/bench.err
+python bench.py --ny 280 --flux-configuration corrected --no-cpu-baseline > $OUT/bench_slab280_corrected.json 2>> $OUT/bench.err
