@@ -200,24 +200,25 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
         // small surface (a slab of a strongly scaled run): every chunk resident at once, one batch per wave — the
         // kernel is as long as its slowest batch, so nothing may queue behind anything
         //
-        // More chunks than CUs, at most twice as many (a 1440×70 latitude slab: 292 on 256): the workgroups of the second
-        // dispatch layer share a CU — and its one LDS pipe, which eight waves' scattered table reads saturate (a trip's ≈ 20
-        // reads of 1 KB per wave) — with an older workgroup that is served first: their waves ran 0.82 instead of 0.59 µs per
-        // trip and ended the kernel 6 µs after the first layer (per-wave stamps, profiles/r05_experiments.md §10; issue
-        // priority does not change it).  So the second layer is cut into the SMALLEST pieces that still give every CU at
-        // most one of them — 64 wet cells = one working wave where the excess allows: a CU then carries five working
-        // waves instead of eight.  (COFLUX_SLAB_SPLIT=0 with COFLUX_EXPERIMENTS=1: the uniform plan, for A/B runs.)
+        // More chunks than CUs (a 1440×70 latitude slab: 292 on 256; 1440×140: 561): a wave of the LAST dispatch layer shares
+        // its SIMD with older waves, which the issue arbiter serves first — on the 1/8 slab its trips took 0.82 instead of
+        // 0.59 µs and the layer ended the kernel 6 µs after the first one (per-wave stamps, profiles/r05_experiments.md §10;
+        // issue priority does not change it, and it is not the CU's LDS pipe).  So that layer is cut into the SMALLEST pieces
+        // that still give every CU at most one of them — 64 wet cells = one working wave where the excess allows: as few
+        // cells as possible in the slow chains, no CU with a whole workgroup more than the others (1440×70: 27.3 → 26.0 µs per
+        // step, 1440×130: 33.6 → 32.6, 1440×140: 34.1 → 33.7).  (COFLUX_SLAB_SPLIT=0 with COFLUX_EXPERIMENTS=1: the uniform plan.)
         const long n256 = chunks(need, 256);
         int w2 = 256;
-        if (n256 > layer && n256 <= 2L * layer) {
+        const long whole = n256 > layer ? (n256 - 1) / layer : 0;  // dispatch layers of whole workgroups ahead of the last one (0: one layer is all)
+        if (whole >= 1) {
             static const bool split = [] { const char* e = experiment_knob("COFLUX_SLAB_SPLIT"); return !(e && e[0] == '0'); }();
-            const long excess = need - cap(256);
+            const long excess = need - whole * cap(256);
             if (split)
                 for (w2 = 64; w2 < 256 && chunks(excess, w2) > layer; w2 += 64) {}
         }
         if (w2 < 256) {
-            add_round(256, layer, false);
-            add_round(w2, chunks(need - cap(256), w2), true);
+            add_round(256, whole * layer, false);
+            add_round(w2, chunks(need - whole * cap(256), w2), true);
         } else {
             add_round(256, n256, true);
         }
