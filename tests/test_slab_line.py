@@ -119,3 +119,16 @@ def test_time_steps_with_tail_workgroups_same_bits(layout, config):
         ctx.close()
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("ny,config", [(70, "default"), (140, "default"), (140, "corrected")])
+def test_piece_layer_plan_same_bits_as_uniform_chunks(ny, config):
+    """plan_chunk_rounds cuts the LAST dispatch layer of a surface of one to three 256-cell chunks per CU into pieces of 64 /
+    128 / 192 wet cells (one piece per CU at most: a wave there shares its SIMD with older ones and runs its chain 1.4 × slower).
+    A plan only steers scheduling: forced uniform 256-cell chunks (CF_OPT_AO_CHUNK) must give the same bits."""
+    fluxes, vd = util.CONFIGS[config]()
+    params = ic.flux_params(fluxes, velocity_difference=vd, ocean_surface=ic.SurfaceRadiationProperties(0.06, 1.0))
+    case = util.build_case(1440, ny, 7, 7, ny_global=560, j_offset=210)
+    auto = run_gpu(case, params, fused=True, ice=True)
+    uniform = run_gpu(case, params, fused=True, ice=True, options=((abi.OPT_AO_CHUNK, 256),))
+    _same_bits(auto, uniform, f"1440x{ny} {config}")
