@@ -613,6 +613,119 @@ def emit(order, insts, preds, entry_waitcnt):
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# verification: the emitted piece against the compiler's, by symbolic execution (run on every edit; a failure stops the build)
+# ---------------------------------------------------------------------------------------------
+ANY_REG = re.compile(r"\b([vsa])\[(\d+):(\d+)\]|\b([vs])(\d+)\b|\b(vcc_lo|vcc_hi|vcc|exec_lo|exec_hi|exec|m0|scc)\b")
+
+
+def _expand(m):
+    if m.group(1):
+        return [f"{m.group(1)}{n}" for n in range(int(m.group(2)), int(m.group(3)) + 1)]
+    if m.group(4):
+        return [f"{m.group(4)}{m.group(5)}"]
+    r = m.group(6)
+    return {"vcc": ["vcc_lo", "vcc_hi"], "exec": ["exec_lo", "exec_hi"]}.get(r, [r])
+
+
+def symbolic_state(raw_lines, scratch_lo=None, scratch_hi=None):
+    """Runs a straight-line piece on symbolic inputs.  Every instruction's result is a hash of its mnemonic, its modifiers and
+    the VALUES (not the names) of what it reads, operand by operand; returns (final value of every register written, the
+    multiset of instructions by value).  Also checks the LDS discipline of the piece's own reads: a result is used, and a
+    destination overwritten, only behind an s_waitcnt lgkmcnt that covers it."""
+    val = {}
+    get = lambda r: val.get(r, ("in", r))
+    bag = []
+    issued = 0            # LDS reads of this piece issued so far
+    landed = 0            # reads [0, landed) are known to have arrived
+    pending = {}          # register -> index of the in-flight read that writes it
+    for line in raw_lines:
+        if line is None:
+            continue
+        code = line.split(";")[0].strip()
+        if not code or code.startswith(";;#") or code.startswith("."):
+            continue
+        m = re.match(r"(\S+)\s*(.*)", code)
+        op, rest = m.group(1), m.group(2)
+        if op == "s_nop":
+            continue
+        if op == "s_waitcnt":
+            c = re.search(r"lgkmcnt\((\d+)\)", rest)
+            if c:
+                landed = max(landed, issued - int(c.group(1)))
+                pending = {r: i for r, i in pending.items() if i >= landed}
+            continue
+        ops = split_operands(rest)
+        ins = parse_inst(line)
+        if ins is None:
+            raise SystemExit(f"verify: cannot parse {line!r}")
+        if op.startswith("ds_read") or (op.startswith("v_") and not op.startswith("v_cmp")) or (op.startswith("s_") and not op.startswith(("s_cmp", "s_bitcmp"))):
+            def_idx = {0}
+        elif op.startswith("v_cmp"):
+            def_idx = {0}
+        else:
+            def_idx = set()
+        tied = bool(FMAC.match(op))
+        reads = []
+        canon = [op]
+        for k, tok in enumerate(ops):
+            if k in def_idx and not tied:
+                canon.append("D")
+                continue
+            parts = []
+
+            def sub(mm):
+                rs = _expand(mm)
+                reads.extend(rs)
+                parts.append(tuple(get(r) for r in rs))
+                return "@"
+            shape = ANY_REG.sub(sub, tok)
+            canon.append((shape, tuple(parts)))
+        implicit = sorted(ins.uses - set(reads))      # exec for VALU, scc for s_addc …
+        for r in implicit:
+            reads.append(r)
+            canon.append((r, get(r)))
+        for r in reads:
+            if r in pending:
+                raise SystemExit(f"verify: {line.strip()!r} reads {r} while the LDS read that writes it may be in flight")
+        for r in ins.defs:
+            if r in pending:
+                raise SystemExit(f"verify: {line.strip()!r} overwrites {r}, the destination of an LDS read in flight")
+        h = hash(tuple(canon))
+        bag.append(h)
+        defs_in_order = []
+        for k in sorted(def_idx):
+            if k < len(ops):
+                for mm in ANY_REG.finditer(ops[k]):
+                    defs_in_order.extend(_expand(mm))
+        for r in sorted(ins.defs - set(defs_in_order)):
+            defs_in_order.append(r)                    # implicit: scc of an s_and, exec of a saveexec (not in pieces)
+        for pos, r in enumerate(defs_in_order):
+            val[r] = (h, pos)
+        if op.startswith("ds_read"):
+            for r in defs_in_order:
+                pending[r] = issued
+            issued += 1
+    scratch = set()
+    if scratch_lo is not None:
+        scratch = {f"v{n}" for n in range(scratch_lo, scratch_hi + 1)}
+    return {r: v for r, v in val.items() if r not in scratch}, sorted(bag)
+
+
+def verify_piece(old_lines, new_lines, pool):
+    lo, hi = pool if pool else (None, None)
+    a_state, a_bag = symbolic_state(old_lines)
+    b_state, b_bag = symbolic_state(new_lines, lo, hi)
+    if a_bag != b_bag:
+        raise SystemExit("verify: the emitted piece does not execute the same instructions on the same values")
+    for r, v in a_state.items():
+        if b_state.get(r) != v:
+            raise SystemExit(f"verify: register {r} ends the piece with another value")
+    extra = set(b_state) - set(a_state)
+    if extra:
+        raise SystemExit(f"verify: the emitted piece writes registers the original does not: {sorted(extra)[:8]}")
+
+
 NO_REORDER = False
 
 
@@ -650,6 +763,7 @@ def process(lines, fn_sub, must_contain, report, min_len=12, pool=None):
         if after >= before and not (renamed and NO_REORDER):
             continue
         text = emit(order, insts, preds, entry)
+        verify_piece(lines[a:b], text, pool)
         edits.append((a, b, text, before, after, len(real), renamed))
     for a, b, text, before, after, nreal, renamed in sorted(edits, reverse=True):
         new_lines[a:b] = text
