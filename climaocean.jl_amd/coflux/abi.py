@@ -223,8 +223,8 @@ _lib = None
 
 
 def source_stamp():
-    """sha256[:16] over csrc/*.{hip,cpp,hpp,h} + include/coflux.h in the Makefile's order, or None when the sources are not
-    there (an installed library without its tree)."""
+    """sha256[:16] over csrc/*.{hip,cpp,hpp,h} + include/coflux.h + csrc/tools/gcn_sched.py (the slab kernels are built through
+    it) in the Makefile's order, or None when the sources are not there (an installed library without its tree)."""
     import glob
     import hashlib
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
@@ -234,7 +234,8 @@ def source_stamp():
         return None
     # GNU make's $(sort) orders byte-wise, "../../include/coflux.h" ahead of every plain file name
     h = hashlib.sha256()
-    for f in [header] + [os.path.join(csrc, n) for n in names]:
+    tool = os.path.join(csrc, "tools", "gcn_sched.py")
+    for f in [header] + [os.path.join(csrc, n) for n in names] + ([tool] if os.path.exists(tool) else []):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
