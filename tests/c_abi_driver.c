@@ -1,7 +1,8 @@
 /* c_abi_driver.c — exercises libcoflux exactly as a non-Python host (the Julia ccall stub) would:
  * plain C, device memory through cf_device_alloc / cf_h2d / cf_d2h, no torch.  Built and run by
  * tests/test_gpu_parity.py::test_c_driver_through_the_abi.  Covers cf_update_state, the step loop cf_time_steps (a
- * cf_run_schedule built in C) and the sea-ice interface (a cf_sea_ice_state built in C).  Prints "OK <checksum>". */
+ * cf_run_schedule built in C), the sea-ice interface (a cf_sea_ice_state built in C) and CF_OPT_LATENCY_LAYOUT with
+ * cf_solver_latency_layout.  Prints "OK <checksum>". */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -102,6 +103,26 @@ int main(void) {
             sum += f[k];
         }
     if (!(first > 20.0 && first < 400.0)) { fprintf(stderr, "implausible latent heat %g\n", first); return 5; }
+    /* the scheduling options of round 5 from a C caller: the latency layout forced on and off must reproduce the same bits
+     * (a small surface with the default flux parameters: off in the automatic mode, cf_solver_latency_layout tells) */
+    {
+        int layout = -1;
+        CHECK(cf_solver_latency_layout(ctx, &layout));
+        if (layout != 0) { fprintf(stderr, "automatic latency layout on the logarithmic profile: %d\n", layout); return 7; }
+        double* again = (double*)malloc(n * 8);
+        for (int mode = 2; mode >= 0; mode -= 2) {
+            CHECK(cf_set_option(ctx, CF_OPT_LATENCY_LAYOUT, mode));
+            CHECK(cf_update_state(ctx, &src, &w, &oc, &e, &fx, NULL, &net));
+            CHECK(cf_sync(ctx));
+            CHECK(cf_solver_latency_layout(ctx, &layout));
+            if (layout != (mode == 2)) { fprintf(stderr, "cf_solver_latency_layout says %d in mode %d\n", layout, mode); return 7; }
+            CHECK(cf_d2h(ctx, again, fl[1], n * 8));
+            if (memcmp(again, f, n * 8) != 0) { fprintf(stderr, "CF_OPT_LATENCY_LAYOUT = %d changes the latent heat's bits\n", mode); return 7; }
+        }
+        CHECK(cf_set_option(ctx, CF_OPT_LATENCY_LAYOUT, 1));
+        if (cf_set_option(ctx, CF_OPT_LATENCY_LAYOUT, 3) == 0) { fprintf(stderr, "CF_OPT_LATENCY_LAYOUT = 3 accepted\n"); return 7; }
+        free(again);
+    }
     /* run!(simulation) in the library: three steps of cf_time_steps over the same uniform state must reproduce the
      * single cf_update_state above (the uniform JRA55 planes make every time fraction equivalent) */
     {
