@@ -200,7 +200,9 @@ __device__ __forceinline__ LeanCell lean_prologue(const DevParams& P, double kap
 // All 64 lanes of a wave must call this together (wave64 ballot inside); `active` lanes iterate.
 // Preconditions (loop_params selects SOLVER_OCEAN_LEAN only then): U_G,min > 0 (⇒ u★ > 0), Charnock-type momentum
 // roughness, identical Reynolds-scaled scalar roughness lengths.  FixedIterations(n) arrives as maxiter = n, tol = 0.
-template <bool COARE>
+// ONE_COMPARE = false: the loop test as `active && !(drift < tol)` — the certified kernels' exact-path batch, whose launch
+// measured 1.5 % slower with the single compare (register allocation around the queue logic; profiles/r05_experiments.md §11)
+template <bool COARE, bool ONE_COMPARE = true>
 __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const LeanCell& c, const double* tab, bool active) {
     const double* logt = tab + LOG_OFFSET;
     // θ★ = χ Δθ and q★ = χ Δq share one transfer coefficient χ = κ / D_q from the first iterate on (one scalar
@@ -209,13 +211,16 @@ __device__ __forceinline__ Scales mo_iterate_lean(const LoopParams& L, const Lea
     // from θ★ = q★ = 1e-4, takes the general expressions (a wave-uniform branch: every running lane has the same count).
     const double B = __builtin_fma(c.dtheta, c.bth, c.bqq * c.dq), S = fabs(c.dtheta) + fabs(c.dq);
     double us = 1e-4, ius = 1e4, chi = 0.0, kb = __builtin_fma(1e-4, c.bth, c.bqq * 1e-4);
-    double drift = __builtin_inf();
+    // (a lane that does not take part starts BELOW every tolerance and never runs: the loop's test is
+    // then ONE compare whose mask is the ballot; `active && …` made the compiler rebuild the mask through v_cndmask / v_cmp_ne
+    // and two more VALU → SALU hand-offs per trip)
+    double drift = (ONE_COMPARE && !active) ? -__builtin_inf() : __builtin_inf();
     int it = 0;
     double log_A_q = L.log_A_q;  // in a vector register: as the third scalar operand of one multiply-add it would be copied there per iteration
     asm("" : "+v"(log_A_q));
     for (int trip = 0;; ++trip) {
         // (every running lane has it == trip: the trip limit is a scalar test)
-        const bool go = active && !(drift < L.tol);
+        const bool go = (ONE_COMPARE || active) && !(drift < L.tol);
         if (trip >= L.maxiter || __builtin_amdgcn_ballot_w64(go) == 0ull) break;  // the wave leaves the loop together
         if (go) {
             const double inv_L = kb * (ius * ius);  // 1/L★ = κ b★ / u★²
@@ -342,7 +347,7 @@ __device__ __forceinline__ Scales mo_iterate_lean_line(const LoopParams& L, cons
     const double* logt = tab + LOG_OFFSET;
     const double B = __builtin_fma(c.dtheta, c.bth, c.bqq * c.dq), S = fabs(c.dtheta) + fabs(c.dq);
     double us = 1e-4, ius = 1e4, chi = 0.0, kb = __builtin_fma(1e-4, c.bth, c.bqq * 1e-4);
-    double drift = __builtin_inf();
+    double drift = active ? __builtin_inf() : -__builtin_inf();  // (see mo_iterate_lean)
     int it = 0;
     double log_A_q = L.log_A_q;
     asm("" : "+v"(log_A_q));
@@ -352,7 +357,7 @@ __device__ __forceinline__ Scales mo_iterate_lean_line(const LoopParams& L, cons
             it = 1;
         }
         for (int trip = 1;; ++trip) {
-            const bool go = active && !(drift < L.tol);
+            const bool go = !(drift < L.tol);
             if (trip >= L.maxiter || __builtin_amdgcn_ballot_w64(go) == 0ull) break;
             if (go) {
                 mo_lean_line_step<COARE, false>(L, c, tab, logt, B, S, log_A_q, us, ius, chi, kb, drift);

@@ -522,7 +522,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                 }
                 if (__builtin_amdgcn_ballot_w64(exact) != 0ull) {
                     const LoopParams Le = kread(&opaque(K)->L);
-                    const Scales e = mo_iterate_lean<COARE>(Le, c, tab, exact);
+                    const Scales e = mo_iterate_lean<COARE, false>(Le, c, tab, exact);
                     if (exact) {
                         s = e;
                         s.it |= CERT_EXACT_FLAG;
