@@ -1,3 +1,4 @@
+# same-box A/B of two library builds on the 1/4-degree surface: scratch/libcoflux_prev.so against the tree's
 export COFLUX_ALLOW_STALE_LIBRARY=1
 for i in 1 2 3; do for lib in prev new; do
   L=$PWD/climaocean.jl_amd/csrc/libcoflux.so; [ $lib = prev ] && L=$PWD/scratch/libcoflux_prev.so
