@@ -85,10 +85,11 @@ def parse():
                     help="CF_OPT_FUSED_INTERP: interpolate_atmosphere_state! inside the solver's prologue (two launches per step); "
                          "default: the library's choice")
     ap.add_argument("--solver-path", choices=("auto", "exact", "certified"), default="auto",
-                    help="CF_OPT_SOLVER_PATH: the reference's own iteration, or the certified reduced-iteration solve with "
-                         "per-cell exact-path fallback (include/coflux.h).  auto = time both; `value` is the certified path's only if "
-                         "it is faster AND every field of this run's parity check of that path (the six flux fields and the net "
-                         "fluxes, each rank against the CPU oracle) is <= 1e-6, else the exact path's; config.solver_path says which")
+                    help="CF_OPT_SOLVER_PATH.  `value` is ALWAYS the path named here: exact (= auto: the library's default, the "
+                         "reference's own iteration) or certified (opt-in: the reduced-iteration solve with per-cell exact-path "
+                         "fallback, include/coflux.h).  auto at N = 1 also times the certified path beside it, interleaved, and "
+                         "reports it as `value_certified` with its parity against the CPU oracle — never as `value`.  At N > 1 "
+                         "only the named path runs, so a SCALE series is one algorithm at every N")
     ap.add_argument("--selftest", action="store_true",
                     help="no timing: verify the halo backends, run 10 steps, gather the surface on rank 0 and compare it with the "
                          "CPU oracle; prints one JSON line, exits non-zero naming the failing stage")
@@ -582,21 +583,19 @@ def main():
         return out
 
     # ---- the two solver paths (CF_OPT_SOLVER_PATH) ---------------------------------------------------------------------
-    # The command line's path (auto: the exact one) is timed on every verified halo backend.  With auto the certified path
-    # is timed beside it, interleaved repetition by repetition on the same schedule and backend, checked against the CPU
-    # oracle on THIS rank's surface (every rank, so that all ranks take the same decision at any N), and used for `value`
-    # only if every field is within 1e-6 and its median is the smaller one.
+    # `value` is the path the command line names — exact unless --solver-path certified — on every verified halo backend.
+    # With auto at N = 1 the certified path is timed beside it (interleaved repetition by repetition on the same schedule),
+    # checked against the CPU oracle, and reported as `value_certified`: a second number, never the number of record
+    # (VERDICT r5 / ADVICE r5: the library and ComponentInterfaces default to the exact path, so that is what `value` measures;
+    # at N > 1 one path only, so that the points of a scaling series are the same algorithm).
     first_path = "certified" if a.solver_path == "certified" else "exact"
     ctx.set_option(abi.OPT_SOLVER_PATH, PATH_CODE[first_path])
     if first_path == "certified" and ctx.solver_iteration_path() != abi.SOLVER_PATH_CERTIFIED:
         first_path = "exact"    # (the option does not apply to this formulation / geometry: the exact path ran)
     paths = [first_path]
-    if a.solver_path == "auto" and a.config == "ocean":
+    if a.solver_path == "auto" and a.config == "ocean" and world == 1:
         ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
-        applies = torch.tensor([1 if ctx.solver_iteration_path() == abi.SOLVER_PATH_CERTIFIED else 0], device=coll_dev)
-        if world > 1:   # every rank runs the same sequence of timed regions (their barriers pair up): all or none
-            dist.all_reduce(applies, op=dist.ReduceOp.MIN)
-        if bool(applies.item()):
+        if ctx.solver_iteration_path() == abi.SOLVER_PATH_CERTIFIED:
             paths.append("certified")
         ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_EXACT)
     switch_steps = {}
@@ -615,19 +614,13 @@ def main():
         ref_rank = oracle_reference(dict(ocean=ocean_np[0], src=src_np, weights=w_np), params, nx, ny, h)
         shares = {}
         worst = measured_parity(ctx, ref_rank, dict(src=src, weights=w, ocean=states[0]), nx, ny, h, shares=shares)
-        # decided on EVERY field parity_measured reports — the six flux fields (the north star's statement) and the net
-        # fluxes assembled from them.  (J_S ∝ F_v − P can cancel to nothing: the certificate bounds the vapour flux against
-        # |F_v − P| as well, coflux_certified.hpp::CertNetSalt.  The face stresses average two cells' ρτ and can cancel too —
-        # nothing bounds that per cell; it is measured here, on every rank, and decides with the rest)
+        # every field parity_measured reports — the six flux fields (the north star's statement) and the net fluxes
+        # assembled from them (J_S ∝ F_v − P and the face stresses can cancel: measured, not bounded per cell)
         six = max(v for k, v in worst.items() if k.startswith("fluxes."))
-        flag = torch.tensor([max(worst.values()), six], dtype=torch.float64, device=coll_dev)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        path_parity["certified"] = dict(max_over_ranks=float(flag[0].item()), max_six_flux_fields_over_ranks=float(flag[1].item()),
-                                        worst_scaled_error_rank0=worst, exact_path_cells_rank0=shares,
-                                        metric="|got - oracle exact path| / max(|oracle|, field scale), one cf_update_state per rank")
-        if float(flag[0].item()) <= 1e-6 and path_results["certified"][0] < path_results["exact"][0]:
-            chosen = "certified"
+        path_parity["certified"] = dict(max=max(worst.values()), max_six_flux_fields=six,
+                                        within_half_the_tolerance=bool(max(worst.values()) <= 5e-7),
+                                        worst_scaled_error=worst, exact_path_cells=shares,
+                                        metric="|got - oracle exact path| / max(|oracle|, field scale), one cf_update_state")
     ctx.set_option(abi.OPT_SOLVER_PATH, PATH_CODE[chosen])
     elapsed, samples, sched, next_step = path_results[chosen]
     next_step = max(v[3] for v in path_results.values())
@@ -758,6 +751,8 @@ def main():
                    ms_per_step_spread=[min(samples) / steps * 1e3, max(samples) / steps * 1e3],
                    ms_per_step_by_rank=([t / steps * 1e3 for t in path_per_rank[chosen]] if path_per_rank.get(chosen) else None),
                    solver_paths_ms_per_step={k: v[0] / steps * 1e3 for k, v in path_results.items()},
+                   value_exact=(cells_total * steps / path_results["exact"][0] if "exact" in path_results else None),
+                   value_certified=(cells_total * steps / path_results["certified"][0] if "certified" in path_results else None),
                    solver_path_parity=path_parity or None,
                    halo_paths_ms_per_step={k: v[0] / steps * 1e3 for k, v in results.items()} if world > 1 else None,
                    # dominant kernel = compute_atmosphere_ocean_fluxes! (SURVEY.md §8d contract figure 128 B/cell)
