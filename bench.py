@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--repetitions", type=int, default=None, help="timed repetitions of K steps; the median is reported")
     ap.add_argument("--latency-layout", choices=("auto", "never", "always"), default="auto",
                     help="CF_OPT_LATENCY_LAYOUT: the exact path's kernels for one or two waves per SIMD (auto: chunk plans of at most two workgroups per CU)")
-    ap.add_argument("--ao-chunk", type=int, default=0, help="CF_OPT_AO_CHUNK (0 = the library's plan): wet cells per solver workgroup, experiments")
+    ap.add_argument("--ao-chunk", type=int, default=0, help="CF_OPT_AO_CHUNK (0 = the library's plan): wet cells per solver workgroup — an experiment "
+                                                            "option, needs COFLUX_EXPERIMENTS=1 in the environment")
     ap.add_argument("--nx", type=int, default=1440)
     ap.add_argument("--ny", type=int, default=560)
     ap.add_argument("--halo", type=int, default=7)  # README.md:58 halo=(7,7,7)
@@ -81,9 +82,6 @@ def parse():
     ap.add_argument("--trip-hints", type=int, choices=(0, 1, 2, 3), default=2,
                     help="CF_OPT_TRIP_HINTS for the timed region: 2 = the library's default (index-ordered batches in the round-3 ocean "
                          "kernel), 1 = batches sorted by last call's trip counts over the whole chunk, 3 = within quarter-chunk windows")
-    ap.add_argument("--fused-interp", type=int, choices=(0, 1), default=None,
-                    help="CF_OPT_FUSED_INTERP: interpolate_atmosphere_state! inside the solver's prologue (two launches per step); "
-                         "default: the library's choice")
     ap.add_argument("--solver-path", choices=("auto", "exact", "certified"), default="auto",
                     help="CF_OPT_SOLVER_PATH.  `value` is ALWAYS the path named here: exact (= auto: the library's default, the "
                          "reference's own iteration) or certified (opt-in: the reduced-iteration solve with per-cell exact-path "
@@ -300,8 +298,6 @@ def main():
     ctx.set_option(abi.OPT_CERTIFIED_BUDGET, a.certified_budget)
     if a.solver_path == "certified":
         ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
-    if a.fused_interp is not None:
-        ctx.set_option(abi.OPT_FUSED_INTERP, a.fused_interp)
     ring_rows = ctx.grid.ring + 1
     states = [{k: ctx.to_device(o[k]) for k in ("T", "S", "u", "v", "mask")} for o in ocean_np]
     states[1]["mask"] = states[0]["mask"]   # one static wet mask (the solver's chunk table is keyed on it)
@@ -638,7 +634,6 @@ def main():
         # 78.1 µs, profiles/r05_experiments.md §4).  The step count of the timed region's own settle loop: the same on every rank
         idle = 4 + (settle.get(best) or 0)
         run_steps(best, sched, next_step, idle)
-        ctx.set_option(abi.OPT_PROFILE_STRIDE, 1)
         ctx.profile_enable(n)
         run_steps(best, sched, next_step + idle, n)
         out = [ctx.profile_read(k) for k in range(3)]
@@ -676,16 +671,19 @@ def main():
 
         def variant_key(name):
             """profile kernel name → the key the roofline looks up: the lean solver's template variants are told apart
-            (<COARE, BLOCK, FUSE, FUSE_INTERP[, TAIL[, CERT]]>)"""
+            (round 6 on: <COARE, FUSE, TAIL, CERT>; the round-5 counter files: <COARE, BLOCK, FUSE, FUSE_INTERP[, TAIL[, CERT]]>)"""
             base = name.split("<")[0].split("::")[-1].strip()
             if base == "ao_lean_kernel" and "<" in name:
                 t = [x.strip() for x in name.split("<")[1].split(">")[0].split(",")]
-                fuse_net, piped, cert = t[2] == "true", len(t) > 4 and t[4] == "true", len(t) > 5 and t[5] == "true"
+                if t[1] in ("true", "false"):
+                    fuse_net, piped, cert = t[1] == "true", t[2] == "true", t[3] == "true"
+                else:
+                    fuse_net, piped, cert = t[2] == "true", len(t) > 4 and t[4] == "true", len(t) > 5 and t[5] == "true"
                 return base + (":fused" if fuse_net else ":plain") + (":piped" if piped else "") + (":certified" if cert else "")
             return base
         traffic, traffic_source, sq, sq_source = {}, None, {}, None
         canonical = (nx, ny, a.flux_configuration, world, a.config) == (1440, 560, "default", 1, "ocean")
-        for tag in ("r05", "r04", "r03", "r02", "r01"):
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
                 if canonical:
@@ -695,7 +693,7 @@ def main():
                 break
             except Exception:
                 continue
-        for tag in ("r05", "r04", "r03"):
+        for tag in ("r06", "r05", "r04", "r03"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json")))
                 if canonical:

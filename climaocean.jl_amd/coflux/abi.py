@@ -6,7 +6,7 @@ the value the library reports and that every declared symbol is exported.
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 PEER_HANDLE_BYTES = 64
 HALO_NONE, HALO_RCCL, HALO_PEER = 0, 1, 2
@@ -24,14 +24,14 @@ FORMULATION_SIMILARITY, FORMULATION_LARGE_YEAGER = 0, 1
 VELOCITY_RELATIVE, VELOCITY_WIND = 0, 1
 MASK_NONE, MASK_U8, MASK_BOTTOM_HEIGHT = 0, 1, 2
 ALBEDO_CONSTANT, ALBEDO_LATITUDE_DEPENDENT = 0, 1
-OPT_SOLVER, OPT_INTERP_TILE_CAP, OPT_MAX_BLOCKS, OPT_TRIP_HINTS, OPT_AO_CHUNK, OPT_PROFILE_STRIDE, OPT_FUSED_NET = 0, 1, 2, 3, 4, 5, 6
-OPT_ICE_ORBIT_SHORTCUT, OPT_FUSED_INTERP, OPT_MERGED_PREFETCH = 7, 8, 9
+OPT_SOLVER, OPT_TRIP_HINTS, OPT_FUSED_NET, OPT_ICE_ORBIT_SHORTCUT, OPT_MERGED_PREFETCH = 0, 3, 6, 7, 9
+OPT_INTERP_TILE_CAP, OPT_AO_CHUNK = 1, 4   # experiment options: the library accepts them only with COFLUX_EXPERIMENTS=1 in the environment
 OPT_SOLVER_PATH, OPT_CERTIFIED_BUDGET, OPT_ICE_FREE_CELLS, OPT_LATENCY_LAYOUT = 10, 11, 12, 13
 ICE_FREE_ITERATE, ICE_FREE_ZERO = 0, 1
 PIPELINE_WITHIN_CALL, PIPELINE_CONTINUING = 1, 2   # cf_run_schedule.pipeline
 SOLVER_PATH_EXACT, SOLVER_PATH_CERTIFIED = 0, 1      # how the Monin–Obukhov fixed point is reached (include/coflux.h)
 CERTIFIED_EXACT_FLAG = 0x100                         # `iterations` of a cell the certified path solved on the exact path
-SOLVER_TABLES, SOLVER_LIBM, SOLVER_TABLES_R2, SOLVER_TABLES_R2_OUTER = 0, 1, 2, 3   # 2, 3: A/B diagnostics (include/coflux.h)
+SOLVER_TABLES, SOLVER_LIBM = 0, 1
 STAGE_INTERPOLATE, STAGE_AO_FLUXES, STAGE_NET_FLUXES, STAGE_UPDATE_STATE = 0, 1, 2, 3
 
 JRA55_VARIABLES = ("tas", "huss", "psl", "uas", "vas", "rlds", "rsds", "prra", "prsn")

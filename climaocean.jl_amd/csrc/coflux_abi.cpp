@@ -175,7 +175,7 @@ static LoopParams loop_params(const cf_flux_params& p, const DevParams& d) {
     // branch-free instruction streams for the two production configurations (omip_simulation.jl:42-49, :63-69)
     const bool gusty = p.minimum_gustiness > 0;  // ⇒ U > 0 ⇒ u★ > 0: no division guards needed
     if (gusty && m.kind != CF_ROUGHNESS_CONSTANT && q.kind == CF_SCALAR_ROUGHNESS_REYNOLDS && C.same_scalar)
-        C.specialization = SOLVER_OCEAN_LEAN;  // (CF_OPT_SOLVER = CF_SOLVER_TABLES_R2 runs it on SOLVER_OCEAN's body)
+        C.specialization = SOLVER_OCEAN_LEAN;
     else if (gusty && m.kind == CF_ROUGHNESS_CONSTANT && q.kind == CF_SCALAR_ROUGHNESS_CONSTANT &&
              t.kind == CF_SCALAR_ROUGHNESS_CONSTANT)
         C.specialization = SOLVER_ICE;
@@ -227,16 +227,15 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_begins, sizeof(int) * chunk_table_capacity(ncells)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chunk_meta, sizeof(int) * 4));
     }
-    int wet = 0, n = 0, wide = 0;
+    int wet = 0, n = 0;
     // (a context whose steps carry tail workgroups gets the plan made for them)
     // (not with a sea-ice formulation: there the riders sit in the interface solve's tail, and both solves do best on the
     // arrival layers — measured 293 vs 283 µs per step)
     const int plan = (ctx->launch.ao_chunk == 0 && ctx->merged_prefetch == 2 && !ctx->ice_ready) ? AO_PLAN_TAIL : ctx->launch.ao_chunk;
     HIP_TRY(ctx, build_chunk_table(ctx->stream, ctx->d_params, ctx->grid, mask, ctx->launch.cu_count, plan,
-                                   ctx->d_chunk_sums, ctx->d_chunk_begins, ctx->d_chunk_meta, &wet, &n, &wide));
-    ctx->launch.ao_wide = wide;
+                                   ctx->d_chunk_sums, ctx->d_chunk_begins, ctx->d_chunk_meta, &wet, &n));
     {   // the lists' storage: n chunks at the geometry's fixed stride (grown when a rebuild needs more)
-        const size_t want = std::max(wet_list_capacity(ncells), (size_t)(n + 1) * wet_list_stride(wide != 0));
+        const size_t want = std::max(wet_list_capacity(ncells), (size_t)(n + 1) * wet_list_stride());
         if (want > ctx->wet_list_entries) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             (void)hipFree(ctx->d_wet_pos);
@@ -265,20 +264,19 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
     ctx->launch.d_chunk_begins = ctx->d_chunk_begins;
     ctx->launch.n_chunks = n;
     int overflow = 0;
-    HIP_TRY(ctx, build_wet_lists(ctx->stream, ctx->d_params, ctx->grid, mask, n, wide != 0, ctx->d_chunk_begins, ctx->d_wet_pos,
+    HIP_TRY(ctx, build_wet_lists(ctx->stream, ctx->d_params, ctx->grid, mask, n, ctx->d_chunk_begins, ctx->d_wet_pos,
                                  ctx->d_trip, ctx->d_chunk_meta, &overflow));
     ctx->launch.d_wet_pos = overflow ? nullptr : ctx->d_wet_pos;
     // the lean ocean kernel's lists: the static lists in index order until the first call has run
     ctx->launch.d_lean_sorted = nullptr;
     ctx->launch.d_lean_info = nullptr;
-    if (!overflow) HIP_TRY(ctx, build_lean_lists(ctx->stream, n, wide != 0, ctx->d_wet_pos, ctx->d_chunk_begins, ctx->d_lean_sorted, ctx->d_lean_info));
+    if (!overflow) HIP_TRY(ctx, build_lean_lists(ctx->stream, n, ctx->d_wet_pos, ctx->d_chunk_begins, ctx->d_lean_sorted, ctx->d_lean_info));
     ctx->launch.d_lean_sorted = ctx->d_lean_sorted;
     ctx->launch.d_lean_info = ctx->d_lean_info;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_trip_ice, 0, (size_t)n * wet_list_stride(wide != 0), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_trip_ice, 0, (size_t)n * wet_list_stride(), ctx->stream));
     ctx->launch.d_trip = ctx->trip_hints ? ctx->d_trip : nullptr;
     if (std::getenv("COFLUX_DEBUG"))
-        std::fprintf(stderr, "[coflux] chunk table: %d chunks of %d wet cells (%d CUs, %s workgroups)\n", n, wet, ctx->launch.cu_count,
-                     wide ? "wide" : "narrow");
+        std::fprintf(stderr, "[coflux] chunk table: %d chunks of %d wet cells (%d CUs)\n", n, wet, ctx->launch.cu_count);
     return CF_OK;
 }
 
@@ -448,7 +446,6 @@ int cf_create(cf_ctx** out, int device, const cf_grid* grid, const cf_flux_param
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
-        ctx->launch.max_blocks = ((4 * prop.multiProcessorCount + 7) / 8) * 8;
         ctx->launch.cu_count = prop.multiProcessorCount;
         ctx->launch.latency_layout = 1;  // CF_OPT_LATENCY_LAYOUT: automatic
     }
@@ -514,17 +511,14 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
     if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
     switch (option) {
         case CF_OPT_SOLVER:
-            if (value != CF_SOLVER_TABLES && value != CF_SOLVER_LIBM && value != CF_SOLVER_TABLES_R2 && value != CF_SOLVER_TABLES_R2_OUTER) return fail(ctx, CF_ERR_INVALID, "unknown solver %d", value);
+            if (value != CF_SOLVER_TABLES && value != CF_SOLVER_LIBM) return fail(ctx, CF_ERR_INVALID, "unknown solver %d", value);
             ctx->launch.solver = value;
             return CF_OK;
         case CF_OPT_INTERP_TILE_CAP:
+            if (!experiment_knob("COFLUX_EXPERIMENTS")) return fail(ctx, CF_ERR_INVALID, "CF_OPT_INTERP_TILE_CAP is an experiment option: start the process with COFLUX_EXPERIMENTS=1");
             // 4 waves × 9 variables × cap × 8 B of dynamic LDS must fit a workgroup's 64 KB
             if (value != 0 && (value < 16 || value > 224)) return fail(ctx, CF_ERR_INVALID, "interp tile cap %d: 0 (LDS-free gather kernel) or 16…224", value);
             ctx->launch.interp_cap = value;
-            return CF_OK;
-        case CF_OPT_MAX_BLOCKS:
-            if (value < 8 || value % 8) return fail(ctx, CF_ERR_INVALID, "max blocks %d must be a positive multiple of 8", value);
-            ctx->launch.max_blocks = value;
             return CF_OK;
         case CF_OPT_TRIP_HINTS:
             if (value < 0 || value > 3) return fail(ctx, CF_ERR_INVALID, "trip hints %d: 0 (off), 1 (on), 2 (automatic), 3 (on, the lean kernel in quarter-chunk windows)", value);
@@ -538,10 +532,6 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
         case CF_OPT_FUSED_NET:
             if (value < 0 || value > 2) return fail(ctx, CF_ERR_INVALID, "fused net fluxes %d: 0 (never), 1 (when possible), 2 (automatic)", value);
             ctx->fused_net = value;
-            return CF_OK;
-        case CF_OPT_FUSED_INTERP:
-            if (value < 0 || value > 1) return fail(ctx, CF_ERR_INVALID, "fused interpolation %d: 0 (off), 1 (when possible)", value);
-            ctx->fused_interp = value;
             return CF_OK;
         case CF_OPT_MERGED_PREFETCH:
             if (value < 0 || value > 2)
@@ -558,10 +548,6 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->ice_free_zero = value == CF_ICE_FREE_ZERO;
             ctx->ice_kernel.ice_free_zero = ctx->ice_free_zero ? 1.0 : 0.0;
             return CF_OK;
-        case CF_OPT_PROFILE_STRIDE:
-            if (value < 1) return fail(ctx, CF_ERR_INVALID, "profile stride %d must be >= 1", value);
-            ctx->prof_stride = value;
-            return CF_OK;
         case CF_OPT_SOLVER_PATH:
             if (value != CF_SOLVER_PATH_EXACT && value != CF_SOLVER_PATH_CERTIFIED) return fail(ctx, CF_ERR_INVALID, "solver path %d: 0 (exact) or 1 (certified)", value);
             ctx->launch.certified = value;
@@ -576,9 +562,10 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
             ctx->fast.cert_budget = ctx->certified_budget / CERT_SAFETY;
             return CF_OK;
         case CF_OPT_AO_CHUNK:
-            if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024 && value != 1280 && value != 3072)
-                return fail(ctx, CF_ERR_INVALID, "solver chunk %d: wet cells per workgroup must be 0 (automatic), 256, 512, 768, 1024, 1280 "
-                            "(narrow workgroups, uniform size) or 3072 (wide workgroups)", value);
+            if (!experiment_knob("COFLUX_EXPERIMENTS")) return fail(ctx, CF_ERR_INVALID, "CF_OPT_AO_CHUNK is an experiment option: start the process with COFLUX_EXPERIMENTS=1");
+            if (value != 0 && value != 256 && value != 512 && value != 768 && value != 1024 && value != 1280)
+                return fail(ctx, CF_ERR_INVALID, "solver chunk %d: wet cells per workgroup must be 0 (automatic), 256, 512, 768, 1024 or 1280 "
+                            "(uniform size)", value);
             ctx->launch.ao_chunk = value;
             ctx->chunk_valid = false;
             return CF_OK;
@@ -732,40 +719,31 @@ static bool net_fluxes_fused(const cf_ctx* ctx) {
     // (CoefficientBasedFluxes runs a fixed trip count: its lists stay in index order, the epilogue's accesses coalesced —
     // measured cf_update_state 71.8 → 63.1 µs)
     const bool fixed_trips = ctx->fast.specialization == SOLVER_LY && ctx->launch.solver == CF_SOLVER_TABLES;
-    return (ctx->fused_net == 1 || (ctx->fused_net == 2 && (lean || fixed_trips))) &&
-           (ctx->launch.solver == CF_SOLVER_TABLES || ctx->launch.solver == CF_SOLVER_TABLES_R2 ||
-            ctx->launch.solver == CF_SOLVER_TABLES_R2_OUTER) &&
-           ctx->dev.albedo_kind == CF_ALBEDO_CONSTANT &&
-           (lean || !ctx->launch.ao_wide);  // (round 2's kernel has the fused epilogue in the narrow geometry only)
+    return (ctx->fused_net == 1 || (ctx->fused_net == 2 && (lean || fixed_trips))) && ctx->launch.solver == CF_SOLVER_TABLES &&
+           ctx->dev.albedo_kind == CF_ALBEDO_CONSTANT;
 }
 
 int cf_solver_iteration_path(cf_ctx* ctx, int* path) {
     if (!ctx || !path) return fail(ctx, CF_ERR_INVALID, "cf_solver_iteration_path: bad arguments");
     const bool lean = ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
-    const bool fused_interp = net_fluxes_fused(ctx) && ctx->fused_interp != 0 && !ctx->launch.ao_wide;
-    // (a chunk plan that has been requested but not built yet: the wide geometry is decided when the table is built)
-    const bool wide_pending = !ctx->chunk_valid && ctx->launch.ao_chunk == 3072;  // (CF_OPT_AO_CHUNK = 3072: the wide geometry)
-    const bool narrow_pending = !ctx->chunk_valid && ctx->launch.ao_chunk != 3072;
-    LaunchCfg L = ctx->launch;
-    if (narrow_pending) L.ao_wide = 0;
-    *path = lean && !wide_pending && lean_certified_applies(L, ctx->fast, fused_interp) ? CF_SOLVER_PATH_CERTIFIED : CF_SOLVER_PATH_EXACT;
+    // the predicate launch_ao_fluxes_lean itself decides on.  One launch runs the exact body whatever this says: with sea ice
+    // and CF_OPT_MERGED_PREFETCH = 2 the ocean solve rides in the interface solve's launch (ice_ocean_kernel), whose rider is the
+    // exact kernel — cf_update_state_sea_ice
+    *path = lean && lean_certified_applies(ctx->launch, ctx->fast) ? CF_SOLVER_PATH_CERTIFIED : CF_SOLVER_PATH_EXACT;
     return CF_OK;
 }
 
 int cf_solver_latency_layout(cf_ctx* ctx, int* layout) {
     if (!ctx || !layout) return fail(ctx, CF_ERR_INVALID, "cf_solver_latency_layout: bad arguments");
     const bool lean = ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
-    const bool fused_interp = net_fluxes_fused(ctx) && ctx->fused_interp != 0 && !ctx->launch.ao_wide;
-    *layout = lean && ctx->chunk_valid && lean_line_applies(ctx->launch, ctx->fast, ctx->dev.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC, fused_interp) ? 1 : 0;
+    *layout = lean && ctx->chunk_valid && lean_line_applies(ctx->launch, ctx->fast, ctx->dev.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC) ? 1 : 0;
     return CF_OK;
 }
 
 int cf_solver_path(cf_ctx* ctx, int* lean_kernel, int* fused_net) {
     if (!ctx || !lean_kernel || !fused_net) return fail(ctx, CF_ERR_INVALID, "cf_solver_path: bad arguments");
     *lean_kernel = ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
-    // 2: the interpolation is fused into the solver as well (cf_update_state without a pending prefetch)
     *fused_net = net_fluxes_fused(ctx) ? 1 : 0;
-    if (*fused_net && *lean_kernel && ctx->fused_interp != 0 && !ctx->launch.ao_wide) *fused_net = 2;
     return CF_OK;
 }
 
@@ -848,7 +826,7 @@ static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_i
     // saves the 40 B/cell re-read of the atmosphere state — ≈ 6 µs — but ties the FP64-issue-bound
     // solver to the interpolation's tile geometry and LDS footprint; measured slower, see DESIGN.md.)
     CHECK(ensure_chunk_table(ctx, ocean->mask));
-    const bool rec = ctx->prof_count < ctx->prof_capacity && (ctx->prof_calls++ % ctx->prof_stride) == 0;
+    const bool rec = ctx->prof_count < ctx->prof_capacity;
     hipEvent_t* ev = rec ? &ctx->prof_events[4 * (size_t)ctx->prof_count] : nullptr;
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
     // a prefetched atmosphere state (cf_prefetch_atmosphere_state) for exactly this step and this set of exchange
@@ -864,22 +842,18 @@ static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_i
     // Fused forms.  Net fluxes: the cell-local part of compute_net_ocean_fluxes! (everything but the two face stresses,
     // which need the west / south neighbour's ρτ) is computed in the solver's epilogue from registers, and a thin stress
     // kernel follows — bitwise the same numbers as the three-launch sequence (shared arithmetic, contraction off).
-    // Interpolation: the round-3 ocean kernel computes a batch's exchange fields in its prologue (the same per-cell
-    // routine as the stand-alone kernels: same bits) — update_state! is then two launches.
     const bool fuse = net_fluxes_fused(ctx);
-    const bool fuse_interp = fuse && !prefetched && ctx->fused_interp != 0 && !ctx->launch.ao_wide &&
-                             ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
-    if (!prefetched && !fuse_interp) HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
+    if (!prefetched) HIP_TRY(ctx, launch_interpolate(ctx->stream, ctx->launch, ctx->grid, src, w, atmos));
     if (rec) HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     CHECK(wait_for_halos(ctx));  // the interpolation above overlapped the halo rows
     // CF_OPT_MERGED_PREFETCH = 2: a requested next-step interpolation becomes the TAIL workgroups of this solver launch
     const bool tail_lean = ctx->launch.d_lean_info && ctx->fast.specialization == SOLVER_OCEAN_LEAN && ctx->launch.solver == CF_SOLVER_TABLES;
     const bool tail_ly = ctx->fast.specialization == SOLVER_LY && ctx->launch.solver == CF_SOLVER_TABLES;
-    const bool tail = fuse && !fuse_interp && !hold_tail_work && ctx->merged_prefetch == 2 && ctx->deferred.valid &&
-                      interp_tile_fits(ctx, 40960) && ctx->deferred.out.u != atmos->u && !ctx->launch.ao_wide && (tail_lean || tail_ly);
+    const bool tail = fuse && !hold_tail_work && ctx->merged_prefetch == 2 && ctx->deferred.valid &&
+                      interp_tile_fits(ctx, 40960) && ctx->deferred.out.u != atmos->u && (tail_lean || tail_ly);
     // With sea ice (cf_update_state_sea_ice): the ocean solve itself is handed to the caller, whose interface-solve launch carries
     // its workgroups behind its own (ice_ocean_kernel) — the stresses then follow that launch
-    const bool ride = hold_tail_work && ocean_rider && fuse && !fuse_interp && tail_lean && !ctx->launch.ao_wide && !rec;
+    const bool ride = hold_tail_work && ocean_rider && fuse && tail_lean && !rec;
     if (ride) {
         HIP_TRY(ctx, make_ocean_rider(ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes, ice, net, ctx->d_land_freshwater,
                                       ocean_rider));
@@ -904,8 +878,7 @@ static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_i
         CHECK(deferred_went_out_on_main(ctx));
     } else
     HIP_TRY(ctx, launch_ao_fluxes(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes,
-                                  fuse ? ice : nullptr, fuse ? net : nullptr, ctx->d_land_freshwater,
-                                  fuse_interp ? src : nullptr, fuse_interp ? w : nullptr));
+                                  fuse ? ice : nullptr, fuse ? net : nullptr, ctx->d_land_freshwater));
     // A requested next-step interpolation (cf_prefetch_atmosphere_state).  CF_OPT_MERGED_PREFETCH: it rides in THIS step's
     // face-stress launch on the main stream — two independent memory-bound kernels, one launch boundary fewer (on a
     // latitude slab a boundary is a tenth of the step).  Otherwise it goes out on the auxiliary stream right behind the
@@ -947,7 +920,7 @@ int cf_profile_enable(cf_ctx* ctx, int max_records) {
     if (!ctx || max_records < 0) return fail(ctx, CF_ERR_INVALID, "cf_profile_enable: bad arguments");
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     ctx->prof_events.clear();
-    ctx->prof_capacity = ctx->prof_count = ctx->prof_calls = 0;
+    ctx->prof_capacity = ctx->prof_count = 0;
     ctx->prof_events.resize(4 * (size_t)max_records);
     for (auto& e : ctx->prof_events) HIP_TRY(ctx, hipEventCreate(&e));
     ctx->prof_capacity = max_records;
@@ -1324,9 +1297,9 @@ int cf_update_state_sea_ice(cf_ctx* ctx, const cf_atmos_source* src, const cf_in
     if (!ctx->ice_ready) return fail(ctx, CF_ERR_INVALID, "cf_set_sea_ice_formulation has not been called");
     // CF_OPT_MERGED_PREFETCH = 2: the face stresses of this step and a requested next-step interpolation ride in the tail
     // workgroups of the interface solve — the longest launch of the step, whose workgroups retire over tens of microseconds
-    if (ocean) CHECK(ensure_chunk_table(ctx, ocean->mask));  // (ao_wide below is decided when the table is built: ADVICE r4)
+    if (ocean) CHECK(ensure_chunk_table(ctx, ocean->mask));
     const bool ice_tail = ctx->merged_prefetch == 2 && ctx->ice_loop.specialization == SOLVER_ICE &&
-                          ctx->launch.solver == CF_SOLVER_TABLES && !ctx->launch.ao_wide;
+                          ctx->launch.solver == CF_SOLVER_TABLES;
     bool stress_held = false;
     // … and the ocean solve itself: its workgroups ride behind the interface solve's (both FP64-bound and independent of each
     // other; two queues do not overlap them, one launch does — profiles/r04_experiments.md §17); the stresses, which need the

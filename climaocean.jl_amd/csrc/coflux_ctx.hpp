@@ -49,7 +49,13 @@ struct cf_ctx {
     hipStream_t stream = nullptr;
     LoopParams fast{};
     DevParams* d_params = nullptr;
-    LaunchCfg launch{CF_SOLVER_TABLES, 128, 1024, 0, 256, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0};
+    LaunchCfg launch = [] {
+        LaunchCfg L{};
+        L.solver = CF_SOLVER_TABLES;
+        L.interp_cap = 128;
+        L.cu_count = 256;
+        return L;
+    }();
     uint8_t* d_trip = nullptr;       // trip count of the previous call per wet-list entry
     uint32_t* d_wet_pos = nullptr;   // static wet lists of the solver's chunks
     uint32_t* d_lean_sorted = nullptr;  // the lean ocean kernel's sorted lists (same capacity as d_wet_pos)
@@ -58,7 +64,6 @@ struct cf_ctx {
     bool lean_hints = false;         // the lean ocean kernel sorts its lists by trip count only when CF_OPT_TRIP_HINTS = 1
     int merged_prefetch = 0;         // CF_OPT_MERGED_PREFETCH: a requested next-step interpolation rides in the face-stress launch
     double certified_budget = 8e-7;  // CF_OPT_CERTIFIED_BUDGET
-    int fused_interp = 0;            // cf_update_state: the interpolation in the lean ocean kernel's prologue (0 off: measured slower; 1 when possible)
     int fused_net = 2;               // cf_update_state: net fluxes in the solver's epilogue + a stress kernel: 0 never, 1 when possible, 2 with the lean ocean kernel
     // cost-balanced chunk table of the solver, rebuilt when the wet mask (pointer / kind / surface z) changes
     int* d_chunk_sums = nullptr;
@@ -131,7 +136,7 @@ struct cf_ctx {
     int rank = 0, nranks = 1;
     // per-kernel event recorder (cf_profile_enable): 4 events per recorded update_state
     std::vector<hipEvent_t> prof_events;
-    int prof_capacity = 0, prof_count = 0, prof_stride = 1, prof_calls = 0;
+    int prof_capacity = 0, prof_count = 0;
 };
 
 // sets the thread-local and the context's last-error text and returns `code`

@@ -367,7 +367,7 @@ struct LoopParams {
     double b_q, log_A_q, log_lm_q, log_const_q;                 // water-vapour roughness
     double b_t, log_A_t, log_lm_t, log_const_t;                 // temperature roughness
     int32_t maxiter, fixed, m_kind, q_kind, t_kind, same_scalar;
-    int32_t specialization;  // SOLVER_OCEAN / SOLVER_ICE / SOLVER_GENERIC / SOLVER_LY (host-selected)
+    int32_t specialization;  // SOLVER_OCEAN_LEAN / SOLVER_ICE / SOLVER_GENERIC / SOLVER_LY (host-selected)
     int32_t cert_max_evals;  // certified path (coflux_certified.hpp): evaluations before a lane is sent down the exact path
     // CoefficientBasedFluxes + LargeYeagerTransferCoefficients
     double ly_min_wind, ly_zeta_bound, ly_cd0, ly_cd1, ly_cd2, ly_cd3, ly_high_wind, ly_cd_high, ly_ce, ly_ch_s, ly_ch_u;
@@ -384,7 +384,7 @@ struct LoopParams {
     double cert_budget;               // flux-metric budget of the truncation certificate ÷ the safety factor
 };
 
-constexpr int SOLVER_OCEAN = 0;    // Charnock-type momentum roughness, identical Reynolds-scaled scalars, U_G,min > 0
+// (0 was SOLVER_OCEAN, round 2's body of the ocean presets' iteration: retired in round 6 with CF_SOLVER_TABLES_R2)
 constexpr int SOLVER_ICE = 1;      // constant roughness lengths, U_G,min > 0
 constexpr int SOLVER_GENERIC = 2;  // anything else (runtime kinds, u★ = 0 guards)
 constexpr int SOLVER_LY = 3;       // CoefficientBasedFluxes: Large & Yeager iteration on (Cd, Ch, Ce)
@@ -471,8 +471,8 @@ struct Scales {
     int work;  // iterations actually executed (= it unless the sea-ice orbit shortcut ended the loop): the scheduling hint
 };
 
-// The fixed point.  SPEC selects a branch-free instruction stream for the two production
-// configurations; SOLVER_GENERIC keeps every runtime switch and the u★ = 0 guards.
+// The fixed point for everything but the ocean presets (those: mo_iterate_lean, coflux_lean.hpp).  SOLVER_ICE is the
+// branch-free stream for constant roughness lengths; SOLVER_GENERIC keeps every runtime switch and the u★ = 0 guards.
 // All 64 lanes of a wave must call this together (wave64 ballot inside); `active` lanes iterate.
 template <bool COARE, int SPEC>
 __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellConsts& c, const double* tab, bool active) {
@@ -493,15 +493,6 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
             const double Jb = -us * bstar;
             const double inv_us = frcp1(us);
             double lu = 0.0;
-            LogHalf half_u, half_q;
-            if constexpr (SPEC == SOLVER_OCEAN) {
-                // the two log-table reads are started here and used behind the gustiness block, whose ≈ 40
-                // instructions cover their latency (the fence keeps the reads from being sunk next to their use)
-                lu = fmin(__builtin_fma(c.alpha_g * us, us, c.lam_nu * inv_us), L.lm_m);
-                half_u = flog_pos_begin(logt, lu);
-                half_q = flog_pos_begin(logt, lu * us * c.inv_nu_q);
-                asm volatile("" ::: "memory");
-            }
             // gustiness: U_G = max(β·cbrt(max(Jᵇ,0)·h_bl), U_G,min); the cube root only where Jᵇ > 0
             double U = c.U_calm;
             if (L.beta_gust != 0.0 && __any(Jb > 0.0)) {
@@ -511,11 +502,7 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
             }
 
             double log_lu, log_lq, log_lt;
-            if constexpr (SPEC == SOLVER_OCEAN) {
-                log_lu = flog_pos_end(half_u);
-                log_lq = fmin(__builtin_fma(-L.b_q, flog_pos_end(half_q), L.log_A_q), L.log_lm_q);
-                log_lt = log_lq;
-            } else if constexpr (SPEC == SOLVER_ICE) {
+            if constexpr (SPEC == SOLVER_ICE) {
                 lu = L.const_m;
                 log_lu = L.log_const_m;
                 log_lq = L.log_const_q;
@@ -546,43 +533,16 @@ __device__ __forceinline__ Scales mo_iterate(const LoopParams& L, const CellCons
             double Dt = L.log_h - log_lt - psi_hh;
             if constexpr (!COARE) {
                 const double zu = lu * inv_L;
-                if constexpr (SPEC == SOLVER_OCEAN) {
-                    // the roughness-length arguments are tiny after the first iterates: low-degree polynomials
-                    // (wave-uniform choice; the table path is bitwise what it always was)
-                    const double zq = fexp_tab(tab, log_lq) * inv_L;
-                    // After the first iterates the roughness-length arguments are tiny (|ζ| < 1e-3 in 99.9 % of the
-                    // cells): a PER-LANE choice between a degree-5 polynomial and the general table, so that a cell's
-                    // result never depends on which cells share its wave; a wave whose lanes all agree — four out of
-                    // five — executes only one side (the empty asm keeps the compiler from evaluating both and
-                    // selecting, which would issue the LDS reads of both sides).
-                    double2 pl;
-                    if (fabs(zu) < SMALL_Z0 && fabs(zq) < SMALL_Z0) {
-                        asm volatile("" ::: "memory");
-                        pl = psi_small_mh(tab, inv_L < 0.0, zu, zq);
-                    } else {
-                        asm volatile("" ::: "memory");
-                        // (the first iterates only: two 8-byte chains — fewer registers in flight than the paired form)
-                        pl = psi_eval_two(psi, psi_arg(zu), psi_arg(zq));
-                    }
-                    Du += pl.x;
-                    Dq += pl.y;
-                    Dt = Dq;
-                } else {
-                    Du += psi_eval(psi, 0, psi_arg(zu));
-                    const double psi_lq = psi_eval(psi, 1, psi_arg(fexp(log_lq) * inv_L));
-                    Dq += psi_lq;
-                    Dt += (L.same_scalar && SPEC != SOLVER_ICE) ? psi_lq
-                                                                : psi_eval(psi, 1, psi_arg(fexp(log_lt) * inv_L));
-                }
+                Du += psi_eval(psi, 0, psi_arg(zu));
+                const double psi_lq = psi_eval(psi, 1, psi_arg(fexp(log_lq) * inv_L));
+                Dq += psi_lq;
+                Dt += (L.same_scalar && SPEC != SOLVER_ICE) ? psi_lq : psi_eval(psi, 1, psi_arg(fexp(log_lt) * inv_L));
             }
             Du = fmax(Du, L.profile_floor);
             Dq = fmax(Dq, L.profile_floor);
             const double chi_q = L.kappa * frcp1(Dq);
-            double chi_t = chi_q;
-            if constexpr (SPEC != SOLVER_OCEAN) {
-                Dt = fmax(Dt, L.profile_floor);
-                chi_t = L.kappa * frcp1(Dt);
-            }
+            Dt = fmax(Dt, L.profile_floor);
+            const double chi_t = L.kappa * frcp1(Dt);
             const double un = L.kappa * frcp1(Du) * U, tn = chi_t * c.dtheta, qn = chi_q * c.dq;
             drift = fabs(un - us) + fabs(tn - ts) + fabs(qn - qq);
             us = un;

@@ -27,7 +27,6 @@ struct IceParams;
 struct LaunchCfg {
     int solver;              // CF_SOLVER_*
     int interp_cap;          // float2 entries per variable of a wave's LDS-staged JRA55 tile
-    int max_blocks;          // reserved (persistent-grid experiments)
     int ao_chunk;            // wet cells per solver workgroup: 256 / 512 / 768 (0 = automatic)
     int cu_count;            // compute units of the device (sizes the automatic chunk)
     const double* d_tables;  // device copy of the solver tables (coflux_tables.cpp)
@@ -36,7 +35,6 @@ struct LaunchCfg {
     const int* d_chunk_begins;  // cost-balanced chunk table of the solver (coflux_solver.hip), n_chunks + 1 entries
     int n_chunks;
     const uint32_t* d_wet_pos;  // static wet lists of the chunks, fixed stride (coflux_solver.hip), or NULL
-    int ao_wide;                // 1: the chunk table was built for the wide geometry (one 768-thread workgroup per CU)
     uint32_t* d_lean_sorted;    // the lean ocean kernel's lists: every chunk's wet cells ordered by last call's trip counts (coflux_solver_lean.hip)
     const int* d_lean_info;     // per chunk: wet cells listed, fingerprint of the wet set (x, y), 0
     int lean_hints;             // 1: the lean ocean kernel re-orders its lists by trip count at the end of every call
@@ -45,24 +43,23 @@ struct LaunchCfg {
 };
 
 // the exact path's kernels for one or two waves per SIMD (coflux_solver_slab.hip) carry this launch
-bool lean_line_applies(const LaunchCfg& L, const LoopParams& C, bool coare, bool fused_interp = false);
+bool lean_line_applies(const LaunchCfg& L, const LoopParams& C, bool coare);
 
-// CF_SOLVER_PATH_CERTIFIED runs in the lean ocean kernel's narrow geometry under the convergence stop rule, with index-ordered
-// lists and without the interpolation fused into the prologue; everywhere else the exact path runs.
-bool lean_certified_applies(const LaunchCfg& L, const LoopParams& C, bool fused_interp = false);
+// CF_SOLVER_PATH_CERTIFIED runs in the lean ocean kernel under the convergence stop rule with index-ordered lists; everywhere
+// else the exact path runs.
+bool lean_certified_applies(const LaunchCfg& L, const LoopParams& C);
 
 hipError_t launch_interpolate(hipStream_t st, const LaunchCfg& L, const GridDesc& G, const cf_atmos_source* s,
                               const cf_interp_weights* w, const cf_exchange_fields* e);
 hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
                             const cf_interface_fluxes* f, const cf_sea_ice_fields* ice = nullptr,
-                            const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr,
-                            const cf_atmos_source* src = nullptr, const cf_interp_weights* w = nullptr);
+                            const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr);
 hipError_t launch_net_stress(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                              const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* n);
-hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks, bool wide,
+hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks,
                            const int* d_begins, uint32_t* d_wet_pos, uint8_t* d_trip, int* d_scratch, int* overflow_out);
-hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32_t* d_wet_pos, const int* d_begins, uint32_t* d_sorted, int* d_info);
+hipError_t build_lean_lists(hipStream_t st, int nchunks, const uint32_t* d_wet_pos, const int* d_begins, uint32_t* d_sorted, int* d_info);
 hipError_t launch_ly_fluxes_with_tail(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
                                       const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
                                       const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land,
@@ -71,10 +68,10 @@ hipError_t launch_ly_fluxes_with_tail(hipStream_t st, const LaunchCfg& L, const 
 hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
                                  const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
                                  const cf_sea_ice_fields* ice = nullptr, const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr,
-                                 const cf_atmos_source* src = nullptr, const cf_interp_weights* w = nullptr,
+                                 const cf_atmos_source* next_src = nullptr, const cf_interp_weights* w = nullptr,
                                  const cf_exchange_fields* next_out = nullptr, int tail_rows = 0, int tail_blocks = 0, int tail_pos = -1);
 size_t wet_list_capacity(int ncells);
-int wet_list_stride(bool wide);
+int wet_list_stride();
 hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
                                  const cf_exchange_fields* e, const cf_interface_fluxes* f);
 hipError_t launch_net_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,
@@ -122,7 +119,7 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
 constexpr int AO_PLAN_TAIL = -2;
 hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
                              int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
-                             int* nchunks_out, int* wide_out);
+                             int* nchunks_out);
 int chunk_table_capacity(int ncells);
 int chunk_sums_capacity(int ncells);
 hipError_t launch_net_sea_ice_fluxes(hipStream_t st, const DevParams& P, const GridDesc& G, const void* mask,

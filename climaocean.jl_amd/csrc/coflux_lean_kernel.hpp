@@ -4,7 +4,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "coflux_interp_cell.hpp"
 #include "coflux_interp_tiles.hpp"
 #include "coflux_lean.hpp"
 #include "coflux_certified.hpp"
@@ -42,7 +41,7 @@ struct LeanArgs {
     long long sort_enabled;   // CF_OPT_TRIP_HINTS
     IceIn I;                  // fused net fluxes only
     NetOut N;
-    SourceDesc S;             // fused interpolation / tail workgroups: the JRA55 window and the weights of interpolate_atmosphere_state!
+    SourceDesc S;             // tail workgroups: the JRA55 window and the weights of interpolate_atmosphere_state!
     WeightDesc Wt;
     Exchange E_next;          // TAIL: the exchange fields of the NEXT step (another set than E)
     long long n_chunks;       // TAIL: workgroups [0, n_chunks) solve, the tail_blocks behind them interpolate
@@ -70,10 +69,11 @@ __device__ __forceinline__ unsigned lean_sum(unsigned idx) { return idx * 0xc2b2
 constexpr int LEAN_LIST_OFFSET = TABLE_BYTES;
 constexpr int LEAN_OFFSET_BITS = 24;
 constexpr unsigned LEAN_OFFSET_MASK = (1u << LEAN_OFFSET_BITS) - 1u;
-static_assert((long)AO_CHUNK_WIDE * AO_WET_COST < (1L << LEAN_OFFSET_BITS), "a chunk's range must fit the offset bits");
+static_assert((long)AO_CHUNK * AO_WET_COST < (1L << LEAN_OFFSET_BITS), "a chunk's range must fit the offset bits");
 template <int BLOCK>
 struct LeanGeom {
-    static constexpr int CHUNK = BLOCK == AO_BLOCK ? AO_CHUNK : AO_CHUNK_WIDE;
+    static_assert(BLOCK == AO_BLOCK, "one workgroup geometry: 256 threads, three workgroups per CU (the 768-thread one-per-CU geometry of rounds 2-5 measured 3 % slower and was retired in round 6)");
+    static constexpr int CHUNK = AO_CHUNK;
     static constexpr int WAVES = BLOCK / 64;
     static constexpr int HIST_OFFSET = LEAN_LIST_OFFSET + CHUNK * 4;
     static constexpr int CURSOR_OFFSET = HIST_OFFSET + AO_BINS * 4;
@@ -84,20 +84,13 @@ struct LeanGeom {
     static_assert(PARAMS_OFFSET % 16 == 0 && LEAN_LIST_OFFSET % 1024 == 0 && (CHUNK * 4) % 1024 == 0, "LDS-DMA pieces");
 };
 static_assert(LeanGeom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow lean solver workgroups must fit the CU's 160 KB of LDS");
-static_assert(LeanGeom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
 #ifndef CF_SKIP_LDS_ASSERT
 static_assert(CF_LEAN_WAVES <= 3 || LeanGeom<AO_BLOCK>::LDS_BYTES <= 40960, "four narrow lean workgroups per CU: 160 KB / 4 in 1280-byte granules");
 #endif
 
 // zero_interface_state of a land cell: all fluxes 0, T = 0 K (and, in the fused form, zero net fluxes inside the interior)
-template <bool FUSE, bool FUSE_INTERP = false>
+template <bool FUSE>
 __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_offset, const GridDesc& G, LeanArgsPtr K, size_t k, int i, int j) {
-    if constexpr (FUSE_INTERP) {  // interpolate_atmosphere_state! fills the exchange fields of land cells too
-        const SourceDesc S = kread(&K->S);
-        const WeightDesc Wt = kread(&K->Wt);
-        const Exchange E = kread(&K->E);
-        store_exchange(E, k, interp_cell(S, Wt, G, i, j, k));
-    }
     CellFluxes Z{};
     Z.Ts_ocean = -T_offset;
     Z.iterations = L.fixed ? L.maxiter : 0;
@@ -114,10 +107,8 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 // FUSE: the cell-local part of compute_net_ocean_fluxes! (everything but the two face stresses, which need the west /
 // south neighbour's ρτ: launch_net_stress) in the epilogue — the same arithmetic as net_flux_kernel, bit for bit
 // (net_cell_local, contraction off).  With batches in index order its nine extra accesses per cell are coalesced.
-// FUSE_INTERP (with FUSE): interpolate_atmosphere_state! as well — a batch computes its cells' eight exchange fields
-// from the JRA55 window in its prologue (72 gathers per cell that hit L2 and ride the vector-memory pipe the FP64-bound
-// solver leaves idle), writes them (the API's outputs) and keeps what it needs in registers; land cells get theirs with
-// their zeros.  update_state! is then two launches: this kernel and the face stresses.
+// (Rounds 3-5 also carried interpolate_atmosphere_state! in the batch prologue — CF_OPT_FUSED_INTERP, bitwise the separate
+// launch, 0.1007 vs 0.0956 ms per step: 72 scattered gathers per cell inside the FP64-bound kernel — retired in round 6.)
 // TAIL: the launch carries tail_blocks more workgroups BEHIND the solver's (dispatch follows the workgroup index, so they
 // take the slots the solver's workgroups free as they retire): they interpolate the NEXT step's atmosphere state into the
 // other set of exchange fields with the tiled routine of interpolate_kernel — memory-bound work under the solver's
@@ -133,8 +124,9 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 #endif
 // LINE: the iteration in its one-wave-per-SIMD layout (mo_iterate_lean_line; coflux_solver_slab.hip builds those kernels
 // through tools/gcn_sched.py); bitwise the same results.
-template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false, bool CERT = false, bool LINE = false>
+template <bool COARE, bool FUSE, bool TAIL = false, bool CERT = false, bool LINE = false>
 __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
+    constexpr int BLOCK = AO_BLOCK;
     using Geo = LeanGeom<BLOCK>;
     constexpr int CHUNK = Geo::CHUNK;
     LeanArgsPtr K = opaque(K_in);
@@ -285,7 +277,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             hx ^= lean_mix((unsigned)idx);
             hy += lean_sum((unsigned)idx);
         } else {
-            lean_zero_cell<FUSE, FUSE_INTERP>(L, T_offset, G, opaque(K), k, idx - jj * wx - G.ring, jj - G.ring);
+            lean_zero_cell<FUSE>(L, T_offset, G, opaque(K), k, idx - jj * wx - G.ring, jj - G.ring);
         }
     }
     for (int d = 32; d; d >>= 1) {
@@ -322,7 +314,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                 const int idx = range_begin + tid + n * BLOCK;
                 const int jj = row_of(idx, wx, wx_rcp);
                 const int i = idx - jj * wx - G.ring, j = jj - G.ring;
-                lean_zero_cell<FUSE, FUSE_INTERP>(L, T_offset, G, Kz, cell_index(G, i, j), i, j);
+                lean_zero_cell<FUSE>(L, T_offset, G, Kz, cell_index(G, i, j), i, j);
             }
     }
     int begin = range_begin, end = range_end;
@@ -337,7 +329,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                     const int i = idx - jj * wx - G.ring, j = jj - G.ring;
                     const size_t k = cell_index(G, i, j);
                     wet = cell_is_wet(P, mask, k);
-                    if (!wet) lean_zero_cell<FUSE, FUSE_INTERP>(L, T_offset, G, opaque(K), k, i, j);
+                    if (!wet) lean_zero_cell<FUSE>(L, T_offset, G, opaque(K), k, i, j);
                 }
                 const unsigned long long m = __ballot(wet);
                 int wave_base = 0;
@@ -395,7 +387,6 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
         };
         struct Raw {
             double ua, va, Ta, pa, qa, u0, u1, v0, v1, To, So;
-            double Qs, Ql, Mp;  // FUSE_INTERP: kept for the net-flux epilogue
         };
         auto request = [&](int st) {
             int ci, cj;
@@ -411,27 +402,11 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             r.v1 = gload(Ov, k8 + (unsigned)G.sj * 8u);
             r.To = gload(Kb->O.T, k8);
             r.So = gload(Kb->O.S, k8);
-            if constexpr (FUSE_INTERP) {
-                const SourceDesc S = kread(&Kb->S);
-                const WeightDesc Wt = kread(&Kb->Wt);
-                const ExchangeCell e = interp_cell(S, Wt, G, ci, cj, k);
-                if (st + lane < limit) store_exchange(kread(&Kb->E), k, e);
-                r.ua = e.u;
-                r.va = e.v;
-                r.Ta = e.T;
-                r.pa = e.p;
-                r.qa = e.q;
-                r.Qs = e.Qs;
-                r.Ql = e.Ql;
-                r.Mp = e.Mp;
-            } else {
-                r.ua = gload(Kb->E.u, k8);
-                r.va = gload(Kb->E.v, k8);
-                r.Ta = gload(Kb->E.T, k8);
-                r.pa = gload(Kb->E.p, k8);
-                r.qa = gload(Kb->E.q, k8);
-                r.Qs = r.Ql = r.Mp = 0.0;
-            }
+            r.ua = gload(Kb->E.u, k8);
+            r.va = gload(Kb->E.v, k8);
+            r.Ta = gload(Kb->E.T, k8);
+            r.pa = gload(Kb->E.p, k8);
+            r.qa = gload(Kb->E.q, k8);
             return r;
         };
         int start = claim();
@@ -467,14 +442,13 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             double Mp_now = 0.0;
             const double raw_So = raw.So;
             if constexpr (CERT && CF_CERT_NET_SALT) {
-                if (!straggling) Mp_now = FUSE_INTERP ? raw.Mp : gload(opaque(K)->E.Mp, (unsigned)cell_of(start) * 8u);
+                if (!straggling) Mp_now = gload(opaque(K)->E.Mp, (unsigned)cell_of(start) * 8u);
             }
             // ℑxᶜᵃᵃ u, ℑyᵃᶜᵃ v: cell-centre ocean velocity from the two bracketing faces
             const LeanCell c = lean_prologue(P, L.kappa, tab, raw.ua, raw.va, raw.Ta, raw.pa, raw.qa, 0.5 * (raw.u0 + raw.u1),
                                              0.5 * (raw.v0 + raw.v1), raw.To, raw.So);
             // the interface temperature does not depend on the iteration: written now, not carried across it
             if (in_range) gstore(opaque(K)->F.Ts, (unsigned)cell_of(start) * 8u, c.Ts - T_offset);
-            const double Qs_kept = raw.Qs, Ql_kept = raw.Ql, Mp_kept = raw.Mp;  // (dead unless FUSE_INTERP)
             CertNetSalt net_salt;
             if constexpr (CERT && CF_CERT_NET_SALT) {
                 // J_S is assembled from the vapour flux (by this launch's epilogue or by net_cell_kernel): the certificate is
@@ -567,8 +541,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                         const NetOut N = kread(&Ke->N);
                         const double Ts_ocean = (gload(Ke->O.T, k8) + P.T_offset) - T_offset;  // what F.Ts holds (written before the iteration)
                         const NetCell C = net_cell_local(P, P.albedo, I.conc ? gload(I.conc, k8) : 0.0, gload(Ke->O.S, k8), Ts_ocean + P.T_offset,
-                                                         FUSE_INTERP ? Mp_kept : gload(Ke->E.Mp, k8), FUSE_INTERP ? Qs_kept : gload(Ke->E.Qs, k8),
-                                                         FUSE_INTERP ? Ql_kept : gload(Ke->E.Ql, k8), R.Qc, R.Qv, R.Fv,
+                                                         gload(Ke->E.Mp, k8), gload(Ke->E.Qs, k8), gload(Ke->E.Ql, k8), R.Qc, R.Qv, R.Fv,
                                                          I.Qio ? gload(I.Qio, k8) : 0.0, I.Jsio ? gload(I.Jsio, k8) : 0.0,
                                                          I.land ? gload(I.land, k8) : 0.0);
                         gstore(N.T, k8, C.JT);  // (store_net_cell's fields, by offset)

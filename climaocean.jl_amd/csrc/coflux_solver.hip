@@ -22,19 +22,19 @@ namespace coflux {
 #define CF_LEAN_WAVES 3  // waves per SIMD the lean ocean solver is compiled for
 #endif
 
-// Two workgroup geometries.  NARROW: 256 threads, three workgroups per CU (each with its own copy of the tables),
-// chunks of ≤ 1280 wet cells in arrival layers — the only choice for a surface too small to give every CU a big chunk.
-// WIDE (CF_OPT_AO_CHUNK = 3072; measured 3 % slower, see build_chunk_table): 768 threads, ONE workgroup per CU: twelve
-// waves of the same age pull batches from both ends of one queue, one copy of the tables per CU, ≈ 100 KB of LDS free.
-int wet_list_stride(bool wide);
+// One workgroup geometry: 256 threads, three workgroups per CU (each with its own copy of the tables), chunks of ≤ 1280 wet
+// cells in arrival layers.  (Rounds 2-5 also shipped a 768-thread one-workgroup-per-CU geometry, CF_OPT_AO_CHUNK = 3072:
+// twelve waves of one age do not stagger themselves as three workgroups of different age do — 3 % slower on the 1/4°
+// surface, bitwise the same results; retired in round 6.)
+int wet_list_stride();
 template <int BLOCK>
 struct Geom {
-    static constexpr int CHUNK = BLOCK == AO_BLOCK ? AO_CHUNK : AO_CHUNK_WIDE;
+    static_assert(BLOCK == AO_BLOCK, "one workgroup geometry");
+    static constexpr int CHUNK = AO_CHUNK;
     static constexpr int COUNTERS_OFFSET = TABLE_DOUBLES * 8 + CHUNK * 4;
     static constexpr int PARAMS_OFFSET = COUNTERS_OFFSET + 16 + 2 * 64 * 4;
     static constexpr int LDS_BYTES = PARAMS_OFFSET + (int)sizeof(DevParams);
 };
-static_assert(Geom<AO_BLOCK_WIDE>::LDS_BYTES <= 65536, "the wide workgroup's LDS");
 constexpr int AO_LAYER_1 = AO_CHUNK < 1024 ? AO_CHUNK : 1024, AO_LAYER_2 = AO_CHUNK < 768 ? AO_CHUNK : 768, AO_LAYER_3 = 512;  // wet cells per chunk of the last three arrival layers (plan_chunk_rounds)
 static_assert(AO_LAYER_1 <= AO_CHUNK && AO_LAYER_1 >= AO_LAYER_2 && AO_LAYER_2 >= AO_LAYER_3, "layer sizes");
 static_assert(AO_BINS == 64, "Geom<>::PARAMS_OFFSET spells the bin count out");
@@ -57,7 +57,6 @@ static_assert(Geom<AO_BLOCK>::LDS_BYTES <= 53760, "three narrow solver workgroup
 // holds more wet cells than the list) when a mask changed in place — a stale table can cost time, never correctness.
 // ---------------------------------------------------------------------------------------------
 constexpr int AO_MAX_ROUNDS = 8;
-constexpr int AO_PLAN_WIDE = -1;  // plan_chunk_rounds: the wide geometry's plan
 struct ChunkRounds {  // round r covers cost prefixes [base[r], base[r+1]) in chunks of cost[r], ids from first[r]
     int n;
     int base[AO_MAX_ROUNDS + 1];
@@ -186,15 +185,7 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
     const long need = total > 0 ? total : 1;
     const bool tail_plan = forced_wet_per_chunk == AO_PLAN_TAIL;
     if (tail_plan) forced_wet_per_chunk = 0;
-    if (forced_wet_per_chunk == AO_PLAN_WIDE) {
-        // one workgroup per CU and round: chunks of equal cost, whole batches, as few rounds as the list capacity allows
-        const long per_round = cap(AO_CHUNK_WIDE);
-        const long rounds = (need + per_round - 1) / per_round;
-        const long want = (need + layer * rounds - 1) / (layer * rounds);                  // cost per chunk
-        int w = (int)((want + 64L * AO_WET_COST - 1) / (64L * AO_WET_COST)) * 64;          // … in whole batches of wet cells
-        w = w < 256 ? 256 : w;  // (the chunk table's capacity is sized for chunks of at least 256 wet cells)
-        add_round(w, chunks(need, w), true);
-    } else if (forced_wet_per_chunk > 0) {
+    if (forced_wet_per_chunk > 0) {
         add_round(forced_wet_per_chunk, chunks(need, forced_wet_per_chunk), true);  // forced uniform size
     } else if (need <= 3 * cap(256)) {
         // small surface (a slab of a strongly scaled run): every chunk resident at once, one batch per wave — the
@@ -262,7 +253,7 @@ int plan_chunk_rounds(long total, int cu_count, int forced_wet_per_chunk, ChunkR
 
 hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int cu_count,
                              int wet_per_chunk, int* d_sums, int* d_begins, int* d_meta, int* wet_per_chunk_out,
-                             int* nchunks_out, int* wide_out) {
+                             int* nchunks_out) {
     const int ncells = (G.nx + 2 * G.ring) * (G.ny + 2 * G.ring);
     const int nblocks = (ncells + CT_CELLS - 1) / CT_CELLS;
     hipLaunchKernelGGL(chunk_block_costs_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums);
@@ -272,15 +263,8 @@ hipError_t build_chunk_table(hipStream_t st, const DevParams* d_params, const Gr
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
     ChunkRounds R{};
-    // Geometry: narrow workgroups in arrival layers unless CF_OPT_AO_CHUNK = 3072 asks for the wide one (one 768-thread
-    // workgroup per CU).  Measured on the 1/4° surface the wide geometry loses 3 % (0.1232 vs 0.1196 ms per step on the
-    // same box; kernel 77.1 vs 75.4 µs on identical inputs) even with its batch queue served from both ends: three
-    // workgroups of different age on a CU stagger themselves — the oldest iterates while the youngest loads — and
-    // twelve waves of one age do not.  It stays as an option because it leaves ≈ 100 KB of the CU's LDS unused.
-    const bool wide = wet_per_chunk == AO_CHUNK_WIDE;
-    const int largest = plan_chunk_rounds(total, cu_count, wide ? AO_PLAN_WIDE : wet_per_chunk, &R);  // (AO_PLAN_TAIL passes through)
+    const int largest = plan_chunk_rounds(total, cu_count, wet_per_chunk, &R);  // (AO_PLAN_TAIL passes through)
     wet_per_chunk = largest;
-    *wide_out = wide ? 1 : 0;
     hipLaunchKernelGGL(chunk_begins_kernel, dim3(nblocks), dim3(256), 0, st, d_params, G, mask, ncells, d_sums, R, d_begins,
                        d_meta);
     int n = 0;
@@ -336,9 +320,9 @@ __global__ __launch_bounds__(256) void chunk_wet_fill_kernel(const DevParams* __
 // Chunk c's list occupies entries [c·stride, (c+1)·stride) of wet_pos / trip — a fixed stride per geometry, so the solver
 // needs no lookup before it can request its list.  *overflow_out != 0: some chunk holds more wet cells than a list
 // (cannot happen with the cost-balanced table; the solver then classifies per call).
-hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks, bool wide,
+hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const GridDesc& G, const void* mask, int nchunks,
                            const int* d_begins, uint32_t* d_wet_pos, uint8_t* d_trip, int* d_scratch, int* overflow_out) {
-    const int stride = wet_list_stride(wide);
+    const int stride = wet_list_stride();
     hipError_t e = hipMemsetAsync(d_scratch, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(chunk_wet_fill_kernel, dim3(nchunks), dim3(256), 0, st, d_params, G, mask, d_begins, d_wet_pos, d_scratch, stride);
@@ -350,8 +334,8 @@ hipError_t build_wet_lists(hipStream_t st, const DevParams* d_params, const Grid
     return hipGetLastError();
 }
 
-int wet_list_stride(bool wide) { return wide ? AO_CHUNK_WIDE : AO_CHUNK; }
-size_t wet_list_capacity(int ncells) { return (size_t)chunk_table_capacity(ncells) * AO_CHUNK; }  // (≥ any wide table's need: fewer, 2.4× longer lists)
+int wet_list_stride() { return AO_CHUNK; }
+size_t wet_list_capacity(int ncells) { return (size_t)chunk_table_capacity(ncells) * AO_CHUNK; }
 
 
 // (second launch bound = waves per SIMD: the lean ocean iteration fits 128 VGPRs — four narrow workgroups per CU, whose
@@ -677,7 +661,7 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
             if (nwet > CHUNK) {  // more wet cells than the list holds: retry on a piece that cannot overflow it
                 end = begin + CHUNK;
                 __syncthreads();
-                if (tid < 4) counters[tid] = 0;  // ([2], [3]: the wide geometry's two queue ends)
+                if (tid < 4) counters[tid] = 0;
                 __syncthreads();
                 continue;
             }
@@ -685,26 +669,9 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
         // ---- waves pull 64 wet cells at a time ---------------------------------------------------------
         for (;;) {
             int start = 0;
-            if constexpr (BLOCK == AO_BLOCK) {
-                if (lane == 0) start = atomicAdd(&counters[1], 64);
-                start = __shfl(start, 0);
-                if (start >= nwet) break;
-            } else {
-                // Twelve waves of one age: taken from one end of the (longest-first) queue they would run in lockstep —
-                // every wave loading, then every wave iterating — so of the three waves that share a SIMD (w, w+4, w+8) the
-                // middle one takes its batches from the short end.
-                // counters[1] counts claims; [2] / [3] (zero again once the list is validated) count each end's.
-                int claim = 0, mine = 0;
-                if (lane == 0) {
-                    claim = atomicAdd(&counters[1], 64);
-                    if (claim < nwet) mine = atomicAdd(&counters[2 + ((tid >> 8) & 1)], 1);
-                }
-                claim = __shfl(claim, 0);
-                mine = __shfl(mine, 0);
-                if (claim >= nwet) break;
-                const int nb = (nwet + 63) >> 6;
-                start = (((tid >> 8) & 1) ? nb - 1 - mine : mine) * 64;
-            }
+            if (lane == 0) start = atomicAdd(&counters[1], 64);
+            start = __shfl(start, 0);
+            if (start >= nwet) break;
             const int q = start + lane;
             const bool in_range = q < nwet;
             const int qc = in_range ? q : nwet - 1;
@@ -803,60 +770,7 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
                 }
                 continue;
             }
-            if constexpr (SPEC == SOLVER_OCEAN_LEAN) {
-                // ---- the round-3 path: lean prologue → lean iteration → five-number epilogue (coflux_lean.hpp) ----
-                LeanCell c;
-                double So;
-                {
-                    const int idx = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
-                    const int jj = row_of(idx, wx, wx_rcp);
-                    const size_t k = cell_index(G, idx - jj * wx - G.ring, jj - G.ring);
-                    SolverArgsPtr Kb = opaque(K);
-                    const double* __restrict__ Ou = Kb->O.u;
-                    const double* __restrict__ Ov = Kb->O.v;
-                    const double uo = 0.5 * (Ou[k] + Ou[k + 1]);
-                    const double vo = 0.5 * (Ov[k] + Ov[k + (size_t)G.sj]);
-                    So = Kb->O.S[k];
-                    c = lean_prologue(P, L.kappa, tab, Kb->E.u[k], Kb->E.v[k], Kb->E.T[k], Kb->E.p[k], Kb->E.q[k], uo, vo, Kb->O.T[k], So);
-                    // the interface temperature does not depend on the iteration: written now, not carried across it
-                    if constexpr (!FUSE_NET) {
-                        if (in_range) Kb->F.Ts[k] = c.Ts - T_offset;
-                    }
-                }
-                const Scales s = mo_iterate_lean<COARE>(L, c, tab, in_range);
-                if (in_range) {
-                    SolverArgsPtr Ke = opaque(K);
-                    const int idx2 = range_begin + (int)(list[qc] & ((1u << AO_LIST_OFFSET_BITS) - 1u));
-                    const int jj2 = row_of(idx2, wx, wx_rcp);
-                    const int ci = idx2 - jj2 * wx - G.ring, cj = jj2 - G.ring;
-                    const size_t k = cell_index(G, ci, cj);
-                    const CellFluxes R = lean_epilogue(c, T_offset, s);
-                    {
-                        const FluxOut F = kread(&Ke->F);
-                        F.Qc[k] = R.Qc;
-                        F.Qv[k] = R.Qv;
-                        F.Fv[k] = R.Fv;
-                        F.tx[k] = R.rho_tau_x;
-                        F.ty[k] = R.rho_tau_y;
-                        if constexpr (FUSE_NET) F.Ts[k] = R.Ts_ocean;
-                        if (F.ustar) F.ustar[k] = R.ustar;
-                        if (F.tstar) F.tstar[k] = R.tstar;
-                        if (F.qstar) F.qstar[k] = R.qstar;
-                        if (F.iters) F.iters[k] = R.iterations;
-                    }
-                    if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.work, 255);
-                    if constexpr (FUSE_NET) {
-                        if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {
-                            const IceIn I = kread(&Ke->I);
-                            const NetOut N = kread(&Ke->N);
-                            store_net_cell(N, k, net_cell_local(P, P.albedo, I.conc ? I.conc[k] : 0.0, So, R.Ts_ocean + P.T_offset,
-                                                                Ke->E.Mp[k], Ke->E.Qs[k], Ke->E.Ql[k], R.Qc, R.Qv, R.Fv,
-                                                                I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0, I.land ? I.land[k] : 0.0));
-                        }
-                    }
-                }
-                continue;
-            }
+            static_assert(SPEC != SOLVER_OCEAN_LEAN, "the ocean presets run in coflux_solver_lean.hip");
             CellConsts c;
             double So;
             {
@@ -907,13 +821,13 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
         begin = end;  // classification path: the rest of the range
         end = range_end;
         __syncthreads();  // list and counters are reused
-        if (tid < 4) counters[tid] = 0;  // ([2], [3]: the wide geometry's two queue ends)
+        if (tid < 4) counters[tid] = 0;
         __syncthreads();
     }
 }
 
 template <bool COARE, int SPEC, bool FUSE_NET, int BLOCK, bool TAIL = false>
-__global__ __launch_bounds__(BLOCK, (SPEC == SOLVER_OCEAN_LEAN && BLOCK == AO_BLOCK) ? CF_LEAN_WAVES : 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
+__global__ __launch_bounds__(BLOCK, 3) void ao_flux_fast_kernel(SolverArgs unused_by_name) {
     ao_flux_fast_body<COARE, SPEC, FUSE_NET, BLOCK, TAIL>((SolverArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
 }
 
@@ -953,7 +867,7 @@ __global__ __launch_bounds__(AO_BLOCK, 3) void ice_ocean_kernel(IceOceanArgs unu
         }
     }
     if (kind == 1) {
-        ao_lean_body<COARE_OCEAN, AO_BLOCK, true, false, false>((LeanArgsPtr)&K->O, idx);
+        ao_lean_body<COARE_OCEAN, true>((LeanArgsPtr)&K->O, idx);
         return;
     }
     block = kind == 2 ? nch + idx : idx;  // the interpolation's workgroups: numbered as in ao_flux_fast_kernel's tail
@@ -1002,22 +916,10 @@ static void launch_ao_spec(hipStream_t st, dim3 grid, const LaunchCfg& L, const 
     const SolverArgs A{C, G, O, E, F, L.d_tables, L.d_params, WetLists{L.d_wet_pos, C.specialization == SOLVER_LY ? nullptr : L.d_trip},
                        L.d_chunk_begins, I, N, IceStateIn{}, IceParams{},
                        z_surface, mask_kind, T_offset, row_reciprocal(G.nx + 2 * G.ring)};
-#define CF_LAUNCH(COARE_, SPEC_)                                                                                                   \
-    do {                                                                                                                          \
-        if (L.ao_wide) { /* (the fused epilogue exists in the narrow geometry only: launch_ao_fluxes refuses the combination) */ \
-            if constexpr (!FUSE)                                                                                                  \
-                hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, false, AO_BLOCK_WIDE>), grid, dim3(AO_BLOCK_WIDE),       \
-                                   Geom<AO_BLOCK_WIDE>::LDS_BYTES, st, A);                                                        \
-        } else {                                                                                                                  \
-            hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, FUSE, AO_BLOCK>), grid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, \
-                               st, A);                                                                                            \
-        }                                                                                                                         \
-    } while (0)
-    int spec = C.specialization;
-    if (spec == SOLVER_OCEAN_LEAN && L.solver == CF_SOLVER_TABLES_R2) spec = SOLVER_OCEAN;  // last round's iteration body (A/B)
-    switch (spec) {
-        case SOLVER_OCEAN_LEAN: CF_LAUNCH(COARE, SOLVER_OCEAN_LEAN); break;
-        case SOLVER_OCEAN: CF_LAUNCH(COARE, SOLVER_OCEAN); break;
+#define CF_LAUNCH(COARE_, SPEC_) \
+    hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, FUSE, AO_BLOCK>), grid, dim3(AO_BLOCK), Geom<AO_BLOCK>::LDS_BYTES, st, A)
+    // (SOLVER_OCEAN_LEAN never arrives here: launch_ao_fluxes hands it to coflux_solver_lean.hip)
+    switch (C.specialization) {
         case SOLVER_ICE: CF_LAUNCH(COARE, SOLVER_ICE); break;
         case SOLVER_LY: CF_LAUNCH(true, SOLVER_LY); break;
         default: CF_LAUNCH(COARE, SOLVER_GENERIC);
@@ -1031,7 +933,7 @@ hipError_t launch_ly_fluxes_with_tail(hipStream_t st, const LaunchCfg& L, const 
                                       const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land,
                                       const cf_atmos_source* next_src, const cf_interp_weights* w, const cf_exchange_fields* next_out,
                                       int tail_rows, int tail_blocks) {
-    if (!L.d_chunk_begins || L.n_chunks <= 0 || L.ao_wide || !net || !next_src || !w || !next_out || L.interp_cap <= 0 || tail_blocks <= 0 ||
+    if (!L.d_chunk_begins || L.n_chunks <= 0 || !net || !next_src || !w || !next_out || L.interp_cap <= 0 || tail_blocks <= 0 ||
         C.specialization != SOLVER_LY)
         return hipErrorInvalidValue;
     if ((size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double) > (size_t)Geom<AO_BLOCK>::LDS_BYTES) return hipErrorInvalidValue;
@@ -1059,12 +961,13 @@ hipError_t launch_ly_fluxes_with_tail(hipStream_t st, const LaunchCfg& L, const 
 hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C,
                             const GridDesc& G, const cf_ocean_surface* o, const cf_exchange_fields* e,
                             const cf_interface_fluxes* f, const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net,
-                            const double* land, const cf_atmos_source* src, const cf_interp_weights* w) {
+                            const double* land) {
     if (L.solver == CF_SOLVER_LIBM) return net ? hipErrorInvalidValue : launch_ao_fluxes_libm(st, P, G, o, e, f);
     // the production ocean configurations: the round-3 kernel
-    if (C.specialization == SOLVER_OCEAN_LEAN && L.solver == CF_SOLVER_TABLES && L.d_lean_info)
-        return launch_ao_fluxes_lean(st, L, P, C, G, o, e, f, ice, net, land, src, w);
-    if (src) return hipErrorInvalidValue;  // only the lean ocean kernel interpolates in its prologue
+    if (C.specialization == SOLVER_OCEAN_LEAN) {
+        if (!L.d_lean_info) return hipErrorInvalidValue;
+        return launch_ao_fluxes_lean(st, L, P, C, G, o, e, f, ice, net, land);
+    }
     OceanIn O = make_ocean(o);
     Exchange E = make_exchange(e);
     FluxOut F = make_fluxes(f);
@@ -1077,7 +980,6 @@ hipError_t launch_ao_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
                    net->downwelling_longwave, net->downwelling_shortwave};
     // one workgroup per chunk of the cost-balanced table: the hardware dispatcher is the dynamic load balancer
     if (!L.d_chunk_begins || L.n_chunks <= 0) return hipErrorInvalidValue;
-    if (net && L.ao_wide) return hipErrorInvalidValue;  // the caller keeps the three-launch sequence on wide tables
     dim3 grid(L.n_chunks);
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
     if (net) {
@@ -1121,7 +1023,7 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     if (tail) {
         // tail workgroups behind the interface solve's (lean iteration, narrow geometry): the next step's interpolation and / or
         // this step's face stresses
-        if (!lean || L.ao_wide) return hipErrorInvalidValue;
+        if (!lean) return hipErrorInvalidValue;
         A.n_chunks = L.n_chunks;
         if (tail->next_out) {
             if (!tail->next_src || !tail->w || L.interp_cap <= 0 || tail->interp_blocks <= 0 ||
@@ -1210,13 +1112,8 @@ hipError_t launch_ai_fluxes(hipStream_t st, const LaunchCfg& L, const DevParams&
     }
 #define CF_AI_LAUNCH(COARE_, SPEC_, BLOCK_) \
     hipLaunchKernelGGL((ao_flux_fast_kernel<COARE_, SPEC_, false, BLOCK_>), grid, dim3(BLOCK_), Geom<BLOCK_>::LDS_BYTES, st, A)
-    if (L.ao_wide) {
-        if (lean) { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE_LEAN, AO_BLOCK_WIDE); else CF_AI_LAUNCH(false, SOLVER_SEAICE_LEAN, AO_BLOCK_WIDE); }
-        else { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE, AO_BLOCK_WIDE); else CF_AI_LAUNCH(false, SOLVER_SEAICE, AO_BLOCK_WIDE); }
-    } else {
-        if (lean) { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE_LEAN, AO_BLOCK); else CF_AI_LAUNCH(false, SOLVER_SEAICE_LEAN, AO_BLOCK); }
-        else { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE, AO_BLOCK); else CF_AI_LAUNCH(false, SOLVER_SEAICE, AO_BLOCK); }
-    }
+    if (lean) { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE_LEAN, AO_BLOCK); else CF_AI_LAUNCH(false, SOLVER_SEAICE_LEAN, AO_BLOCK); }
+    else { if (coare) CF_AI_LAUNCH(true, SOLVER_SEAICE, AO_BLOCK); else CF_AI_LAUNCH(false, SOLVER_SEAICE, AO_BLOCK); }
 #undef CF_AI_LAUNCH
     return hipGetLastError();
 }

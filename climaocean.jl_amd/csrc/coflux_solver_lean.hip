@@ -53,9 +53,9 @@ extern "C" int cf_debug_phase_read(unsigned long long* out, int n) {
 
 namespace coflux {
 
-template <bool COARE, int BLOCK, bool FUSE, bool FUSE_INTERP = false, bool TAIL = false, bool CERT = false>
-__global__ __launch_bounds__(BLOCK, BLOCK == AO_BLOCK ? CF_LEAN_WAVES : 3) void ao_lean_kernel(LeanArgs unused_by_name) {
-    ao_lean_body<COARE, BLOCK, FUSE, FUSE_INTERP, TAIL, CERT>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
+template <bool COARE, bool FUSE, bool TAIL = false, bool CERT = false>
+__global__ __launch_bounds__(AO_BLOCK, CF_LEAN_WAVES) void ao_lean_kernel(LeanArgs unused_by_name) {
+    ao_lean_body<COARE, FUSE, TAIL, CERT>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == AO_BLOCK ? CF_LEAN_WAVES : 3) void 
 // the wet count of every chunk are computed here, once per mask.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lean_list_build_kernel(const uint32_t* __restrict__ wet_pos, const int* __restrict__ begins, int stride,
-                                                              uint32_t* __restrict__ sorted, int* __restrict__ info) {  // stride: AO_CHUNK or AO_CHUNK_WIDE
+                                                              uint32_t* __restrict__ sorted, int* __restrict__ info) {  // stride: AO_CHUNK
     __shared__ unsigned sx[4], sy[4];
     __shared__ int sn[4];
     const int chunk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -99,24 +99,24 @@ __global__ __launch_bounds__(256) void lean_list_build_kernel(const uint32_t* __
     }
 }
 
-hipError_t build_lean_lists(hipStream_t st, int nchunks, bool wide, const uint32_t* d_wet_pos, const int* d_begins, uint32_t* d_sorted, int* d_info) {
-    hipLaunchKernelGGL(lean_list_build_kernel, dim3(nchunks), dim3(256), 0, st, d_wet_pos, d_begins, wide ? AO_CHUNK_WIDE : AO_CHUNK, d_sorted, d_info);
+hipError_t build_lean_lists(hipStream_t st, int nchunks, const uint32_t* d_wet_pos, const int* d_begins, uint32_t* d_sorted, int* d_info) {
+    hipLaunchKernelGGL(lean_list_build_kernel, dim3(nchunks), dim3(256), 0, st, d_wet_pos, d_begins, AO_CHUNK, d_sorted, d_info);
     return hipGetLastError();
 }
 
-bool lean_certified_applies(const LaunchCfg& L, const LoopParams& C, bool fused_interp) {
+bool lean_certified_applies(const LaunchCfg& L, const LoopParams& C) {
     // (maxiter ≥ 40: a cell is certified only where the map's spectral radius is below 0.6 — from the 1e-4 first guess the
     // reference then needs fewer than 40 trips to bring its drift under any tolerance ≥ 1e-9, i.e. it stops on the drift,
     // not on the cap, which the certificate presumes)
-    return L.certified && C.specialization == SOLVER_OCEAN_LEAN && !C.fixed && !L.ao_wide && L.lean_hints == 0 && !fused_interp &&
+    return L.certified && C.specialization == SOLVER_OCEAN_LEAN && !C.fixed && L.lean_hints == 0 &&
            C.cert_max_evals > 2 && C.tol >= 1e-9 && C.maxiter >= 40;
 }
 
-bool lean_line_applies(const LaunchCfg& L, const LoopParams& C, bool coare, bool fused_interp) {
+bool lean_line_applies(const LaunchCfg& L, const LoopParams& C, bool coare) {
     // (two workgroups of 256 VGPRs per lane fill a CU: a plan with more would run in rounds; β_gust ≠ 0 is the layout's
     // precondition — mo_iterate_lean_line —; the certified path has its own kernels)
-    if (L.latency_layout == 0 || C.specialization != SOLVER_OCEAN_LEAN || L.ao_wide || fused_interp || C.beta_gust == 0.0) return false;
-    if (lean_certified_applies(L, C, fused_interp)) return false;
+    if (L.latency_layout == 0 || C.specialization != SOLVER_OCEAN_LEAN || C.beta_gust == 0.0) return false;
+    if (lean_certified_applies(L, C)) return false;
     // automatic: where it is measured to pay — the COARE profile, whose trip is ONE basic block (1440×70: 24.3 → 22.0 µs per
     // step); with the plain logarithmic profile the slowest waves are the ones that take the general ψ at the roughness
     // lengths behind a per-lane branch, and a lone wave issues that block no faster re-ordered (27.3 µs either way,
@@ -164,7 +164,7 @@ hipError_t make_ocean_rider(const LaunchCfg& L, const DevParams& P, const LoopPa
                             const cf_exchange_fields* e, const cf_interface_fluxes* f, const cf_sea_ice_fields* ice,
                             const cf_net_ocean_fluxes* net, const double* land, OceanRider* out) {
     static_assert(sizeof(LeanArgs) <= sizeof(out->args), "OceanRider::args holds a LeanArgs");
-    if (!out || !net || L.ao_wide) return hipErrorInvalidValue;
+    if (!out || !net) return hipErrorInvalidValue;
     LeanArgs A{};
     if (hipError_t err = fill_lean_args(L, P, C, G, o, e, f, ice, net, land, A)) return err;
     memcpy(out->args, &A, sizeof(A));
@@ -177,18 +177,20 @@ hipError_t make_ocean_rider(const LaunchCfg& L, const DevParams& P, const LoopPa
 hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevParams& P, const LoopParams& C, const GridDesc& G,
                                  const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
                                  const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land,
-                                 const cf_atmos_source* src, const cf_interp_weights* w, const cf_exchange_fields* next_out,
+                                 const cf_atmos_source* next_src, const cf_interp_weights* w, const cf_exchange_fields* next_out,
                                  int tail_rows, int tail_blocks, int tail_pos) {
     LeanArgs A{};
     if (hipError_t err = fill_lean_args(L, P, C, G, o, e, f, ice, net, land, A)) return err;
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
-    const bool cert = lean_certified_applies(L, C, src != nullptr && next_out == nullptr);
-    if (next_out) {
-        // tail workgroups: `src`, `w` describe the NEXT step's interpolation into `next_out` (narrow geometry, fused net fluxes)
-        if (!net || !src || !w || L.ao_wide || L.interp_cap <= 0 || tail_blocks <= 0) return hipErrorInvalidValue;
+    const bool cert = lean_certified_applies(L, C);
+    const bool tail = next_out != nullptr;
+    int blocks = L.n_chunks;
+    if (tail) {
+        // tail workgroups: `next_src`, `w` describe the NEXT step's interpolation into `next_out` (with the fused net fluxes)
+        if (!net || !next_src || !w || L.interp_cap <= 0 || tail_blocks <= 0) return hipErrorInvalidValue;
         const size_t tile_lds = (size_t)IT_WAVES * CF_JRA55_NVARS * L.interp_cap * sizeof(double);
         if (tile_lds > (size_t)LeanGeom<AO_BLOCK>::LDS_BYTES) return hipErrorInvalidValue;
-        A.S = make_source(src);
+        A.S = make_source(next_src);
         A.Wt = make_weights(w);
         A.E_next = make_exchange(next_out);
         A.n_chunks = L.n_chunks;
@@ -196,50 +198,23 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
         A.tail_rows = tail_rows;
         A.tail_cap = L.interp_cap;
         A.tail_pos = tail_pos < 0 || tail_pos > L.n_chunks ? L.n_chunks : tail_pos;
-        if (lean_line_applies(L, C, coare)) return launch_ao_lean_line(st, coare, true, true, L.n_chunks + tail_blocks, A);
-        if (cert) {
-            if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK, true, false, true, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
-            else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK, true, false, true, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
-        } else {
-            if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK, true, false, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
-            else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK, true, false, true>), dim3(L.n_chunks + tail_blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
-        }
-        return hipGetLastError();
+        blocks += tail_blocks;
     }
-#define CF_LEAN_LAUNCH(COARE_, BLOCK_, FUSE_) \
-    hipLaunchKernelGGL((ao_lean_kernel<COARE_, BLOCK_, FUSE_>), dim3(L.n_chunks), dim3(BLOCK_), LeanGeom<BLOCK_>::LDS_BYTES, st, A)
-    if (src) {  // interpolation fused too (narrow geometry, with the fused net fluxes: launch_ao_fluxes checks)
-        if (!net || !w || L.ao_wide) return hipErrorInvalidValue;
-        A.S = make_source(src);
-        A.Wt = make_weights(w);
-        if (coare) hipLaunchKernelGGL((ao_lean_kernel<true, AO_BLOCK, true, true>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
-        else hipLaunchKernelGGL((ao_lean_kernel<false, AO_BLOCK, true, true>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
-        return hipGetLastError();
-    }
-    if (L.ao_wide) {
-        if (net) {
-            if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK_WIDE, true); else CF_LEAN_LAUNCH(false, AO_BLOCK_WIDE, true);
-        } else {
-            if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK_WIDE, false); else CF_LEAN_LAUNCH(false, AO_BLOCK_WIDE, false);
-        }
-    } else if (lean_line_applies(L, C, coare)) {
-        return launch_ao_lean_line(st, coare, net != nullptr, false, L.n_chunks, A);
-    } else if (cert) {
-#define CF_CERT_LAUNCH(COARE_, FUSE_) \
-    hipLaunchKernelGGL((ao_lean_kernel<COARE_, AO_BLOCK, FUSE_, false, false, true>), dim3(L.n_chunks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A)
-        if (net) {
-            if (coare) CF_CERT_LAUNCH(true, true); else CF_CERT_LAUNCH(false, true);
-        } else {
-            if (coare) CF_CERT_LAUNCH(true, false); else CF_CERT_LAUNCH(false, false);
-        }
-#undef CF_CERT_LAUNCH
-    } else {
-        if (net) {
-            if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK, true); else CF_LEAN_LAUNCH(false, AO_BLOCK, true);
-        } else {
-            if (coare) CF_LEAN_LAUNCH(true, AO_BLOCK, false); else CF_LEAN_LAUNCH(false, AO_BLOCK, false);
-        }
-    }
+    if (lean_line_applies(L, C, coare)) return launch_ao_lean_line(st, coare, net != nullptr, tail, blocks, A);
+#define CF_LEAN_LAUNCH(COARE_, FUSE_, TAIL_, CERT_) \
+    hipLaunchKernelGGL((ao_lean_kernel<COARE_, FUSE_, TAIL_, CERT_>), dim3(blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A)
+#define CF_LEAN_PICK(FUSE_, TAIL_)                                                       \
+    do {                                                                                 \
+        if (cert) {                                                                      \
+            if (coare) CF_LEAN_LAUNCH(true, FUSE_, TAIL_, true); else CF_LEAN_LAUNCH(false, FUSE_, TAIL_, true);   \
+        } else {                                                                         \
+            if (coare) CF_LEAN_LAUNCH(true, FUSE_, TAIL_, false); else CF_LEAN_LAUNCH(false, FUSE_, TAIL_, false); \
+        }                                                                                \
+    } while (0)
+    if (tail) CF_LEAN_PICK(true, true);
+    else if (net) CF_LEAN_PICK(true, false);
+    else CF_LEAN_PICK(false, false);
+#undef CF_LEAN_PICK
 #undef CF_LEAN_LAUNCH
     return hipGetLastError();
 }

@@ -17,8 +17,6 @@ constexpr int AO_BLOCK = 256;
 #define CF_AO_CHUNK 1280
 #endif
 constexpr int AO_CHUNK = CF_AO_CHUNK;  // capacity of a narrow workgroup's wet-cell list = the most wet cells a chunk can hold
-constexpr int AO_BLOCK_WIDE = 768;
-constexpr int AO_CHUNK_WIDE = 3072;
 constexpr int AO_BINS = 64;    // trip-count bins of the per-chunk counting sort (one wave scans them)
 constexpr int AO_WET_COST = 64;
 
@@ -37,11 +35,11 @@ __device__ __forceinline__ void zero_cell(const LoopParams& L, double T_offset, 
 
 // ---- production solver: LDS tables, one workgroup per chunk of the table above -----------------
 // LDS: tables | list (cell offset + list entry per sorted position) | counters, histogram, bin cursors | DevParams
-// A list word: the cell's offset from the start of the chunk's range (20 bits: a range costs at most AO_CHUNK_WIDE wet
+// A list word: the cell's offset from the start of the chunk's range (20 bits: a range costs at most AO_CHUNK wet
 // cells' worth of AO_WET_COST = 196 608 cells if it were all land) and its entry in the static list (12 bits).
 constexpr int AO_LIST_OFFSET_BITS = 20;
-static_assert(AO_CHUNK_WIDE <= (1 << (32 - AO_LIST_OFFSET_BITS)), "list entry index must fit the upper bits");
-static_assert((long)AO_CHUNK_WIDE * AO_WET_COST < (1L << AO_LIST_OFFSET_BITS), "a chunk's range must fit the lower bits");
+static_assert(AO_CHUNK <= (1 << (32 - AO_LIST_OFFSET_BITS)), "list entry index must fit the upper bits");
+static_assert((long)AO_CHUNK * AO_WET_COST < (1L << AO_LIST_OFFSET_BITS), "a chunk's range must fit the lower bits");
 
 struct WetLists {
     const uint32_t* pos;    // wet cells of chunk c in index order at [c·AO_CHUNK, …), 0xffffffff-padded; nullptr: classify per call

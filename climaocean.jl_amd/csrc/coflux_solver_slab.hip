@@ -29,7 +29,7 @@ namespace coflux {
 
 template <bool COARE, bool FUSE, bool TAIL>
 __global__ __launch_bounds__(AO_BLOCK, 2) void ao_lean_line_kernel(LeanArgs unused_by_name) {
-    ao_lean_body<COARE, AO_BLOCK, FUSE, false, TAIL, false, true>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
+    ao_lean_body<COARE, FUSE, TAIL, false, true>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
 }
 
 hipError_t launch_ao_lean_line(hipStream_t st, bool coare, bool fuse, bool tail, int blocks, const LeanArgs& A) {

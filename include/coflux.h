@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 2 /* 2: cf_flux_params.shear_gustiness_coefficient */
+#define CF_ABI_VERSION 3 /* 2: cf_flux_params.shear_gustiness_coefficient; 3: CF_OPT_MAX_BLOCKS, CF_OPT_PROFILE_STRIDE, CF_OPT_FUSED_INTERP,
+                          * CF_SOLVER_TABLES_R2(_OUTER) and the 768-thread geometry (CF_OPT_AO_CHUNK = 3072) retired; CF_OPT_AO_CHUNK and
+                          * CF_OPT_INTERP_TILE_CAP are experiment options (COFLUX_EXPERIMENTS=1) */
 
 /* status codes */
 #define CF_OK 0
@@ -329,12 +331,16 @@ int cf_set_flux_params(cf_ctx* ctx, const cf_flux_params* params);
 #define CF_STREAM_LEGACY ((void*)1) /* == hipStreamLegacy */
 int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 
-/* Implementation options (none of them changes what is computed beyond the stated tolerance).  */
+/* Options (cf_set_option).  None of them changes what is computed beyond the stated tolerance.  NINE are part of the drop-in
+ * surface: CF_OPT_SOLVER, _TRIP_HINTS, _FUSED_NET, _ICE_ORBIT_SHORTCUT, _MERGED_PREFETCH, _SOLVER_PATH, _CERTIFIED_BUDGET,
+ * _ICE_FREE_CELLS, _LATENCY_LAYOUT.  Two more are EXPERIMENT options, accepted only in a process started with
+ * COFLUX_EXPERIMENTS=1 (measurements, and the test-suite's schedule-invariance checks): CF_OPT_INTERP_TILE_CAP, CF_OPT_AO_CHUNK.
+ * Numbers 2, 5 and 8 were CF_OPT_MAX_BLOCKS, _PROFILE_STRIDE and _FUSED_INTERP (retired in ABI version 3: cf_set_option
+ * answers CF_ERR_INVALID).                                                                                              */
 #define CF_OPT_SOLVER 0           /* CF_SOLVER_*                                                   */
-#define CF_OPT_INTERP_TILE_CAP 1  /* source nodes per variable in a wave's LDS JRA55 tile (128; 16…224: 4 waves × 9 variables × cap × 8 B of LDS), or 0:
+#define CF_OPT_INTERP_TILE_CAP 1  /* EXPERIMENT option.  Source nodes per variable in a wave's LDS JRA55 tile (128; 16…224: 4 waves × 9 variables × cap × 8 B of LDS), or 0:
                                      the LDS-free one-cell-per-lane gather kernel (≤ 56 VGPRs: small enough to run
                                      beside the resident solver workgroups from a second stream)            */
-#define CF_OPT_MAX_BLOCKS 2       /* reserved for persistent-grid experiments (multiple of 8)        */
 #define CF_OPT_TRIP_HINTS 3       /* order each chunk's cells by the iteration count of the previous call (batches of equal trip
                                    * counts): 0 off, 1 on, 2 (default) automatic = on for the atmosphere–sea-ice solve, whose counts span
                                    * 10…100, off for the ocean solve, where with forcing that evolves from call to call the scattered
@@ -342,12 +348,9 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * 3 = as 1, but the round-3 ocean kernel sorts each QUARTER of a chunk's list separately (a batch
                                    * stays within a quarter of the chunk's cell range: 16 instead of 64 lines per access) — measured
                                    * −2 % on the solver alone, +0.5 % on the fused cf_update_state: not the default either          */
-#define CF_OPT_AO_CHUNK 4         /* wet cells per workgroup of the flux solver: 0 = automatic (arrival layers of 1024 / 768 / 512
-                                     on a surface that fills the device, 256 on a slab that does not), 256 … 1280 = that size for
-                                     every 256-thread workgroup, 3072 = the wide geometry (one 768-thread workgroup per CU;
-                                     measured 3 % slower on the 1/4° surface) */
-#define CF_OPT_PROFILE_STRIDE 5   /* cf_profile_enable: bracket only every n-th cf_update_state with events (1); the event
-                                     records between the kernels cost ≈ 4 µs of stream time each               */
+#define CF_OPT_AO_CHUNK 4         /* EXPERIMENT option.  Wet cells per workgroup of the flux solver: 0 = automatic (arrival layers of
+                                     1024 / 768 / 512 on a surface that fills the device, 256 on a slab that does not), 256 … 1280 = that
+                                     size for every workgroup.  Results do not depend on it, bit for bit (tested).               */
 #define CF_OPT_FUSED_NET 6        /* cf_update_state computes the cell-local net ocean fluxes in the solver's epilogue and follows
                                    * with a face-stress kernel instead of the three-launch sequence (bitwise the same results):
                                    * 0 never, 1 whenever the configuration allows it (constant ocean albedo), 2 (default) when the
@@ -355,12 +358,6 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * accesses per cell are coalesced: update_state 0.107 → 0.096 ms — or CoefficientBasedFluxes
                                    * (fixed trip count: index order too; 0.072 → 0.063 ms); in round 2's trip-sorted kernels
                                    * the same accesses were scattered and cost more than the net-flux kernel they save.        */
-#define CF_OPT_FUSED_INTERP 8     /* 1: cf_update_state interpolates the atmosphere state in the round-3 ocean kernel's prologue
-                                   * instead of a launch of its own (same bits: one shared per-cell routine; needs the fused net
-                                   * fluxes, no pending prefetch) — update_state! in two launches.  0 (default): measured SLOWER
-                                   * on MI355X, 0.1007 vs 0.0956 ms per step: the 72 corner gathers per cell cost the solver's
-                                   * vector-memory address path more than the tiled kernel's 18 µs (which stages them in LDS the
-                                   * solver has no room for) and push 19 registers to scratch.                                 */
 #define CF_OPT_MERGED_PREFETCH 9   /* 1: an interpolation requested ahead (cf_prefetch_atmosphere_state, cf_time_steps with pipelining) is
                                    * launched TOGETHER with the current step's face stresses — one kernel on the context's stream whose
                                    * workgroups do one or the other (same arithmetic, same bits) — instead of on the auxiliary stream: a
@@ -449,11 +446,11 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                tests hold 1e-9 on the ocean presets and 1e-8 on the sea-ice interface
                                (test_gpu_parity.py: sea_ice_fixed5), where the skin-temperature balance amplifies. */
 #define CF_SOLVER_LIBM 1    /* same iteration on ocml's libm (slow; cross-check)                     */
-#define CF_SOLVER_TABLES_R2 2 /* diagnostic, not part of the drop-in surface: CF_SOLVER_TABLES with round 2's body of the ocean iteration (A/B measurements) */
-#define CF_SOLVER_TABLES_R2_OUTER 3 /* diagnostic: round 3's iteration inside round 2's kernel structure (start-phase sort; A/B measurements) */
 int cf_set_option(cf_ctx* ctx, int option, int value);
 /* *path = CF_SOLVER_PATH_* that cf_compute_atmosphere_ocean_fluxes / cf_update_state would run with the current
- * options, flux parameters and chunk geometry (the certified path falls back to the exact one where it does not apply). */
+ * options and flux parameters (the certified path falls back to the exact one where it does not apply) — the predicate
+ * the launch itself decides on.  One launch runs the exact iteration whatever this answers: cf_update_state_sea_ice with
+ * CF_OPT_MERGED_PREFETCH = 2 carries the ocean solve in the interface solve's launch, whose rider is the exact kernel.   */
 int cf_solver_iteration_path(cf_ctx* ctx, int* path);
 /* *layout = 1 when the ocean solve's EXACT path would be carried by the kernels laid out for one or two waves per SIMD
  * (CF_OPT_LATENCY_LAYOUT; coflux_solver_slab.hip) with the current options, flux parameters and the chunk table as built
@@ -741,7 +738,7 @@ int cf_time_copy(cf_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int 
 /* Per-kernel timing INSIDE a caller's timed region: while enabled, cf_update_state brackets each of
  * its kernels with HIP events on the launch stream (no host sync).  cf_profile_read synchronises and
  * returns the average duration of `kernel` over the recorded steps.  cf_profile_enable(ctx, n)
- * (re)arms the recorder for n records; 0 disables; CF_OPT_PROFILE_STRIDE samples every k-th step.                                                 */
+ * (re)arms the recorder for n records; 0 disables.                                                 */
 #define CF_KERNEL_INTERPOLATE 0
 #define CF_KERNEL_AO_FLUXES 1
 #define CF_KERNEL_NET_FLUXES 2

@@ -1,6 +1,10 @@
 import os
 import sys
 
+# the schedule-invariance tests set the library's experiment options (CF_OPT_AO_CHUNK, CF_OPT_INTERP_TILE_CAP), which it accepts
+# only in a process started with this (include/coflux.h); no experiment knob of the environment is set by the suite
+os.environ.setdefault("COFLUX_EXPERIMENTS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "climaocean.jl_amd"), os.path.join(ROOT, "oracle"), ROOT, os.path.dirname(__file__)):
     if p not in sys.path:

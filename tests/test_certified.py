@@ -215,9 +215,10 @@ def test_certified_budget_option_and_path_query():
     assert ctx.solver_iteration_path() == abi.SOLVER_PATH_EXACT
     ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
     assert ctx.solver_iteration_path() == abi.SOLVER_PATH_CERTIFIED
-    ctx.set_option(abi.OPT_AO_CHUNK, 3072)      # the wide geometry has no certified variant: the exact path runs
+    ctx.set_option(abi.OPT_TRIP_HINTS, 1)       # trip-sorted lists have no certified variant: the exact path runs
     assert ctx.solver_iteration_path() == abi.SOLVER_PATH_EXACT
-    ctx.set_option(abi.OPT_AO_CHUNK, 0)
+    ctx.set_option(abi.OPT_TRIP_HINTS, 2)
+    assert ctx.solver_iteration_path() == abi.SOLVER_PATH_CERTIFIED
     with pytest.raises(RuntimeError):
         ctx.set_option(abi.OPT_CERTIFIED_BUDGET, 10)
     with pytest.raises(RuntimeError):

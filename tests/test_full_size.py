@@ -32,19 +32,6 @@ def test_config2_quarter_degree_full_surface_against_the_oracle(config):
                                   util.window(ref["fluxes"]["iterations"], 7, 7, 1440, 560, 1))
 
 
-def test_wide_workgroup_geometry_is_bitwise_the_layered_one_on_the_full_surface():
-    """CF_OPT_AO_CHUNK = 3072: one 768-thread workgroup per CU, twelve waves pulling batches from both ends of one queue —
-    a different schedule of the same per-cell arithmetic (measured slower, kept as an option: DESIGN §5.2)."""
-    from coflux import abi
-    params = ic.flux_params(ic.SimilarityTheoryFluxes(), ocean_surface=ic.SurfaceRadiationProperties(0.06, 1.0))
-    case = util.build_case(1440, 560, 7, 7)
-    ref = run_gpu(case, params)
-    got = run_gpu(case, params, options=((abi.OPT_AO_CHUNK, 3072),))
-    for grp in ("fluxes", "net"):
-        for k in got[grp]:
-            np.testing.assert_array_equal(got[grp][k], ref[grp][k], err_msg=f"{grp}.{k}")
-
-
 def _slab(case, j0, j1):
     """Rows [j0, j1) of a global case as a slab case whose halos are cut out of the global arrays."""
     h = case["hy"]

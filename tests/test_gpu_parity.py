@@ -207,14 +207,12 @@ def test_tripolar_like_general_weights_and_rotation(fused):
 
 
 def test_launch_geometry_does_not_change_results():
-    """Persistent-grid size, the LDS tile capacity (incl. the global-gather fallback), the solver's chunk size and its
-    workgroup geometry (3072 = one 768-thread workgroup per CU) are pure speed knobs."""
+    """The LDS tile capacity (incl. the global-gather fallback) and the solver's chunk size are pure speed knobs."""
     params = ic.flux_params()
     case = util.build_case(200, 37, 4, 4)
     ref = run_gpu(case, params, fused=True)
-    for options in (((abi.OPT_MAX_BLOCKS, 8),), ((abi.OPT_MAX_BLOCKS, 24), (abi.OPT_INTERP_TILE_CAP, 16)),
-                    ((abi.OPT_INTERP_TILE_CAP, 224),), ((abi.OPT_INTERP_TILE_CAP, 0),), ((abi.OPT_AO_CHUNK, 256),), ((abi.OPT_AO_CHUNK, 512),),
-                    ((abi.OPT_AO_CHUNK, 768),), ((abi.OPT_AO_CHUNK, 1280),), ((abi.OPT_AO_CHUNK, 3072),)):
+    for options in (((abi.OPT_INTERP_TILE_CAP, 16),), ((abi.OPT_INTERP_TILE_CAP, 224),), ((abi.OPT_INTERP_TILE_CAP, 0),),
+                    ((abi.OPT_AO_CHUNK, 256),), ((abi.OPT_AO_CHUNK, 512),), ((abi.OPT_AO_CHUNK, 768),), ((abi.OPT_AO_CHUNK, 1280),)):
         for fused in (False, True):
             got = run_gpu(case, params, fused=fused, options=options)
             for grp in ("atmos", "fluxes", "net"):
@@ -364,7 +362,7 @@ def test_trip_count_hints_only_reorder_work():
     ctx.close()
 
 
-@pytest.mark.parametrize("plan", [0, 3072])
+@pytest.mark.parametrize("plan", [0, 1280])
 def test_stale_chunk_table_costs_time_not_correctness(plan):
     """The solver's chunk table is built from the wet mask on the first call.  Rewriting the mask IN PLACE (same
     pointer) afterwards — here: almost-all-land becomes all-ocean, so ranges sized for 16× as many land cells now
@@ -373,7 +371,7 @@ def test_stale_chunk_table_costs_time_not_correctness(plan):
     params = ic.flux_params()
     case = util.build_case(300, 64, 4, 4)
     ctx = FluxContext(300, 64, 4, 4, params)
-    ctx.set_option(abi.OPT_AO_CHUNK, plan)   # 3072: the wide workgroup geometry (its two-ended batch queue restarts per piece)
+    ctx.set_option(abi.OPT_AO_CHUNK, plan)   # (1280: chunks as long as a workgroup's list — the overflow path splits its range)
     dev = ctx.to_device
     src = {k: dev(v) for k, v in case["src"].items()}
     w = {k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in case["weights"].items()}
