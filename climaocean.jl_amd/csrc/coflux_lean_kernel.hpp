@@ -429,8 +429,9 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                     filled = __shfl(filled, 0);
                     if (filled <= 0 || filled >= QUEUE_CLOSED) break;
                     limit = min(filled, QUEUE_CAP);
+                    // (acquire: pairs with the producers' release store of the entry below)
                     for (int e = lane; e < limit; e += 64)
-                        while (((volatile int*)queue)[e] < 0) __builtin_amdgcn_s_sleep(1);
+                        while (__hip_atomic_load(&queue[e], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 0) __builtin_amdgcn_s_sleep(1);
                     straggling = true;
                     start = 0;
                     raw = request(start);
@@ -488,7 +489,9 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                         if (lane == 0) slot = atomicAdd(&counters[1], __popcll(m));
                         slot = __shfl(slot, 0) + __popcll(m & ((1ull << lane) - 1ull));
                         if (exact && slot < QUEUE_CAP) {
-                            queue[slot] = q;
+                            // (release at workgroup scope: the closer's acquire load sees a written entry, whatever the compiler
+                            // would have liked to do with a plain LDS store between relaxed atomics — ADVICE r5)
+                            __hip_atomic_store(&queue[slot], q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                             exact = false;
                             finish = false;
                         }

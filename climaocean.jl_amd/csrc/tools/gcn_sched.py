@@ -773,10 +773,16 @@ def process(lines, fn_sub, must_contain, report, min_len=12, pool=None):
 
 
 def set_vgpr_count(lines, fn_sub, n):
-    """the .amdhsa_kernel block and the metadata entry of every kernel whose name contains fn_sub"""
+    """the .amdhsa_kernel block and the metadata entry of every kernel whose name contains fn_sub.
+
+    Raising next_free_vgpr / accum_offset to n hands the kernel the registers [old next_free_vgpr, n) as the rename pool.  That
+    is only sound for a kernel that uses NO accumulation registers (they would start at the old accum_offset) and NO scratch
+    (a spill slot's register may be live where the pool says free): both are checked here, per kernel, in the descriptor and
+    in the metadata, and a violation stops the build."""
     out = list(lines)
     in_desc = False
     in_meta = False
+    meta_agpr = None   # (.agpr_count precedes .name in a metadata entry: remembered until the name says whose it is)
     for i, l in enumerate(out):
         s_ = l.strip()
         if s_.startswith(".amdhsa_kernel "):
@@ -787,12 +793,17 @@ def set_vgpr_count(lines, fn_sub, n):
             out[i] = f"\t\t.amdhsa_next_free_vgpr {n}"
         elif in_desc and s_.startswith(".amdhsa_accum_offset"):
             out[i] = f"\t\t.amdhsa_accum_offset {n}"
-        if s_.startswith(".name:") or s_.startswith("- .agpr_count:"):
-            pass
+        elif in_desc and s_.startswith(".amdhsa_private_segment_fixed_size"):
+            if int(s_.split()[-1]) != 0:
+                raise SystemExit(f"gcn_sched: a kernel matching {fn_sub!r} uses scratch ({s_}): its registers cannot be renamed into a pool")
+        if s_.startswith("- .agpr_count:"):
+            meta_agpr = int(s_.split()[-1])
         if s_.startswith(".name:"):
             in_meta = fn_sub in s_
-        if s_.startswith(".symbol:"):
-            in_meta_sym = fn_sub in s_
+            if in_meta and meta_agpr not in (None, 0):
+                raise SystemExit(f"gcn_sched: kernel {s_.split()[-1]} uses {meta_agpr} AGPRs: raising accum_offset to {n} would move them")
+        if in_meta and s_.startswith(".private_segment_fixed_size:") and int(s_.split()[-1]) != 0:
+            raise SystemExit(f"gcn_sched: a kernel matching {fn_sub!r} uses scratch ({s_})")
         if s_.startswith(".vgpr_count:"):
             # metadata entries list .name before .vgpr_count (alphabetical keys: .name < .vgpr_count)
             if in_meta:
