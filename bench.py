@@ -88,6 +88,20 @@ def parse():
                          "fallback, include/coflux.h).  auto at N = 1 also times the certified path beside it, interleaved, and "
                          "reports it as `value_certified` with its parity against the CPU oracle — never as `value`.  At N > 1 "
                          "only the named path runs, so a SCALE series is one algorithm at every N")
+    ap.add_argument("--days", type=float, default=None,
+                    help="LONG RUN instead of the throughput line: this many simulated days of the flux path at --dt seconds per step "
+                         "(BASELINE configs[3]/[4]: --grid tripolar --nx 2160 --ny 1080 --days 30 --dt 300 is sixth_degree_tripolar_ocean_sea_ice.jl:52's "
+                         "8 640 steps; --nx 360 --ny 180 --dt 1200 is one_degree_tripolar_ocean_sea_ice.jl:47).  cf_time_steps runs one "
+                         "3-hourly snapshot interval per call through a RepeatYearJRA55-style record of --record-snapshots snapshots held in host "
+                         "memory, a --window-slots sliding window in HBM (cf_window_*) and --ocean-states surface states; every --check-every'th "
+                         "step is compared with the CPU oracle at 1e-9, and the fields at those steps are hashed and compared with an un-pipelined "
+                         "host-driven loop over the same steps.  Prints one JSON line: flux-path seconds per simulated day and the flux-only SYPD ceiling")
+    ap.add_argument("--dt", type=float, default=300.0, help="--days: coupled time step in seconds (3 h must be a whole number of steps)")
+    ap.add_argument("--record-snapshots", type=int, default=16, help="--days: 3-hourly snapshots in the repeat-year record (16 = two days: a 30-day run wraps it 15 times)")
+    ap.add_argument("--window-slots", type=int, default=4, help="--days: time_indices_in_memory of the sliding window (>= 4: three resident + one being refilled)")
+    ap.add_argument("--ocean-states", type=int, default=4, help="--days: distinct ocean surface states the steps cycle through")
+    ap.add_argument("--check-every", type=int, default=720, help="--days: compare with the CPU oracle every this many steps (a whole number of snapshot intervals)")
+    ap.add_argument("--no-host-loop", action="store_true", help="--days: skip the un-pipelined host-driven loop (its hashes are then not compared)")
     ap.add_argument("--selftest", action="store_true",
                     help="no timing: verify the halo backends, run 10 steps, gather the surface on rank 0 and compare it with the "
                          "CPU oracle; prints one JSON line, exits non-zero naming the failing stage")
@@ -203,6 +217,152 @@ def measured_parity(ctx, ref, dev_case, nx, ny, h, shares=None):
     return out
 
 
+def long_run(a, ctx, params, nx, ny, h, tripolar, ocean_np, w_np, states, w, atmos_sets, fl, net, pipeline, mode):
+    """--days: `days` simulated days of time_step!'s flux path on one GPU (see the option's help).  The loop a host-language driver
+    would write around the C ABI: per 3-hourly snapshot interval, make the window hold snapshots k, k+1 (this interval) and k+2 (the
+    request the pipelined loop's last step makes for the next interval's first step), then ONE cf_time_steps call for the interval's
+    steps.  Nothing synchronises with the host except the pinned staging buffers' reuse and the check steps."""
+    import hashlib
+    import numpy as np
+    import torch
+    from coflux import abi, synthetic as syn
+    from coflux.runtime import EXCHANGE_NAMES, FLUX_NAMES, NET_NAMES, SnapshotWindow
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+
+    spi = SNAPSHOT_INTERVAL / a.dt
+    if abs(spi - round(spi)) > 1e-9 or spi < 1:
+        raise SystemExit(f"bench.py --days: the 3-hourly snapshot interval must be a whole number of steps (--dt {a.dt})")
+    spi = int(round(spi))
+    n_steps = int(round(a.days * 86400.0 / a.dt))
+    n_intervals = (n_steps + spi - 1) // spi
+    n_steps = n_intervals * spi                     # whole intervals
+    if a.check_every % spi or a.check_every <= 0:
+        raise SystemExit(f"bench.py --days: --check-every must be a whole number of snapshot intervals ({spi} steps)")
+    R, slots, n_states = a.record_snapshots, a.window_slots, len(states)
+    if slots < 4 or R < 2:
+        raise SystemExit("bench.py --days: --window-slots >= 4 and --record-snapshots >= 2")
+    inc = a.dt / SNAPSHOT_INTERVAL
+    record = syn.jra55_snapshots(R, temporal_correlation=0.95)   # the repeat-year record, in host memory: snapshot counter k is record[k mod R]
+    g = orc.make_grid(nx, ny, h, h, 1)
+    W1 = (slice(h - 1, h + ny + 1), slice(h - 1, h + nx + 1))
+    W0 = (slice(h, h + ny), slice(h, h + nx))
+    fold_args = ([abi.FOLD_CENTER, abi.FOLD_CENTER, abi.FOLD_X_FACE, abi.FOLD_Y_FACE], [1.0, 1.0, -1.0, -1.0])
+
+    def clock(step):
+        """(snapshot counter, time fraction) of a step — the arithmetic of cf_time_steps::source_at, in the same order"""
+        total = 0.0 + float(step) * inc
+        whole = int(np.floor(total))
+        return whole, total - whole
+
+    def new_window():
+        win = SnapshotWindow(ctx, syn.JRA55_NX, syn.JRA55_NY, slots)
+        return win
+
+    def ensure(win, k):
+        if win.find(k) >= 0:
+            return
+        slot = k % slots
+        win.wait_slot(slot)
+        for v in abi.JRA55_VARIABLES:
+            np.copyto(win.host_view(slot, v), record[v][k % R])
+        win.commit(slot, k)
+
+    def digest(fields_f, fields_n):
+        hh = hashlib.sha256()
+        for k in FLUX_NAMES:
+            hh.update(fields_f[k].cpu().numpy().tobytes())
+        for k in fields_n:
+            hh.update(fields_n[k].cpu().numpy().tobytes())
+        return hh.hexdigest()[:16]
+
+    def check_against_oracle(step, fields_f, fields_n):
+        k, frac = clock(step)
+        atm = orc.interpolate_atmosphere_state(g, record, w_np, k % R, (k + 1) % R, frac)
+        st = ocean_np[step % n_states]
+        ref_f = orc.compute_atmosphere_ocean_fluxes(g, params, st, atm, nthreads=min(32, orc.max_threads()), scales=False)
+        ref_n = orc.compute_net_ocean_fluxes(g, params, st, atm, ref_f, weights=w_np)
+        worst = 0.0
+        for name, got, want, Wn in [(k_, fields_f[k_], ref_f[k_], W1) for k_ in FLUX_NAMES] + [(k_, fields_n[k_], ref_n[k_], W0) for k_ in fields_n]:
+            gg, rr = got.cpu().numpy()[Wn], want[Wn]
+            worst = max(worst, float(np.max(np.abs(gg - rr) / np.maximum(np.abs(rr), PARITY_SCALE[name]))))
+        return worst
+
+    # ---- pass 1: the C step loop, pipelined (the next step's interpolation in the solver launch's tail workgroups) ------------------
+    win = new_window()
+    sched = ctx.make_schedule(states, atmos_sets, first_level=0, time_fraction=0.0, time_fraction_increment=inc,
+                              pipeline=abi.PIPELINE_CONTINUING if pipeline else 0, fold_north=tripolar)
+    checks, wall, t_group = [], 0.0, None
+    per_interval = []
+    for k in range(n_intervals):
+        if t_group is None:
+            ctx.sync()
+            t_group = time.perf_counter()
+        for kk in (k, k + 1, k + 2):
+            ensure(win, kk)
+        src_struct = win.source(k, k + 1, 0.0)        # (orders the stream behind the uploads of the slots this interval reads …
+        win.source(k + 1, k + 2, 0.0)                 #  … and of the one its last step's request reads)
+        ctx.time_steps(k * spi, spi, sched, src_struct, w, fl, net)
+        last = (k + 1) * spi - 1
+        if (last + 1) % a.check_every == 0 or k == n_intervals - 1:
+            ctx.sync()
+            dt_group = time.perf_counter() - t_group
+            wall += dt_group
+            t_group = None
+            checks.append(dict(step=last, worst_scaled_error_vs_oracle=check_against_oracle(last, fl, net), sha256=digest(fl, net)))
+    win.close()
+    ctx.discard_prefetched_atmosphere_state()
+
+    # ---- pass 2: the same steps as an un-pipelined host-driven loop (three launches per step, one exchange set) ---------------------
+    host = None
+    if not a.no_host_loop:
+        ctx.set_option(abi.OPT_MERGED_PREFETCH, 0)
+        win = new_window()
+        fl2, net2 = ctx.field_set(FLUX_NAMES), ctx.field_set(tuple(net))
+        one = ctx.field_set(EXCHANGE_NAMES)
+        host, t0 = [], time.perf_counter()
+        want_steps = {c["step"] for c in checks}
+        for step in range(n_steps):
+            k, frac = clock(step)
+            ensure(win, k)
+            ensure(win, k + 1)
+            st = states[step % n_states]
+            if tripolar:
+                ctx.fold_north_halo([st[f] for f in ("T", "S", "u", "v")], *fold_args, rows=2)
+            ctx.update_state(win.source(k, k + 1, frac), w, st, one, fl2, net2)
+            if step in want_steps:
+                ctx.sync()
+                host.append(dict(step=step, sha256=digest(fl2, net2)))
+        ctx.sync()
+        host_wall = time.perf_counter() - t0
+        win.close()
+
+    sim_days = n_steps * a.dt / 86400.0
+    sec_per_day = wall / sim_days
+    worst = max(c["worst_scaled_error_vs_oracle"] for c in checks)
+    same = None if host is None else all(hc["sha256"] == c["sha256"] for hc, c in zip(host, checks)) and len(host) == len(checks)
+    grid_name = f"TripolarGrid surface {nx}x{ny} (synthetic mesh with the real fold)" if tripolar else f"LatitudeLongitudeGrid surface {nx}x{ny}"
+    return dict(metric="flux-path wall seconds per simulated day (time_step!'s update_state!: JRA55 interp + similarity-theory fluxes + net fluxes)",
+                value=sec_per_day, unit="s per simulated day", higher_is_better=False, n_gpus=1, steps=n_steps, warmup=0,
+                ms_per_step=wall / n_steps * 1e3, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+                config=dict(workload=f"{grid_name}, {sim_days:g} simulated days at dt = {a.dt:g} s ({n_steps} steps of cf_time_steps, one call per "
+                                     f"3-hourly snapshot interval = {spi} steps), RepeatYearJRA55-style record of {R} snapshots in host memory "
+                                     f"(wrapped {n_intervals / R:.1f} times) through a {slots}-slot window in HBM (cf_window_*; every slot rewritten "
+                                     f"{n_intervals / slots:.0f} times), {n_states} ocean surface states in turn, "
+                                     f"SimilarityTheoryFluxes(:{a.flux_configuration}) + Radiation, halo {h}, ring 1",
+                            pipeline_mode=mode, solver_path="exact", cells=nx * ny),
+                simulated_days=sim_days, wall_seconds=wall, cells_per_s=nx * ny * n_steps / wall,
+                flux_only_sypd_ceiling=86400.0 / sec_per_day / 365.0,
+                sypd_note="simulated years per wall day if NOTHING but this path ran: the ceiling the flux path alone puts on the coupled model's "
+                          "SYPD (the ocean dynamical core, which sets the real figure, is out of scope: DESIGN.md section 1)",
+                checks=checks, checks_every_steps=a.check_every, worst_scaled_error_vs_oracle=worst, tolerance=1e-9,
+                parity_ok=bool(worst <= 1e-9),
+                host_loop=(None if host is None else dict(kind="un-pipelined: cf_update_state per step from the host, one exchange set, CF_OPT_MERGED_PREFETCH = 0",
+                                                          wall_seconds=host_wall, ms_per_step=host_wall / n_steps * 1e3, hashes_equal_at_every_check=same,
+                                                          checks=host)),
+                parity="vs reference: unpinned (the oracle is a restatement; see DESIGN.md)")
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -266,27 +426,32 @@ def main():
     if tripolar and a.scaling != "strong":
         raise SystemExit("bench.py: --grid tripolar shards ONE folded surface (strong scaling)")
 
-    def make_case(r0, r1):
-        """The two ocean states (one step apart) and the interpolation weights of rows [r0, r1) of the global surface:
+    def make_case(r0, r1, n_states=2):
+        """`n_states` ocean states (one step apart each) and the interpolation weights of rows [r0, r1) of the global surface:
         every field is a function of the GLOBAL cell index, so slabs and the whole surface agree where they overlap."""
         rows = r1 - r0
         if tripolar:
             tc = syn.tripolar_case(nx, ny_global, h, h, j0=r0, j1=r1)
-            first = dict(tc["ocean"])
-            evolved = syn.evolved_ocean_state(syn.ocean_state(nx, ny_global, h, h, latitude=(-80.0, 90.0)), nx, ny_global, h, h, 1)
-            second = {}
-            for k in ("T", "S", "u", "v"):          # the second state folds like the first
-                gfull = evolved[k].copy()
-                syn.fold_north(gfull, nx, ny_global, h, h, 2, syn.FOLD_LOCATION[k], syn.FOLD_SIGN[k])
-                second[k] = np.ascontiguousarray(gfull[r0:r1 + 2 * h])
-            second["mask"] = tc["ocean"]["mask"]
-            return [first, second], tc["weights"]
+            out = [dict(tc["ocean"])]
+            base = syn.ocean_state(nx, ny_global, h, h, latitude=(-80.0, 90.0))
+            for n in range(1, n_states):
+                evolved = syn.evolved_ocean_state(base, nx, ny_global, h, h, n)
+                nxt = {}
+                for k in ("T", "S", "u", "v"):          # the later states fold like the first
+                    gfull = evolved[k].copy()
+                    syn.fold_north(gfull, nx, ny_global, h, h, 2, syn.FOLD_LOCATION[k], syn.FOLD_SIGN[k])
+                    nxt[k] = np.ascontiguousarray(gfull[r0:r1 + 2 * h])
+                nxt["mask"] = tc["ocean"]["mask"]
+                out.append(nxt)
+            return out, tc["weights"]
         first = syn.ocean_state(nx, rows, h, h, ny_global=ny_global, j_offset=r0)
-        second = syn.evolved_ocean_state(first, nx, rows, h, h, 1, ny_global=ny_global, j_offset=r0)
+        out = [first] + [syn.evolved_ocean_state(first, nx, rows, h, h, n, ny_global=ny_global, j_offset=r0) for n in range(1, n_states)]
         fi, fj, phi = syn.latlon_fractional_indices(nx, rows, h, h, ny_global=ny_global, j_offset=r0)
-        return [first, second], dict(separable=True, fi=fi, fj=fj, latitude=phi)
+        return out, dict(separable=True, fi=fi, fj=fj, latitude=phi)
 
-    ocean_np, w_np = make_case(j0, j1)
+    if a.days is not None and (world != 1 or a.config != "ocean"):
+        raise SystemExit("bench.py --days: the long run is a one-GPU, ocean-only (configs without prognostic sea ice) measurement")
+    ocean_np, w_np = make_case(j0, j1, max(2, a.ocean_states) if a.days is not None else 2)
 
     ctx = FluxContext(nx, ny, h, h, params, ring=1, device=local_rank)
     if a.trip_hints != 2:
@@ -300,7 +465,8 @@ def main():
         ctx.set_option(abi.OPT_SOLVER_PATH, abi.SOLVER_PATH_CERTIFIED)
     ring_rows = ctx.grid.ring + 1
     states = [{k: ctx.to_device(o[k]) for k in ("T", "S", "u", "v", "mask")} for o in ocean_np]
-    states[1]["mask"] = states[0]["mask"]   # one static wet mask (the solver's chunk table is keyed on it)
+    for st in states[1:]:
+        st["mask"] = states[0]["mask"]   # one static wet mask (the solver's chunk table is keyed on it)
     src = {k: ctx.to_device(v) for k, v in src_np.items()}
     w = {k: (ctx.to_device(v) if isinstance(v, np.ndarray) else v) for k, v in w_np.items()}
     # --pipeline auto: the next step's interpolation as tail workgroups of the solver launch (CF_OPT_MERGED_PREFETCH = 2) wherever
@@ -337,6 +503,12 @@ def main():
         # first guess (atmosphere.jl:34-39; coflux/models.py::update_state): one buffer for both, as in a coupled run
         ai["temperature"].copy_(ice_state["top_temperature"])
         ice_state["top_temperature"] = ai["temperature"]
+
+    if a.days is not None:
+        out = long_run(a, ctx, params, nx, ny, h, tripolar, ocean_np, w_np, states, w, atmos_sets, fl, net, pipeline, mode)
+        print(json.dumps(out), flush=True)
+        ctx.close()
+        return
 
     # ---- halo rows: prove each backend on this machine before timing it ------------------------------
     # The synthetic state is a function of the GLOBAL cell index, so every rank knows what its neighbours' boundary
