@@ -982,6 +982,25 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             case_np = dict(ocean=ocean_np[0], src=src_np, weights=w_np)
             out["cpu_baseline"], ref = cpu_baseline(case_np, params, nx, ny, h, a.cpu_seconds)
+            # The reference itself, where this box can run it (never in the build image): its CPU()
+            # path on the same inputs becomes the cpu_baseline (the port stays beside it), and the upstream vectors are produced so
+            # that tests/test_upstream_pin.py stops skipping.  Elsewhere the line says so instead of saying nothing.
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import upstream_probe
+            info = upstream_probe.probe()
+            out["julia_probe"] = info["status"]
+            if info["status"] == "present":
+                out["julia_probe_versions"] = info["versions"]
+                out["upstream_vectors"] = upstream_probe.ensure_upstream_vectors()
+                ref_rec = upstream_probe.time_reference_cpu(case_np, nx, ny, h, seconds=a.cpu_seconds) if (a.config == "ocean" and not tripolar) else None
+                if ref_rec is not None:
+                    out["cpu_baseline_port"] = out["cpu_baseline"]
+                    out["cpu_baseline"] = ref_rec
+                if upstream_probe.upstream_vectors_present():
+                    out["parity"] = (f"vs {upstream_probe.reference_label(info)}: vectors in tests/golden/upstream/ "
+                                     f"(python -m pytest tests/test_upstream_pin.py holds the oracle and the HIP path to them at 1e-6)")
+            elif info["detail"]:
+                out["julia_probe_detail"] = info["detail"]
             if a.config == "ocean" and not tripolar:
                 worst = measured_parity(ctx, ref, dict(src=src, weights=w, ocean=states[0]), nx, ny, h)
                 out["parity_measured"] = dict(worst_scaled_error=worst, max=max(worst.values()),

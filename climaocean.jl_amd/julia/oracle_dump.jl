@@ -23,27 +23,7 @@ const ROOT = normpath(joinpath(@__DIR__, "..", ".."))
 const INP = joinpath(ROOT, "tests", "golden", "upstream_inputs")
 const OUT = joinpath(ROOT, "tests", "golden", "upstream")
 
-# ---- minimal .npy (v1.0, little-endian Float64, C order) reader / writer -------------------------------------------------
-function read_npy(path)
-    open(path) do io
-        read(io, 6) == UInt8[0x93, 'N', 'U', 'M', 'P', 'Y'] || error("not an .npy file: $path")
-        read(io, 2); hlen = Int(read(io, UInt16))
-        header = String(read(io, hlen))
-        occursin("'<f8'", header) && occursin("'fortran_order': False", header) || error("expected C-order <f8: $header")
-        dims = parse.(Int, split(strip(match(r"\(([^)]*)\)", header).captures[1], [' ', ',']), r"\s*,\s*"; keepempty = false))
-        data = Vector{Float64}(undef, prod(dims)); read!(io, data)
-        length(dims) == 1 ? data : permutedims(reshape(data, reverse(dims)...))   # rows = j, columns = i
-    end
-end
-
-function write_npy(path, A::AbstractMatrix{Float64})   # A[j, i] → C-order (ny, nx)
-    header = "{'descr': '<f8', 'fortran_order': False, 'shape': ($(size(A, 1)), $(size(A, 2))), }"
-    header *= " "^(63 - (10 + length(header)) % 64) * "\n"
-    open(path, "w") do io
-        write(io, UInt8[0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0]); write(io, UInt16(length(header))); write(io, header)
-        write(io, collect(permutedims(A)))
-    end
-end
+include(joinpath(@__DIR__, "npy_io.jl"))     # read_npy, write_npy
 
 # ---- inputs --------------------------------------------------------------------------------------------------------------
 Nx, Ny, H, ring = Int.(read_npy(joinpath(INP, "shape.npy")))
@@ -200,6 +180,47 @@ section("sea_ice") do
         d(net.sea_ice.top.heat, "net_top_heat"); d(net.sea_ice.bottom.heat, "net_bottom_heat")
         d(net.ocean.T, "net_ocean_T"); d(net.ocean.S, "net_ocean_S"); d(net.ocean.u, "net_ocean_u"); d(net.ocean.v, "net_ocean_v")
         try d(model.interfaces.atmosphere_sea_ice_interface.iterations, "iterations") catch; end
+    end
+end
+
+# ---- (iii-b) the POLAR tile: 48 × 24 cells, all wet, all ice-covered, a cold atmosphere (VERDICT r5 item 6) -------------------
+# The restatement's skin-temperature iteration leaves 66–71 % of a polar surface's cells at maxiter (DESIGN.md §5.4): a
+# production scheme that does not converge on most of an ice pack is more likely a mis-recollection than upstream behaviour.
+# 1 152 cells answer it: the iteration count per cell (where this version exposes it), the skin temperature and the five fluxes.
+section("sea_ice_polar") do
+    OM = ClimaOcean.OMIPConfigurations
+    pnx, pny, ph, _ = Int.(read_npy(joinpath(INP, "polar_shape.npy")))
+    pin(group, k) = read_npy(joinpath(INP, "polar_$(group)_$(k).npy"))
+    pint(A) = permutedims(A[ph+1:ph+pny, ph+1:ph+pnx])
+    pgrid = LatitudeLongitudeGrid(CPU(); size = (pnx, pny, 1), halo = (ph, ph, ph), longitude = (0, pnx / 4), latitude = (64, 64 + pny / 4),
+                                  z = (-10, 0), topology = (Periodic, Bounded, Bounded))
+    pocean = ocean_simulation(pgrid; momentum_advection = nothing, tracer_advection = nothing, closure = nothing)
+    for (f, k) in ((pocean.model.tracers.T, "T"), (pocean.model.tracers.S, "S"), (pocean.model.velocities.u, "u"), (pocean.model.velocities.v, "v"))
+        P = parent(f); src = permutedims(pin("ocean", k))
+        P[1:size(src, 1), 1:size(src, 2), ph+1] .= src
+    end
+    patm = PrescribedAtmosphere(pgrid, [0.0, 1.0])
+    for n in 1:2
+        Oceananigans.interior(patm.velocities.u[n], :, :, 1) .= pint(pin("atmos", "u")); Oceananigans.interior(patm.velocities.v[n], :, :, 1) .= pint(pin("atmos", "v"))
+        Oceananigans.interior(patm.tracers.T[n], :, :, 1) .= pint(pin("atmos", "T"));    Oceananigans.interior(patm.tracers.q[n], :, :, 1) .= pint(pin("atmos", "q"))
+        Oceananigans.interior(patm.pressure[n], :, :, 1) .= pint(pin("atmos", "p"))
+        Oceananigans.interior(patm.downwelling_radiation.shortwave[n], :, :, 1) .= pint(pin("atmos", "Qs"))
+        Oceananigans.interior(patm.downwelling_radiation.longwave[n], :, :, 1) .= pint(pin("atmos", "Ql"))
+        Oceananigans.interior(patm.freshwater_flux.rain[n], :, :, 1) .= pint(pin("atmos", "Mp")); Oceananigans.interior(patm.freshwater_flux.snow[n], :, :, 1) .= 0
+    end
+    psea = sea_ice_simulation(pgrid, pocean; dynamics = nothing, advection = nothing)
+    set!(psea.model, h = pint(pin("ice", "thickness")), ℵ = pint(pin("ice", "concentration")))
+    Oceananigans.interior(psea.model.ice_thermodynamics.top_surface_temperature, :, :, 1) .= pint(pin("ice", "top_temperature"))
+    prad = Radiation(ocean_albedo = 0.06, ocean_emissivity = 1.0, sea_ice_albedo = 0.7, sea_ice_emissivity = 1.0)
+    for (name, ao, ai) in (("corrected", OM.corrected_atmosphere_ocean_fluxes(FT), OM.corrected_atmosphere_sea_ice_fluxes(FT)),
+                           ("ncar", OM.ncar_atmosphere_ocean_fluxes(FT), OM.ncar_atmosphere_sea_ice_fluxes(FT)))
+        interfaces = ComponentInterfaces(patm, pocean, psea; radiation = prad, atmosphere_ocean_fluxes = ao, atmosphere_sea_ice_fluxes = ai)
+        model = OceanSeaIceModel(pocean, psea; atmosphere = patm, radiation = prad, interfaces)
+        itf = model.interfaces.atmosphere_sea_ice_interface
+        d(field, tag) = write_npy(joinpath(OUT, "sea_ice_polar_$(name)_$(tag).npy"), permutedims(Array(Oceananigans.interior(field, :, :, 1))))
+        d(itf.fluxes.sensible_heat, "sensible_heat"); d(itf.fluxes.latent_heat, "latent_heat"); d(itf.fluxes.water_vapor, "water_vapor")
+        d(itf.fluxes.x_momentum, "x_momentum"); d(itf.fluxes.y_momentum, "y_momentum"); d(itf.temperature, "skin_temperature")
+        try d(itf.iterations, "iterations") catch; @warn "this version does not expose the interface solve's iteration counts: the histogram stays open" end
     end
 end
 

@@ -21,6 +21,7 @@ def pytest_sessionstart(session):
     a hard error there (tests/test_abi.py::test_missing_library_is_loud)."""
     lib = os.path.join(ROOT, "climaocean.jl_amd", "csrc", "libcoflux.so")
     orc = os.path.join(ROOT, "oracle", "liboracle_coflux.so")
+    _upstream_pin()
     if os.path.exists(lib) and os.path.exists(orc):
         return
     import subprocess
@@ -30,3 +31,16 @@ def pytest_sessionstart(session):
     if not os.path.exists(orc):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=False,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def _upstream_pin():
+    """The first box with Julia + ClimaOcean flips the parity status by itself: where
+    `julia -e 'using ClimaOcean'` works and tests/golden/upstream/ is still empty, oracle_dump.jl runs before collection and
+    tests/test_upstream_pin.py compares instead of skipping.  Anywhere else this is one `which julia`."""
+    try:
+        import upstream_probe
+        if upstream_probe.probe()["status"] == "present" and not upstream_probe.upstream_vectors_present():
+            res = upstream_probe.ensure_upstream_vectors()
+            print(f"[conftest] oracle_dump.jl: ran={res['ran']} ok={res['ok']} {res['detail'] or ''}", file=sys.stderr)
+    except Exception as exc:  # noqa: BLE001 — the pin is an upgrade, never a reason for the suite not to start
+        print(f"[conftest] upstream probe failed: {exc}", file=sys.stderr)

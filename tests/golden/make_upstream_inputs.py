@@ -10,6 +10,11 @@ tests/golden/upstream_inputs/ (which stay byte-identical: tests/test_upstream_pi
                                         temperature, ice velocity) — pins the atmosphere–sea-ice interface, the
                                         three-equation exchange and the CCSM3 albedo (f1)
   land_<var>_<n>.npy                    river + calving freshwater on the 64 × 32 source grid — pins where M_land enters JS
+  polar_<group>_<field>.npy             a 48 × 24 POLAR tile (64–70°N of the 1/4° grid, every cell wet and ice-covered, a cold
+                                        atmosphere already on the ocean grid): 1 152 cells of the atmosphere–sea-ice interface
+                                        solve — enough to show whether upstream's skin-temperature iteration, too, leaves most of
+                                        an ice pack at maxiter: the dump writes the
+                                        iteration histogram, the skin temperature and all five interface fluxes
 
 Re-run:  python tests/golden/make_upstream_inputs.py     (deterministic: counter-based generator, seed 20260612)"""
 import os
@@ -59,7 +64,33 @@ def main():
         np.save(os.path.join(inp, f"ice_{k}.npy"), np.ascontiguousarray(v, dtype=np.float64))
     for k in ("x_stress", "y_stress"):
         np.save(os.path.join(inp, f"ice_ocean_{k}.npy"), np.ascontiguousarray(oc["ice_" + k], dtype=np.float64))
+    polar_tile(inp)
     print("wrote", len(os.listdir(inp)), "files to", inp, "(%d KB)" % (sum(os.path.getsize(os.path.join(inp, f)) for f in os.listdir(inp)) // 1024))
+
+
+PNX, PNY, PJ0 = 48, 24, 536      # rows 536…559 of the 1/4° grid's 560: 64–70°N
+
+
+def polar_tile(inp):
+    import util
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    oc = syn.ocean_state(PNX, PNY, H, H, ny_global=NYG, j_offset=PJ0, land_fraction=False)
+    oc["T"] = np.minimum(oc["T"], -1.0 + 0.0 * oc["T"])                      # water under ice: near freezing
+    ice = syn.sea_ice_state(PNX, PNY, H, H, ny_global=NYG, j_offset=PJ0)
+    i, j = syn.ocean_indices(PNX, PNY, H, H, PJ0)
+    ice["concentration"] = np.clip(0.75 + 0.25 * syn.normal("ice", i, j, 5) + 0.0 * oc["T"], 0.3, 1.0)
+    ice["thickness"] = np.clip(ice["thickness"], 0.05, 3.0)
+    fi, fj, phi = syn.latlon_fractional_indices(PNX, PNY, H, H, ny_global=NYG, j_offset=PJ0)
+    g = orc.make_grid(PNX, PNY, H, H, 1)
+    at = util.polar_atmosphere(orc.interpolate_atmosphere_state(g, syn.jra55_snapshots(2), dict(separable=True, fi=fi, fj=fj, latitude=phi), 0, 1, TF))
+    np.save(os.path.join(inp, "polar_shape.npy"), np.array([PNX, PNY, H, RING], dtype=np.float64))
+    for k in ("T", "S", "u", "v", "mask"):
+        np.save(os.path.join(inp, f"polar_ocean_{k}.npy"), np.ascontiguousarray(oc[k], dtype=np.float64))
+    for k in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp"):
+        np.save(os.path.join(inp, f"polar_atmos_{k}.npy"), np.ascontiguousarray(at[k], dtype=np.float64))
+    for k in ("concentration", "thickness", "top_temperature", "u", "v", "albedo"):
+        np.save(os.path.join(inp, f"polar_ice_{k}.npy"), np.ascontiguousarray(ice[k], dtype=np.float64))
 
 
 if __name__ == "__main__":

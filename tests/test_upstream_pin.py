@@ -244,6 +244,62 @@ def test_cpu_oracle_sea_ice_interface_matches_upstream(name):
         assert abs(share_up - share_here) <= 0.02, ("share of cells left at maxiter", share_up, share_here)
 
 
+def _polar_case():
+    nx, ny, h, ring = (int(v) for v in np.load(os.path.join(INPUTS, "polar_shape.npy")))
+    ld = lambda grp, k: np.load(os.path.join(INPUTS, f"polar_{grp}_{k}.npy"))
+    ocean = {k: ld("ocean", k) for k in ("T", "S", "u", "v")}
+    ocean["mask"] = ld("ocean", "mask").astype(np.uint8)
+    atmos = {k: ld("atmos", k) for k in ("u", "v", "T", "p", "q", "Qs", "Ql", "Mp")}
+    ice = {k: ld("ice", k) for k in ("concentration", "thickness", "top_temperature", "u", "v", "albedo")}
+    return nx, ny, h, ring, ocean, atmos, ice
+
+
+def test_polar_tile_inputs_are_shipped_and_the_restatement_does_not_converge_on_them():
+    """The question the polar tile puts to upstream, stated as data: ≥ 1 000 ice-covered wet
+    cells under a cold atmosphere, on which THIS repository's restatement of the skin-temperature iteration leaves a large
+    share at maxiter.  The dump's sea_ice_polar section writes upstream's answer; the test below compares."""
+    text = open(DUMP).read()
+    for name in ("sea_ice_polar", "polar_shape.npy", "skin_temperature", "iterations"):
+        assert name in text, name
+    nx, ny, h, ring, ocean, atmos, ice = _polar_case()
+    inner = (slice(h, h + ny), slice(h, h + nx))
+    assert nx * ny >= 1000 and np.all(ocean["mask"][inner] != 0) and np.all(ice["concentration"][inner] > 0)
+    g = orc.make_grid(nx, ny, h, h, ring)
+    got = orc.compute_atmosphere_sea_ice_fluxes(g, ic.flux_params(ic.corrected_atmosphere_sea_ice_fluxes()),
+                                                ic.SeaIceInterfaceProperties().to_params(), ice, ocean, atmos)
+    its = got["iterations"][inner]
+    share = float((its >= 100).mean())
+    print(f"polar tile: {100 * share:.1f} % of {its.size} cells at maxiter; iterations min/median/max {its.min()}/{int(np.median(its))}/{its.max()}")
+    assert np.all(np.isfinite(got["temperature"][inner])) and share > 0.2      # the finding DESIGN §5.4 reports, reproduced on the tile
+
+
+@pytest.mark.skipif(not _have("sea_ice_polar_corrected_skin_temperature.npy"),
+                    reason="parity unpinned: tests/golden/upstream/sea_ice_polar_*.npy absent (oracle_dump.jl, section sea_ice_polar)")
+@pytest.mark.parametrize("name", ["corrected", "ncar"])
+def test_cpu_oracle_polar_tile_matches_upstream(name):
+    """Which way DESIGN §5.4's fork goes: if upstream converges where the restatement orbits, the histogram comparison fails
+    first and says so; if upstream orbits too, converged cells must agree at 1e-6 and the abandoned sets must coincide."""
+    nx, ny, h, ring, ocean, atmos, ice = _polar_case()
+    make = {"corrected": ic.corrected_atmosphere_sea_ice_fluxes, "ncar": ic.ncar_atmosphere_sea_ice_fluxes}[name]
+    got = orc.compute_atmosphere_sea_ice_fluxes(orc.make_grid(nx, ny, h, h, ring), ic.flux_params(make()),
+                                                ic.SeaIceInterfaceProperties().to_params(), ice, ocean, atmos)
+    inner = (slice(h, h + ny), slice(h, h + nx))
+    here = got["iterations"][inner]
+    if _have(f"sea_ice_polar_{name}_iterations.npy"):
+        up_its = np.load(os.path.join(UPSTREAM, f"sea_ice_polar_{name}_iterations.npy"))
+        share_up, share_here = float((up_its >= 100).mean()), float((here >= 100).mean())
+        assert abs(share_up - share_here) <= 0.02, (
+            f"upstream leaves {100 * share_up:.1f} % of the polar tile at maxiter, the restatement {100 * share_here:.1f} %: "
+            "the recalled skin-temperature balance is not upstream's (DESIGN.md §5.4, first row of the decision table)")
+        np.testing.assert_array_equal(up_its >= 100, here >= 100)
+    ok = here < 100
+    for k in FIELDS:
+        ref = np.load(os.path.join(UPSTREAM, f"sea_ice_polar_{name}_{k}.npy"))
+        assert util.rel_err(got[k][inner][ok], ref[ok], util.FIELD_SCALE[k]) <= TOL, (name, k)
+    ref = np.load(os.path.join(UPSTREAM, f"sea_ice_polar_{name}_skin_temperature.npy"))
+    assert np.max(np.abs(got["temperature"][inner][ok] - ref[ok])) <= 1e-5, name
+
+
 @pytest.mark.skipif(not _have("land_net_S.npy"), reason="parity unpinned: tests/golden/upstream/land_net_S.npy absent (oracle_dump.jl, section land)")
 def test_land_freshwater_enters_the_salinity_flux_as_upstream_does():
     """M_land inside Mp (ice-masked, one S_min guard with the rain) or outside (this repository)?  The dump decides."""
