@@ -53,6 +53,8 @@ python bench.py --solver-path certified --no-cpu-baseline > $OUT/bench_certified
 python bench.py --solver-path certified --flux-configuration corrected --no-cpu-baseline > $OUT/bench_certified_corrected.json 2>> $OUT/bench.err
 python bench.py --grid tripolar --nx 2160 --ny 1080 --flux-configuration corrected --no-cpu-baseline --no-sorted-pass > $OUT/bench_tripolar_2160x1080.json 2>> $OUT/bench.err
 python bench.py --grid tripolar --nx 360 --ny 180 --flux-configuration corrected --no-cpu-baseline --no-sorted-pass > $OUT/bench_tripolar_360x180.json 2>> $OUT/bench.err
+python bench.py --grid tripolar --nx 2160 --ny 1080 --flux-configuration corrected --days 30 --dt 300 > $OUT/bench_30day_tripolar_2160x1080.json 2>> $OUT/bench.err
+python bench.py --grid tripolar --nx 360 --ny 180 --flux-configuration corrected --days 30 --dt 1200 --check-every 180 > $OUT/bench_30day_tripolar_360x180.json 2>> $OUT/bench.err
 for f in bench bench_steps20 bench_corrected bench_ncar bench_slab70 bench_profiled; do python -c "
 import json,sys
 d=json.load(open('$OUT/$f.json')); r=d['roofline']
