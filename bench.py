@@ -55,6 +55,10 @@ def parse():
                          "the last rank (use --nx 360 --ny 180 for the 1-degree grid, --nx 2160 --ny 1080 for the 1/6-degree one)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--halo-backend", choices=("auto", "rccl", "peer", "torch"), default="auto")
+    ap.add_argument("--halo-in-launch", choices=("auto", "on", "off"), default="auto",
+                    help="CF_OPT_HALO_IN_SOLVER_LAUNCH at N > 1 with the peer-direct backend: the step's halo rows as rider workgroups of its "
+                         "solver launch.  auto = on if, on this machine, six steps with it leave the bits of six steps with the exchange "
+                         "kernel on every rank (halo rows poisoned first); the line says which ran (config.halo_in_solver_launch)")
     ap.add_argument("--flux-configuration", choices=("default", "corrected", "ncar"), default="default")
     ap.add_argument("--config", choices=("ocean", "sea_ice"), default="ocean",
                     help="ocean: BASELINE configs[1]; sea_ice: configs[2] (atmosphere–sea-ice interface + partition)")
@@ -689,6 +693,34 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- the halo rows inside the solver launch: proven on this machine against the exchange kernel before it is timed -------------
+    halo_in_launch = False
+    if world > 1 and "peer" in exchangers and tail_mode and a.config == "ocean" and a.halo_in_launch != "off" and not a.selftest:
+        def six_steps(flag):
+            ctx.set_option(abi.OPT_HALO_IN_SOLVER_LAUNCH, flag)
+            for st in states:                        # rows a neighbour must deliver (the synthetic state is a function of the global index)
+                for k in ("T", "S", "u", "v"):
+                    if rank > 0:
+                        st[k][h - ring_rows:h] = float("nan")
+                    if rank < world - 1:
+                        st[k][h + ny:h + ny + ring_rows] = float("nan")
+            barrier()
+            before = ctx.peer_halo_stats()
+            run_steps("peer", schedule_for("peer"), 0, 6)
+            barrier()
+            ctx.discard_prefetched_atmosphere_state()
+            rode = ctx.peer_halo_stats()[1] - before[1]
+            return [fl[k].clone() for k in FLUX_NAMES] + [net[k].clone() for k in net], rode
+        ref_fields, _ = six_steps(0)
+        got_fields, rode = six_steps(1)
+        good = rode > 0 and all(torch.equal(x, y) for x, y in zip(ref_fields, got_fields)) and all(bool(torch.isfinite(x[h:h + ny, h:h + nx]).all()) for x in got_fields)
+        flag = torch.tensor([1 if good else 0], device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        halo_in_launch = bool(flag.item())
+        if a.halo_in_launch == "on" and not halo_in_launch:
+            raise SystemExit("bench.py --halo-in-launch on: the riders do not reproduce the exchange kernel's steps on this machine")
+        ctx.set_option(abi.OPT_HALO_IN_SOLVER_LAUNCH, 1 if halo_in_launch else 0)
+
     settle, per_rank = {}, {}
 
     PATH_CODE = {"exact": abi.SOLVER_PATH_EXACT, "certified": abi.SOLVER_PATH_CERTIFIED}
@@ -910,7 +942,8 @@ def main():
                                rccl_comm_ranks=rccl_comm_ranks, solver_path=chosen,
                                ice_free_cells=(a.ice_free_cells if a.config == "sea_ice" else None),
                                certified_budget=(a.certified_budget * 1e-9 if "certified" in path_results else None),
-                               halo_rows=ring_rows if world > 1 else 0, pipelined_interpolation=pipeline,
+                               halo_rows=ring_rows if world > 1 else 0, halo_in_solver_launch=(halo_in_launch if world > 1 else None),
+                               pipelined_interpolation=pipeline,
                                pipeline_mode=mode,
                                step_loop="cf_time_steps (C)" if (a.config == "ocean" and best != "torch") else "host"),
                    settle_steps=settle.get(best), untimed_steps=(settle.get(best) or 0) + warmup + (switch_steps.get(best) or 0),

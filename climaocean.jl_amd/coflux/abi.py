@@ -26,7 +26,7 @@ MASK_NONE, MASK_U8, MASK_BOTTOM_HEIGHT = 0, 1, 2
 ALBEDO_CONSTANT, ALBEDO_LATITUDE_DEPENDENT = 0, 1
 OPT_SOLVER, OPT_TRIP_HINTS, OPT_FUSED_NET, OPT_ICE_ORBIT_SHORTCUT, OPT_MERGED_PREFETCH = 0, 3, 6, 7, 9
 OPT_INTERP_TILE_CAP, OPT_AO_CHUNK = 1, 4   # experiment options: the library accepts them only with COFLUX_EXPERIMENTS=1 in the environment
-OPT_SOLVER_PATH, OPT_CERTIFIED_BUDGET, OPT_ICE_FREE_CELLS, OPT_LATENCY_LAYOUT = 10, 11, 12, 13
+OPT_SOLVER_PATH, OPT_CERTIFIED_BUDGET, OPT_ICE_FREE_CELLS, OPT_LATENCY_LAYOUT, OPT_HALO_IN_SOLVER_LAUNCH = 10, 11, 12, 13, 14
 ICE_FREE_ITERATE, ICE_FREE_ZERO = 0, 1
 PIPELINE_WITHIN_CALL, PIPELINE_CONTINUING = 1, 2   # cf_run_schedule.pipeline
 SOLVER_PATH_EXACT, SOLVER_PATH_CERTIFIED = 0, 1      # how the Monin–Obukhov fixed point is reached (include/coflux.h)
@@ -201,7 +201,7 @@ EXPORTED_SYMBOLS = (
     "cf_compute_net_sea_ice_fluxes", "cf_update_state_sea_ice",
     "cf_time_stage", "cf_time_copy", "cf_profile_enable", "cf_profile_read",
     "cf_comm_unique_id", "cf_comm_init", "cf_comm_destroy", "cf_halo_exchange_rows",
-    "cf_peer_halo_export", "cf_peer_halo_connect", "cf_halo_exchange_rows_peer", "cf_fold_north_halo",
+    "cf_peer_halo_export", "cf_peer_halo_connect", "cf_halo_exchange_rows_peer", "cf_peer_halo_stats", "cf_fold_north_halo",
     "cf_time_steps", "cf_prefetch_atmosphere_state",
     "cf_default_sea_ice_albedo_params", "cf_set_sea_ice_albedo", "cf_compute_sea_ice_albedo",
     "cf_default_ice_ocean_params", "cf_compute_sea_ice_ocean_fluxes",
@@ -269,6 +269,7 @@ def load_library(path=None):
     lib.cf_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.cf_solver_iteration_path.argtypes = [vp, C.POINTER(C.c_int)]
     lib.cf_solver_latency_layout.argtypes = [vp, C.POINTER(C.c_int)]
+    lib.cf_peer_halo_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.cf_discard_prefetched_atmosphere_state.argtypes = [vp]
     lib.cf_comm_count.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.cf_debug_eval.argtypes = [vp, C.c_int, C.c_int, vp, vp]

@@ -386,6 +386,12 @@ class FluxContext:
         nb = C.create_string_buffer(north, abi.PEER_HANDLE_BYTES) if north is not None else None
         self._check(self.lib.cf_peer_halo_connect(self._h, sb, nb, rank, nranks), "cf_peer_halo_connect")
 
+    def peer_halo_stats(self):
+        """(exchanges issued, of which as riders of a solver launch: CF_OPT_HALO_IN_SOLVER_LAUNCH)."""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        self._check(self.lib.cf_peer_halo_stats(self._h, C.byref(a), C.byref(b)), "cf_peer_halo_stats")
+        return a.value, b.value
+
     def halo_exchange_rows_peer(self, tensors, rows=2):
         arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         self._check(self.lib.cf_halo_exchange_rows_peer(self._h, arr, len(tensors), rows), "cf_halo_exchange_rows_peer")

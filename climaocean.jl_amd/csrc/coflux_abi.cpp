@@ -263,6 +263,19 @@ static int ensure_chunk_table(cf_ctx* ctx, const void* mask) {
     ctx->chunk_valid = true;
     ctx->launch.d_chunk_begins = ctx->d_chunk_begins;
     ctx->launch.n_chunks = n;
+    {   // which chunks hold cells that read halo rows of the ocean state (HaloRider): the ring rows south of the interior read
+        // rows j < 0; the last interior row and the ring rows north of it read row j + 1 ≥ ny (ℑy v)
+        std::vector<int> begins((size_t)n + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(begins.data(), ctx->d_chunk_begins, sizeof(int) * begins.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const long wx = ctx->grid.nx + 2 * ctx->grid.ring, south_cells = (long)ctx->grid.ring * wx,
+                   north_from = (long)(ctx->grid.ny - 1 + ctx->grid.ring) * wx;
+        int cs = 0, cn = n;
+        while (cs < n && begins[cs] < south_cells) ++cs;
+        while (cn > 0 && begins[cn] > north_from) --cn;
+        ctx->launch.chunk_south = cs;
+        ctx->launch.chunk_north = cn;
+    }
     int overflow = 0;
     HIP_TRY(ctx, build_wet_lists(ctx->stream, ctx->d_params, ctx->grid, mask, n, ctx->d_chunk_begins, ctx->d_wet_pos,
                                  ctx->d_trip, ctx->d_chunk_meta, &overflow));
@@ -479,6 +492,7 @@ int cf_destroy(cf_ctx* ctx) {
         (void)hipFree(ctx->peer.mine);
     }
     if (ctx->d_peer_status) (void)hipFree(ctx->d_peer_status);
+    if (ctx->d_halo_counters) (void)hipFree(ctx->d_halo_counters);
     if (ctx->d_trip) (void)hipFree(ctx->d_trip);
     if (ctx->d_trip_ice) (void)hipFree(ctx->d_trip_ice);
     if (ctx->d_wet_pos) (void)hipFree(ctx->d_wet_pos);
@@ -551,6 +565,15 @@ int cf_set_option(cf_ctx* ctx, int option, int value) {
         case CF_OPT_SOLVER_PATH:
             if (value != CF_SOLVER_PATH_EXACT && value != CF_SOLVER_PATH_CERTIFIED) return fail(ctx, CF_ERR_INVALID, "solver path %d: 0 (exact) or 1 (certified)", value);
             ctx->launch.certified = value;
+            return CF_OK;
+        case CF_OPT_HALO_IN_SOLVER_LAUNCH:
+            if (value < 0 || value > 1) return fail(ctx, CF_ERR_INVALID, "halo rows in the solver launch %d: 0 (the exchange kernel of its own) or 1", value);
+            if (value && !ctx->d_halo_counters) {
+                HIP_TRY(ctx, hipSetDevice(ctx->device));
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_halo_counters, 4 * sizeof(unsigned long long)));
+                HIP_TRY(ctx, hipMemset(ctx->d_halo_counters, 0, 4 * sizeof(unsigned long long)));
+            }
+            ctx->halo_in_launch = value;
             return CF_OK;
         case CF_OPT_LATENCY_LAYOUT:
             if (value < 0 || value > 2) return fail(ctx, CF_ERR_INVALID, "latency layout %d: 0 (never), 1 (automatic), 2 (always)", value);
@@ -854,6 +877,40 @@ static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_i
     // With sea ice (cf_update_state_sea_ice): the ocean solve itself is handed to the caller, whose interface-solve launch carries
     // its workgroups behind its own (ice_ocean_kernel) — the stresses then follow that launch
     const bool ride = hold_tail_work && ocean_rider && fuse && tail_lean && !rec;
+    // the step's peer-direct halo rows (cf_time_steps left them as a request): riders of this solver launch where it is the
+    // stepping loop's exact-path launch with tail workgroups, else the exchange kernel of its own, now, in front of the solver
+    HaloRider halo_rider{};
+    const HaloRider* halo = nullptr;
+    if (ctx->halo_request.valid) {
+        ctx->halo_request.valid = false;
+        if (tail && tail_lean && !ride && ctx->d_halo_counters && lean_halo_rides(ctx->launch, ctx->fast)) {
+            HaloRider& H = halo_rider;
+            H.M = ctx->peer;
+            H.F = ctx->halo_request.F;
+            H.counters = ctx->d_halo_counters;
+            H.seq = ++ctx->peer_seq;
+            ++ctx->halo_in_launch_count;
+            for (int dir = 0; dir < 2; ++dir)
+                if ((dir == 0 ? ctx->peer.south : ctx->peer.north) != nullptr) {
+                    ctx->halo_expect_sent[dir] += (unsigned long long)H.F.n;
+                    ctx->halo_expect_done[dir] += (unsigned long long)H.F.n;
+                }
+            for (int dir = 0; dir < 2; ++dir) {
+                H.expect_sent[dir] = ctx->halo_expect_sent[dir];
+                H.expect_done[dir] = ctx->halo_expect_done[dir];
+            }
+            H.status = ctx->d_peer_status;
+            H.rows = ctx->halo_request.rows;
+            H.blocks = 2 * H.F.n;
+            H.chunk_south = ctx->launch.chunk_south;
+            H.chunk_north = ctx->launch.chunk_north;
+            H.wait_south = ctx->peer.south != nullptr;
+            H.wait_north = ctx->peer.north != nullptr;
+            halo = &halo_rider;
+        } else {
+            CHECK(cf_peer_halo_launch_now(ctx, &ctx->halo_request.F, ctx->halo_request.rows));
+        }
+    }
     if (ride) {
         HIP_TRY(ctx, make_ocean_rider(ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes, ice, net, ctx->d_land_freshwater,
                                       ocean_rider));
@@ -871,7 +928,7 @@ static int update_state_impl(cf_ctx* ctx, const cf_atmos_source* src, const cf_i
         }();
         if (tail_lean)
             HIP_TRY(ctx, launch_ao_fluxes_lean(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes, ice, net,
-                                               ctx->d_land_freshwater, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out, rows, blocks, tail_pos));
+                                               ctx->d_land_freshwater, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out, rows, blocks, tail_pos, halo));
         else
             HIP_TRY(ctx, launch_ly_fluxes_with_tail(ctx->stream, ctx->launch, ctx->dev, ctx->fast, ctx->grid, ocean, atmos, fluxes, ice, net,
                                                     ctx->d_land_freshwater, &ctx->deferred.src, &ctx->deferred.w, &ctx->deferred.out, rows, blocks));

@@ -131,6 +131,16 @@ struct cf_ctx {
     bool peer_south_mapped = false, peer_north_mapped = false;  // opened through HIP IPC (to be closed)
     unsigned long long peer_seq = 0;
     int* d_peer_status = nullptr;
+    // the peer-direct exchange as riders of the solver launch (CF_OPT_HALO_IN_SOLVER_LAUNCH; coflux_lean_kernel.hpp, HALO)
+    int halo_in_launch = 0;
+    unsigned long long halo_in_launch_count = 0;            // exchanges that rode in a solver launch (cf_peer_halo_stats)
+    unsigned long long* d_halo_counters = nullptr;          // [0,1] fields sent south / north, [2,3] fields received from there
+    unsigned long long halo_expect_sent[2] = {0, 0}, halo_expect_done[2] = {0, 0};
+    struct HaloRequest {                                    // cf_time_steps asked for this step's rows: the next solver launch carries
+        bool valid = false;                                 // them, or cf_update_state issues the stand-alone kernel in front of it
+        PeerFields F{};
+        int rows = 0;
+    } halo_request;
     // RCCL
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
@@ -156,5 +166,7 @@ int cf_fail(cf_ctx* ctx, int code, const char* fmt, ...);
         if (rc_ != CF_OK) return rc_; \
     } while (0)
 
+// coflux_steps.cpp: the stand-alone peer-direct exchange kernel for `F` (counts the exchange in ctx->peer_seq)
+extern "C" __attribute__((visibility("hidden"))) int cf_peer_halo_launch_now(cf_ctx* ctx, const PeerFields* F, int rows);
 // coflux_abi.cpp: books ctx->deferred as launched on the main stream (see cf_update_state)
 extern "C" __attribute__((visibility("hidden"))) int deferred_went_out_on_main(cf_ctx* ctx);

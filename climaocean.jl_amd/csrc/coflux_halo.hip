@@ -9,20 +9,11 @@
 // rows.  No host round trip, no second launch, nothing for the solver to wait on except stream order.
 #include <hip/hip_runtime.h>
 
+#include "coflux_halo_device.hpp"
 #include "coflux_kernel_types.hpp"
 #include "coflux_kernels.h"
 
 namespace coflux {
-
-// the waiting lane gives up after this many polls (s_sleep 8 ≈ 512 clocks + the load ≈ 1.3 µs each): ≈ 5 s
-constexpr unsigned long long PEER_SPIN_LIMIT = 4ull * 1000 * 1000;
-
-__device__ __forceinline__ double* mailbox_rows(const PeerMailbox& M, char* base, int side, int parity) {
-    return reinterpret_cast<double*>(base + M.data_offset) + ((size_t)(side * 2 + parity)) * M.slot_doubles;
-}
-__device__ __forceinline__ unsigned long long* mailbox_flag(char* base, int side, int parity) {
-    return reinterpret_cast<unsigned long long*>(base) + (side * 2 + parity) * 8;  // one flag per 64-byte line
-}
 
 __global__ __launch_bounds__(PEER_BLOCK) void peer_halo_kernel(PeerMailbox M, PeerFields F, GridDesc G, int rows,
                                                                unsigned long long seq, int* __restrict__ status) {

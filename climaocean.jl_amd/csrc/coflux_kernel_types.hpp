@@ -108,6 +108,25 @@ struct PeerFields {
     double* ptr[PEER_MAX_FIELDS];
     int n;
 };
+// The peer-direct exchange as RIDER workgroups of the solver launch (coflux_lean_kernel.hpp, HALO): one workgroup per
+// (direction, field); `counters` (device memory, monotone): [0], [1] fields SENT towards the south / north neighbour, [2], [3]
+// fields RECEIVED from them and copied into the halo rows.  expect_* = the counters' values once this launch's exchange is complete.
+struct HaloRider {
+    PeerMailbox M;
+    PeerFields F;
+    unsigned long long* counters;
+    unsigned long long seq;
+    unsigned long long expect_sent[2], expect_done[2];
+    int* status;
+    int rows;
+    int blocks;       // 2 · F.n rider workgroups at the head of the launch, or 0: this launch carries no exchange
+    int chunk_south;  // chunks [0, chunk_south) hold cells that read the south halo rows
+    int chunk_north;  // chunks [chunk_north, n_chunks) hold cells that read the north halo rows
+    int wait_south, wait_north;   // 1: a neighbour exists on that side
+    int pad[2];
+};
+static_assert(sizeof(HaloRider) % 8 == 0, "argument bundles are made of 8-byte words");
+
 struct FoldFields {
     double* ptr[PEER_MAX_FIELDS];
     double sign[PEER_MAX_FIELDS];

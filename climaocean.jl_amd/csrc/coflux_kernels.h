@@ -23,6 +23,7 @@ inline const char* experiment_knob(const char* name) {
 
 struct LoopParams;
 struct IceParams;
+struct HaloRider;
 
 struct LaunchCfg {
     int solver;              // CF_SOLVER_*
@@ -34,6 +35,7 @@ struct LaunchCfg {
     uint8_t* d_trip;            // per-wet-cell trip count of the previous call (scheduling hint) or NULL
     const int* d_chunk_begins;  // cost-balanced chunk table of the solver (coflux_solver.hip), n_chunks + 1 entries
     int n_chunks;
+    int chunk_south, chunk_north;  // chunks [0, chunk_south) read the south halo rows, [chunk_north, n_chunks) the north ones (HaloRider)
     const uint32_t* d_wet_pos;  // static wet lists of the chunks, fixed stride (coflux_solver.hip), or NULL
     uint32_t* d_lean_sorted;    // the lean ocean kernel's lists: every chunk's wet cells ordered by last call's trip counts (coflux_solver_lean.hip)
     const int* d_lean_info;     // per chunk: wet cells listed, fingerprint of the wet set (x, y), 0
@@ -69,7 +71,10 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
                                  const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
                                  const cf_sea_ice_fields* ice = nullptr, const cf_net_ocean_fluxes* net = nullptr, const double* land = nullptr,
                                  const cf_atmos_source* next_src = nullptr, const cf_interp_weights* w = nullptr,
-                                 const cf_exchange_fields* next_out = nullptr, int tail_rows = 0, int tail_blocks = 0, int tail_pos = -1);
+                                 const cf_exchange_fields* next_out = nullptr, int tail_rows = 0, int tail_blocks = 0, int tail_pos = -1,
+                                 const HaloRider* halo = nullptr);
+// the step's peer-direct halo rows can ride in the ocean solver's launch (exact path of the lean kernel, with tail workgroups)
+bool lean_halo_rides(const LaunchCfg& L, const LoopParams& C);
 size_t wet_list_capacity(int ncells);
 int wet_list_stride();
 hipError_t launch_ao_fluxes_libm(hipStream_t st, const DevParams& P, const GridDesc& G, const cf_ocean_surface* o,

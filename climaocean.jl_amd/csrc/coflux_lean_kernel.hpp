@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "coflux_halo_device.hpp"
 #include "coflux_interp_tiles.hpp"
 #include "coflux_lean.hpp"
 #include "coflux_certified.hpp"
@@ -47,11 +48,12 @@ struct LeanArgs {
     long long n_chunks;       // TAIL: workgroups [0, n_chunks) solve, the tail_blocks behind them interpolate
     long long tail_blocks, tail_rows, tail_cap;
     long long tail_pos;       // TAIL: index of the first interpolation workgroup in dispatch order (n_chunks: behind every solver workgroup)
+    HaloRider H;              // HALO: the peer-direct halo rows of this step as rider workgroups at the head of the launch
 };
 typedef const LeanArgs __attribute__((address_space(4)))* LeanArgsPtr;
 
 // coflux_solver_slab.hip: the exact path's kernels in the one-wave-per-SIMD layout (COARE × plain / fused net fluxes / + tail workgroups)
-hipError_t launch_ao_lean_line(hipStream_t st, bool coare, bool fuse, bool tail, int blocks, const LeanArgs& A);
+hipError_t launch_ao_lean_line(hipStream_t st, bool coare, bool fuse, bool tail, bool halo, int blocks, const LeanArgs& A);
 
 __device__ __forceinline__ LeanArgsPtr opaque(LeanArgsPtr p) {
     asm volatile("" : "+s"(p));
@@ -124,13 +126,34 @@ __device__ __forceinline__ void lean_zero_cell(const LoopParams& L, double T_off
 #endif
 // LINE: the iteration in its one-wave-per-SIMD layout (mo_iterate_lean_line; coflux_solver_slab.hip builds those kernels
 // through tools/gcn_sched.py); bitwise the same results.
-template <bool COARE, bool FUSE, bool TAIL = false, bool CERT = false, bool LINE = false>
+// HALO (with TAIL, exact path): the step's peer-direct halo rows inside this launch.  The first
+// H.blocks workgroups are the exchange's riders (peer_halo_rider: one per direction and field); the chunks whose cells read
+// halo rows — the south ring row; the last interior row and the north ring row — are dispatched BEHIND every other chunk and
+// wait, after their own start phase, for the riders' counter: interior chunks never wait, and the neighbours' latency
+// passes under interior work instead of in front of the launch.  The same rows arrive by the same protocol: bitwise the step
+// with the stand-alone exchange kernel (tests/test_steps.py).
+template <bool COARE, bool FUSE, bool TAIL = false, bool CERT = false, bool LINE = false, bool HALO = false>
 __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
     constexpr int BLOCK = AO_BLOCK;
     using Geo = LeanGeom<BLOCK>;
     constexpr int CHUNK = Geo::CHUNK;
     LeanArgsPtr K = opaque(K_in);
     int chunk = chunk_in;  // dispatch order = layer order of the chunk table
+    bool wait_south = false, wait_north = false;
+    if constexpr (HALO) {
+        static_assert(TAIL && !CERT, "the halo riders belong to the stepping loop's exact-path launch");
+        const int nh = K->H.blocks;
+        if (chunk < nh) {
+            extern __shared__ __attribute__((aligned(16))) char smem_h[];
+            const int nf = K->H.F.n, dir = chunk / nf, f = chunk - dir * nf;   // (uniform: scalar loads with a computed offset)
+            const PeerMailbox M = kread(&K->H.M);
+            const GridDesc Gh = kread(&K->G);
+            peer_halo_rider(M, K->H.F.ptr[f], f, dir, K->H.rows, K->H.seq, K->H.counters, K->H.expect_sent[dir], K->H.status, Gh, BLOCK,
+                            reinterpret_cast<int*>(smem_h));
+            return;
+        }
+        chunk -= nh;
+    }
     if constexpr (TAIL) {
         static_assert(BLOCK == 64 * IT_WAVES, "a tail workgroup is an interpolation workgroup");
         const int nb = (int)K->tail_blocks, ipos = (int)K->tail_pos;
@@ -146,6 +169,18 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             return;
         }
         if (chunk >= ipos) chunk -= nb;
+    }
+    if constexpr (HALO) {
+        // dispatch position → chunk: the chunks between the two boundary sets first, then the south set, then the north set
+        const int cs = K->H.chunk_south, cn = K->H.chunk_north, nc = (int)K->n_chunks;
+        if (K->H.blocks > 0) {
+            if (cs <= cn) {
+                const int inner = cn - cs;
+                chunk = chunk < inner ? cs + chunk : (chunk - inner < cs ? chunk - inner : cn + (chunk - inner - cs));
+            }
+            wait_south = K->H.wait_south != 0 && chunk < cs;
+            wait_north = K->H.wait_north != 0 && chunk >= cn && chunk < nc;
+        }
     }
     const LoopParams L = kread(&K->L);
     const GridDesc G = kread(&K->G);
@@ -290,6 +325,11 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
     }
     __syncthreads();  // the ONE barrier of the start phase: tables, parameters, list and fingerprints are in LDS
     LEAN_STAMP(3);
+    if constexpr (HALO) {
+        // a boundary chunk: the halo rows its first batch is about to load (nothing before this point reads the ocean state)
+        if (wait_south) peer_halo_wait(&opaque(K)->H.counters[2], K->H.expect_done[0]);
+        if (wait_north) peer_halo_wait(&opaque(K)->H.counters[3], K->H.expect_done[1]);
+    }
     const DevParams& P = *lp;
     bool have_list = false;
     int nwet = 0;

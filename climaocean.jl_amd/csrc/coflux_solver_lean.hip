@@ -58,6 +58,12 @@ __global__ __launch_bounds__(AO_BLOCK, CF_LEAN_WAVES) void ao_lean_kernel(LeanAr
     ao_lean_body<COARE, FUSE, TAIL, CERT>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
 }
 
+// the stepping loop's exact-path launch with the step's peer-direct halo rows as rider workgroups (ao_lean_body, HALO)
+template <bool COARE>
+__global__ __launch_bounds__(AO_BLOCK, CF_LEAN_WAVES) void ao_lean_halo_kernel(LeanArgs unused_by_name) {
+    ao_lean_body<COARE, true, true, false, false, true>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host side: the sorted lists start as the static wet lists of the chunk table (index order); the fingerprint and
 // the wet count of every chunk are computed here, once per mask.
@@ -110,6 +116,10 @@ bool lean_certified_applies(const LaunchCfg& L, const LoopParams& C) {
     // not on the cap, which the certificate presumes)
     return L.certified && C.specialization == SOLVER_OCEAN_LEAN && !C.fixed && L.lean_hints == 0 &&
            C.cert_max_evals > 2 && C.tol >= 1e-9 && C.maxiter >= 40;
+}
+
+bool lean_halo_rides(const LaunchCfg& L, const LoopParams& C) {
+    return C.specialization == SOLVER_OCEAN_LEAN && L.solver == CF_SOLVER_TABLES && !lean_certified_applies(L, C);
 }
 
 bool lean_line_applies(const LaunchCfg& L, const LoopParams& C, bool coare) {
@@ -178,7 +188,7 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
                                  const cf_ocean_surface* o, const cf_exchange_fields* e, const cf_interface_fluxes* f,
                                  const cf_sea_ice_fields* ice, const cf_net_ocean_fluxes* net, const double* land,
                                  const cf_atmos_source* next_src, const cf_interp_weights* w, const cf_exchange_fields* next_out,
-                                 int tail_rows, int tail_blocks, int tail_pos) {
+                                 int tail_rows, int tail_blocks, int tail_pos, const HaloRider* halo) {
     LeanArgs A{};
     if (hipError_t err = fill_lean_args(L, P, C, G, o, e, f, ice, net, land, A)) return err;
     const bool coare = P.similarity_form == CF_SIMILARITY_COARE_LOGARITHMIC;
@@ -200,7 +210,18 @@ hipError_t launch_ao_fluxes_lean(hipStream_t st, const LaunchCfg& L, const DevPa
         A.tail_pos = tail_pos < 0 || tail_pos > L.n_chunks ? L.n_chunks : tail_pos;
         blocks += tail_blocks;
     }
-    if (lean_line_applies(L, C, coare)) return launch_ao_lean_line(st, coare, net != nullptr, tail, blocks, A);
+    const bool riders = halo != nullptr && halo->blocks > 0;
+    if (riders) {
+        if (!tail || !lean_halo_rides(L, C) || halo->F.n < 1 || halo->blocks != 2 * halo->F.n) return hipErrorInvalidValue;
+        A.H = *halo;
+        blocks += halo->blocks;
+    }
+    if (lean_line_applies(L, C, coare)) return launch_ao_lean_line(st, coare, net != nullptr, tail, riders, blocks, A);
+    if (riders) {
+        if (coare) hipLaunchKernelGGL((ao_lean_halo_kernel<true>), dim3(blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        else hipLaunchKernelGGL((ao_lean_halo_kernel<false>), dim3(blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        return hipGetLastError();
+    }
 #define CF_LEAN_LAUNCH(COARE_, FUSE_, TAIL_, CERT_) \
     hipLaunchKernelGGL((ao_lean_kernel<COARE_, FUSE_, TAIL_, CERT_>), dim3(blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A)
 #define CF_LEAN_PICK(FUSE_, TAIL_)                                                       \

@@ -27,16 +27,19 @@
 
 namespace coflux {
 
-template <bool COARE, bool FUSE, bool TAIL>
+template <bool COARE, bool FUSE, bool TAIL, bool HALO = false>
 __global__ __launch_bounds__(AO_BLOCK, 2) void ao_lean_line_kernel(LeanArgs unused_by_name) {
-    ao_lean_body<COARE, FUSE, TAIL, false, true>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
+    ao_lean_body<COARE, FUSE, TAIL, false, true, HALO>((LeanArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
 }
 
-hipError_t launch_ao_lean_line(hipStream_t st, bool coare, bool fuse, bool tail, int blocks, const LeanArgs& A) {
-    if (tail && !fuse) return hipErrorInvalidValue;
+hipError_t launch_ao_lean_line(hipStream_t st, bool coare, bool fuse, bool tail, bool halo, int blocks, const LeanArgs& A) {
+    if ((tail && !fuse) || (halo && !tail)) return hipErrorInvalidValue;
 #define CF_LINE_LAUNCH(COARE_, FUSE_, TAIL_) \
     hipLaunchKernelGGL((ao_lean_line_kernel<COARE_, FUSE_, TAIL_>), dim3(blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A)
-    if (tail) {
+    if (halo) {
+        if (coare) hipLaunchKernelGGL((ao_lean_line_kernel<true, true, true, true>), dim3(blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+        else hipLaunchKernelGGL((ao_lean_line_kernel<false, true, true, true>), dim3(blocks), dim3(AO_BLOCK), LeanGeom<AO_BLOCK>::LDS_BYTES, st, A);
+    } else if (tail) {
         if (coare) CF_LINE_LAUNCH(true, true, true); else CF_LINE_LAUNCH(false, true, true);
     } else if (fuse) {
         if (coare) CF_LINE_LAUNCH(true, true, false); else CF_LINE_LAUNCH(false, true, false);

@@ -225,8 +225,19 @@ int cf_halo_exchange_rows_peer(cf_ctx* ctx, double* const* d_fields, int nfields
         if (!d_fields[f]) return fail(ctx, CF_ERR_INVALID, "cf_halo_exchange_rows_peer: field %d is NULL", f);
         F.ptr[f] = d_fields[f];
     }
+    return cf_peer_halo_launch_now(ctx, &F, rows);
+}
+
+int cf_peer_halo_launch_now(cf_ctx* ctx, const PeerFields* F, int rows) {
     ++ctx->peer_seq;  // every rank counts its exchanges: the same number names the same step everywhere
-    HIP_TRY(ctx, launch_peer_halo(ctx->stream, ctx->peer, F, G, rows, ctx->peer_seq, ctx->d_peer_status));
+    HIP_TRY(ctx, launch_peer_halo(ctx->stream, ctx->peer, *F, ctx->grid, rows, ctx->peer_seq, ctx->d_peer_status));
+    return CF_OK;
+}
+
+int cf_peer_halo_stats(cf_ctx* ctx, unsigned long long* exchanges, unsigned long long* in_solver_launch) {
+    if (!ctx) return fail(nullptr, CF_ERR_INVALID, "ctx is NULL");
+    if (exchanges) *exchanges = ctx->peer_seq;
+    if (in_solver_launch) *in_solver_launch = ctx->halo_in_launch_count;
     return CF_OK;
 }
 
@@ -336,8 +347,20 @@ int cf_time_steps(cf_ctx* ctx, int64_t first_step, int nsteps, const cf_run_sche
                            const_cast<double*>(o->v)};
         if (S->halo_backend == CF_HALO_RCCL)
             CHECK(cf_halo_exchange_rows(ctx, rows, 4, S->halo_rows));
-        else if (S->halo_backend == CF_HALO_PEER)
-            CHECK(cf_halo_exchange_rows_peer(ctx, rows, 4, S->halo_rows));
+        else if (S->halo_backend == CF_HALO_PEER) {
+            if (ctx->halo_in_launch && ctx->peer_connected && 4 <= ctx->peer_max_fields && S->halo_rows <= ctx->peer_max_rows &&
+                S->halo_rows <= ctx->grid.ny) {
+                // CF_OPT_HALO_IN_SOLVER_LAUNCH: left as a request — this step's solver launch carries the exchange as rider
+                // workgroups where it can, cf_update_state issues the exchange kernel in front of the solver where it cannot
+                ctx->halo_request.F = PeerFields{};
+                ctx->halo_request.F.n = 4;
+                for (int f = 0; f < 4; ++f) ctx->halo_request.F.ptr[f] = rows[f];
+                ctx->halo_request.rows = S->halo_rows;
+                ctx->halo_request.valid = true;
+            } else {
+                CHECK(cf_halo_exchange_rows_peer(ctx, rows, 4, S->halo_rows));
+            }
+        }
         if (S->fold_north) CHECK(cf_fold_north_halo(ctx, rows, fold_loc, fold_sign, 4, ctx->grid.ring + 1));
         const cf_atmos_source s = source_at(step);
         const cf_exchange_fields* a = &S->atmos[S->n_atmos_sets == 2 ? step % 2 : 0];

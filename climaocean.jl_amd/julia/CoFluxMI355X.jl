@@ -147,6 +147,14 @@ solver_iteration_path(b) = (p = Ref{Cint}(0); check(b.ctx, ccall((:cf_solver_ite
                             p[] == 1 ? :certified : :exact)
 
 solver_latency_layout(b) = (p = Ref{Cint}(0); check(b.ctx, ccall((:cf_solver_latency_layout, libcoflux), Cint, (Ptr{Cvoid}, Ref{Cint}), b.ctx, p)); p[] == 1)
+# CF_OPT_HALO_IN_SOLVER_LAUNCH: a step's peer-direct halo rows as rider workgroups of its solver launch (include/coflux.h)
+const CF_OPT_HALO_IN_SOLVER_LAUNCH = Cint(14)
+halo_in_solver_launch!(b, on::Bool) = set_option!(b, CF_OPT_HALO_IN_SOLVER_LAUNCH, on ? 1 : 0)
+function peer_halo_stats(b)
+    n = Ref{Culonglong}(0); m = Ref{Culonglong}(0)
+    check(b.ctx, ccall((:cf_peer_halo_stats, libcoflux), Cint, (Ptr{Cvoid}, Ref{Culonglong}, Ref{Culonglong}), b.ctx, n, m))
+    return (exchanges = n[], in_solver_launch = m[])
+end
 
 # ---- the three functions of update_state! ------------------------------------------------------
 # Each body is ONE ccall; these are the methods a maintainer adds for

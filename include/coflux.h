@@ -331,9 +331,9 @@ int cf_set_flux_params(cf_ctx* ctx, const cf_flux_params* params);
 #define CF_STREAM_LEGACY ((void*)1) /* == hipStreamLegacy */
 int cf_set_stream(cf_ctx* ctx, void* hip_stream);
 
-/* Options (cf_set_option).  None of them changes what is computed beyond the stated tolerance.  NINE are part of the drop-in
+/* Options (cf_set_option).  None of them changes what is computed beyond the stated tolerance.  TEN are part of the drop-in
  * surface: CF_OPT_SOLVER, _TRIP_HINTS, _FUSED_NET, _ICE_ORBIT_SHORTCUT, _MERGED_PREFETCH, _SOLVER_PATH, _CERTIFIED_BUDGET,
- * _ICE_FREE_CELLS, _LATENCY_LAYOUT.  Two more are EXPERIMENT options, accepted only in a process started with
+ * _ICE_FREE_CELLS, _LATENCY_LAYOUT, _HALO_IN_SOLVER_LAUNCH.  Two more are EXPERIMENT options, accepted only in a process started with
  * COFLUX_EXPERIMENTS=1 (measurements, and the test-suite's schedule-invariance checks): CF_OPT_INTERP_TILE_CAP, CF_OPT_AO_CHUNK.
  * Numbers 2, 5 and 8 were CF_OPT_MAX_BLOCKS, _PROFILE_STRIDE and _FUSED_INTERP (retired in ABI version 3: cf_set_option
  * answers CF_ERR_INVALID).                                                                                              */
@@ -444,6 +444,17 @@ int cf_set_stream(cf_ctx* ctx, void* hip_stream);
                                    * wave issues no faster re-ordered).  Results are the same bits in every mode (tests/test_slab_line.py).  Needs gustiness_parameter != 0 (every
                                    * SimilarityTheoryFluxes preset of the reference); other parameter sets keep the production kernels. */
 #define CF_ICE_FREE_ZERO 1
+#define CF_OPT_HALO_IN_SOLVER_LAUNCH 14 /* 1: cf_time_steps with CF_HALO_PEER hands each step's halo rows to that step's solver launch instead of
+                                   * launching the exchange kernel in front of it: 2 × 4 rider workgroups at the head of the launch run the
+                                   * same mailbox protocol (one per direction and field), the chunks whose cells read halo rows — the south
+                                   * ring row, the last interior row, the north ring row — are dispatched behind every other chunk and wait
+                                   * for the riders' counter after their own start phase; interior chunks never wait, and the neighbours'
+                                   * latency passes under interior work.  Applies where the step's solver launch is the exact path of the
+                                   * round-3 ocean kernel with tail workgroups (CF_OPT_MERGED_PREFETCH = 2 inside a pipelined cf_time_steps);
+                                   * any other step gets the exchange kernel as before.  The rows that arrive are the same bits
+                                   * (tests/test_steps.py: 2 and 4 ranks, lat-lon and tripolar).  0 (default): the exchange kernel of its
+                                   * own.  What it buys on N devices is UNMEASURED: no multi-GPU node has run either form;
+                                   * one launch boundary and a 3–5 µs kernel per step are what it removes from a 26 µs slab step.        */
 #define CF_SOLVER_TABLES 0  /* default: reference iteration path on LDS-tabulated ψ / log / exp.  Accuracy of the tabulated primitives
                                against libm (tests/test_gpu_parity.py::test_device_primitives_accuracy): ψ_m, ψ_h ≤ 5e-12 of
                                max(|ψ|, 1) for |ζ| < 1024 (every state a converging iteration can stop on) and ≤ 2e-10 for
@@ -794,6 +805,9 @@ int cf_halo_exchange_rows(cf_ctx* ctx, double* const* d_fields, int nfields, int
 int cf_peer_halo_export(cf_ctx* ctx, int max_fields, int max_rows, void* handle_out);
 int cf_peer_halo_connect(cf_ctx* ctx, const void* south_handle, const void* north_handle, int rank, int nranks);
 int cf_halo_exchange_rows_peer(cf_ctx* ctx, double* const* d_fields, int nfields, int rows);
+/* How many peer-direct exchanges this context has issued, and how many of them rode in a solver launch
+ * (CF_OPT_HALO_IN_SOLVER_LAUNCH) instead of the exchange kernel of their own.  A measurement / test aid.      */
+int cf_peer_halo_stats(cf_ctx* ctx, unsigned long long* exchanges, unsigned long long* in_solver_launch);
 
 /* Tripolar fold (TripolarGrid(arch; size=(360,180,Nz)), OceanConfigurations/one_degree_tripolar.jl:48-51; the
  * fold itself lives in Oceananigans' zipper boundary condition, [UPSTREAM-RECALL] fold_north_center_center! /

@@ -363,6 +363,8 @@ def test_bench_n_rank_code_path_rehearsal():
     assert line["untimed_steps"] >= line["settle_steps"] + 5 and set(line["solver_paths_ms_per_step"]) == {"exact"}
     assert line["config"]["solver_path"] == "exact" and line["value"] == line["value_exact"] and line["value_certified"] is None
     assert "rccl_comm_ranks" in line["config"]
+    # the halo rows rode in the solver launches (CF_OPT_HALO_IN_SOLVER_LAUNCH), after bench.py had proven them against the exchange kernel
+    assert line["config"]["halo_in_solver_launch"] is True
 
 
 @pytest.mark.gpu
