@@ -869,7 +869,7 @@ def main():
         copy_ms = ctx.time_copy(copy_bytes, 20)
 
         # HBM bytes and VALU instructions per launch from committed rocprofv3 PMC passes (separate runs of this command,
-        # scratch/round_profile.sh; see profiles/): properties of the kernels on this workload, not re-measured in this
+        # tools/round_profile.sh; see profiles/): properties of the kernels on this workload, not re-measured in this
         # run — `traffic_source` / `instructions_source` name the file and the commit it was taken at
         lean, fused = ctx.solver_path()
 
@@ -996,17 +996,17 @@ def main():
                       "power-limited to about 1.9 GHz = 480 G wave-instr/s (scratch/ubench_valu.hip), the solver is not; every "
                       "VALU instruction is counted at the FP64 rate (the SQ counters book an integer VALU instruction at one "
                       "quad cycle as well: 28.5 M active quads for 27.0 M instructions)"))
-        # strong-scaling projection from single-GPU measurements of one rank's slab (scratch/slab_curve.py): a PROJECTION,
+        # strong-scaling projection from single-GPU measurements of one rank's slab (tools/slab_curve.py): a PROJECTION,
         # labelled as such — the driver computes the real curve from its own N-GPU runs
         try:
-            sc = json.load(open(os.path.join(ROOT, "profiles", next(f for f in ("r05_slab_curve.json", "r04f_slab_curve.json")
+            sc = json.load(open(os.path.join(ROOT, "profiles", next(f for f in ("r06_slab_curve.json", "r05_slab_curve.json", "r04f_slab_curve.json")
                                                                          if os.path.exists(os.path.join(ROOT, "profiles", f))))))
             if canonical and world == 1:
                 out["projected_scaling"] = dict(
                     kind="projection from one GPU, not a multi-GPU measurement",
                     speedup_before_halo_rows={k: round(v, 3) for k, v in sc["projected_speedup_before_halos"].items()},
                     slab_ms_per_step={k: round(v["ms_per_step"], 5) for k, v in sc["slabs"].items()},
-                    source="committed: profiles/r05_slab_curve.json, else r04f (python bench.py --ny 560/280/140/70 on one MI355X)",
+                    source="committed: profiles/r06_slab_curve.json, else r05 / r04f (python bench.py --ny 560/280/140/70 on one MI355X, tools/slab_curve.py)",
                     note=sc["note"])
         except Exception:
             pass

@@ -1,4 +1,4 @@
-"""gpurun_out/<tag>/pmc_traffic_raw.json + pmc_sq_raw.json (scratch/round_profile.sh) → profiles/<round>_pmc_traffic.json and
+"""gpurun_out/<tag>/pmc_traffic_raw.json + pmc_sq_raw.json (tools/round_profile.sh) → profiles/<round>_pmc_traffic.json and
 profiles/<round>_pmc_sq.json, the files bench.py cites.  usage: make_pmc_profiles.py <tag> <round> (e.g. r03a r03)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ for k, v in raw.items():
     kernels[k] = dict(FETCH_SIZE_KB=v["FETCH_SIZE"], WRITE_SIZE_KB=v["WRITE_SIZE"], fetch_scale=scale, launches=v.get("launches"),
                       hbm_bytes_per_launch=(scale * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0)
 note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (counters only) over `python bench.py --steps 20 --warmup 2 "
-        "--repetitions 1 --no-cpu-baseline` (scratch/round_profile.sh %s); KB per launch, averaged over all launches of the run. gfx950 "
+        "--repetitions 1 --no-cpu-baseline` (tools/round_profile.sh %s); KB per launch, averaged over all launches of the run. gfx950 "
         "correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE tallies 128-B requests at 64 B — calibrated in the same run on copy_kernel "
         "(256 MiB copied: FETCH_SIZE %s KB, WRITE_SIZE %s KB) — so fetch bytes = 2 x FETCH_SIZE for 8/16-B-per-lane streams; the "
         "interpolation's 4-B gathers are counted unscaled. The counters sit on the fabric side of L2 and include what the 256 MB "
@@ -34,6 +34,6 @@ for k, v in sq.items():
         rec["valu_busy_note"] = "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x 3 waves per SIMD"
     out[k] = rec
 json.dump(dict(note="rocprofv3 --pmc SQ passes (counters only) over the same command; per launch, averaged over all launches of the run "
-                    "(scratch/round_profile.sh %s)" % tag, commit=commit, kernels=out),
+                    "(tools/round_profile.sh %s)" % tag, commit=commit, kernels=out),
           open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_sq.json"), "w"), indent=1)
 print("wrote profiles/%s_pmc_traffic.json, profiles/%s_pmc_sq.json at %s" % (rnd, rnd, commit))

@@ -46,7 +46,7 @@ open("$OUT/pmc_sq_raw.json","w").write(json.dumps(res,indent=1))
 print(json.dumps({k:v for k,v in res.items() if "ao_" in k or "interp" in k or "net_" in k},indent=1))
 PY
 rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ $OUT/pmc_SQ2
-python scratch/slab_curve.py $TAG > $OUT/slab_curve.log 2>&1
+python tools/slab_curve.py $TAG > $OUT/slab_curve.log 2>&1
 python bench.py --config sea_ice --no-cpu-baseline > $OUT/bench_sea_ice.json 2>> $OUT/bench.err
 python bench.py --config sea_ice --ice-free-cells zero --no-cpu-baseline > $OUT/bench_sea_ice_zero.json 2>> $OUT/bench.err
 python bench.py --solver-path certified --no-cpu-baseline > $OUT/bench_certified.json 2>> $OUT/bench.err
