@@ -11,9 +11,12 @@ Reference surface being mirrored:
 What is here: the dataset objects, the `start_date` / `end_date` → snapshot-counter mapping (repeat-year wrap, multi-year
 clamping, leap days), and a snapshot PROVIDER — `provider(n) -> {variable: float32[320, 640]}` — for
 models.JRA55PrescribedAtmosphere's sliding HBM window (cf_window_*), reading RAW little-endian Float32 planes with
-`np.memmap`, or NetCDF CLASSIC files (`nccopy -k classic tas_1990.nc4 tas_1990.nc`) through scipy.io.netcdf_file
-(ClassicNetCDFFiles).  NetCDF4/HDF5 decoding itself is not possible in this image (no netCDF4 / h5py / HDF5 library);
-the one-line conversion to raw planes a maintainer runs once per yearly file, anywhere netCDF4 exists, is
+`np.memmap`, NetCDF CLASSIC files (`nccopy -k classic tas_1990.nc4 tas_1990.nc`) through scipy.io.netcdf_file
+(ClassicNetCDFFiles), or — round 6 — the distributed NetCDF-4 files themselves through a pure-Python reader of the HDF5 subset
+they use (NetCDF4Files, coflux/hdf5_subset.py: chunked `[time, lat, lon]` variables, shuffle + deflate through zlib; written
+from the format specification and tested against an independent writer of it, never against a file made by libhdf5 — this image
+has no HDF5 library).  Where that reader refuses a file, the one-line conversion to raw planes a maintainer runs once per
+yearly file, anywhere netCDF4 exists, is
 
     python -c "import netCDF4, sys; f, v = sys.argv[1:]; netCDF4.Dataset(f)[v][:].astype('<f4').tofile(f[:-3] + '.f32')" tas_1990.nc tas
 
@@ -181,11 +184,66 @@ class ClassicNetCDFFiles:
         return a
 
 
+class NetCDF4Files:
+    """`<dir>/<shortname>_<year>.nc` (or `.nc4`) in the NetCDF-4 format the JRA55-do files are distributed in
+    (jra55_data_staging.jl:8,134), read with coflux/hdf5_subset.py — no HDF5 library.  One time level per `plane()` call: with
+    the files' one-level chunks that is one chunk located through the chunk B-tree, inflated and un-shuffled (≈ 1 ms for
+    640×320 Float32).  `scale_factor` / `add_offset` are applied where the variable carries them.  Same contract as
+    RawPlaneFiles: Float32 [320, 640]."""
+
+    def __init__(self, directory, shortnames=JRA55_SHORTNAMES, shape=(NY, NX)):
+        self.dir, self.shape = directory, tuple(shape)
+        self.shortnames = tuple(shortnames)
+        self._vars = {}
+
+    def path(self, shortname, year):
+        for ext in (".nc", ".nc4"):
+            p = os.path.join(self.dir, f"{shortname}_{year}{ext}")
+            if os.path.exists(p):
+                return p
+        return os.path.join(self.dir, f"{shortname}_{year}.nc")
+
+    def _variable(self, shortname, year):
+        key = (shortname, year)
+        v = self._vars.get(key)
+        if v is None:
+            from . import hdf5_subset
+            p = self.path(shortname, year)
+            if not os.path.exists(p):
+                raise FileNotFoundError(f"{p}: JRA55 NetCDF-4 file missing")
+            f, ds = hdf5_subset.open_variable(p, shortname)
+            if len(ds.shape) != 3 or tuple(ds.shape[1:]) != self.shape:
+                raise ValueError(f"{p}: variable of shape {ds.shape}, expected [time, {self.shape[0]}, {self.shape[1]}]")
+            v = self._vars[key] = (f, ds, float(ds.attrs.get("scale_factor", 1.0)), float(ds.attrs.get("add_offset", 0.0)))
+        return v
+
+    def plane(self, shortname, year, k):
+        _, ds, scale, offset = self._variable(shortname, year)
+        if not 0 <= k < ds.shape[0]:
+            raise IndexError(f"{self.path(shortname, year)} holds {ds.shape[0]} snapshots, asked for {k}")
+        a = ds.read_leading(k).astype(np.float32)
+        if scale != 1.0 or offset != 0.0:
+            a = (a * np.float32(scale) + np.float32(offset)).astype(np.float32)
+        return a
+
+
+def _is_hdf5(path):
+    try:
+        with open(path, "rb") as fh:
+            return fh.read(8) == b"\x89HDF\r\n\x1a\n"
+    except OSError:
+        return False
+
+
 def plane_files(directory):
-    """RawPlaneFiles or ClassicNetCDFFiles, by what the directory holds (`*.f32` wins)."""
+    """RawPlaneFiles, ClassicNetCDFFiles or NetCDF4Files, by what the directory holds (`*.f32` wins; a `.nc` file is told apart
+    by its first eight bytes: the HDF5 signature means NetCDF-4)."""
     names = os.listdir(directory) if os.path.isdir(directory) else []
-    if any(n.endswith(".f32") for n in names) or not any(n.endswith(".nc") for n in names):
+    nc = sorted(n for n in names if n.endswith((".nc", ".nc4")))
+    if any(n.endswith(".f32") for n in names) or not nc:
         return RawPlaneFiles(directory)
+    if _is_hdf5(os.path.join(directory, nc[0])):
+        return NetCDF4Files(directory)
     return ClassicNetCDFFiles(directory)
 
 
