@@ -97,7 +97,7 @@ def test_built_slab_kernels_verify_piece_by_piece():
         pytest.skip("coflux_solver_slab.dev.s is a build artefact (python __graft_entry__.py build)")
     lines = open(dev).read().split("\n")
     fns = gs.matching_functions(lines, "ao_lean_line_kernel")
-    assert len(fns) == 6
+    assert len(fns) == 8      # COARE x (plain, fused, fused + tail, fused + tail + halo riders)
     total = 0
     for fn in fns:
         lo = gs.next_free_vgpr(lines, fn)
