@@ -614,6 +614,54 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
+    # ---- the halo rows inside the solver launch: proven on this machine against the exchange kernel before it is timed -------------
+    def prove_halo_in_launch():
+        """True where six steps with CF_OPT_HALO_IN_SOLVER_LAUNCH leave, on every rank, the bits of six steps with the exchange kernel
+        (halo rows poisoned first, the riders really used); the option is left on exactly then."""
+        if not (world > 1 and "peer" in exchangers and tail_mode and a.config == "ocean" and a.halo_in_launch != "off"):
+            return False
+
+        def six_steps(flag):
+            """(fields, exchanges that rode, ok): every collective sits OUTSIDE the part that can fail, so that a rank whose
+            riders time out (≈ 5 s, surfacing as an error of its next cf_sync) stays in step with the others"""
+            dist.barrier()
+            fields, rode, ok = None, 0, True
+            try:
+                ctx.set_option(abi.OPT_HALO_IN_SOLVER_LAUNCH, flag)
+                for st in states:                        # rows a neighbour must deliver (the synthetic state is a function of the global index)
+                    for k in ("T", "S", "u", "v"):
+                        if rank > 0:
+                            st[k][h - ring_rows:h] = float("nan")
+                        if rank < world - 1:
+                            st[k][h + ny:h + ny + ring_rows] = float("nan")
+                torch.cuda.synchronize()
+                before = ctx.peer_halo_stats()
+                run_steps("peer", schedule_for("peer"), 0, 6)
+                ctx.sync()
+                torch.cuda.synchronize()
+                ctx.discard_prefetched_atmosphere_state()
+                rode = ctx.peer_halo_stats()[1] - before[1]
+                fields = [fl[k].clone() for k in FLUX_NAMES] + [net[k].clone() for k in net]
+            except Exception as exc:  # noqa: BLE001 — a form that fails on this machine is a form that is not used
+                print(f"[bench] rank {rank}: six steps with CF_OPT_HALO_IN_SOLVER_LAUNCH = {flag} failed: {exc}", file=sys.stderr)
+                ok = False
+                try:
+                    ctx.discard_prefetched_atmosphere_state()
+                    ctx.sync()
+                except Exception:  # noqa: BLE001
+                    pass
+            dist.barrier()
+            return fields, rode, ok
+        ref_fields, _, ok0 = six_steps(0)
+        got_fields, rode, ok1 = six_steps(1)
+        good = (ok0 and ok1 and rode > 0 and all(torch.equal(x, y) for x, y in zip(ref_fields, got_fields)) and
+                all(bool(torch.isfinite(x[h:h + ny, h:h + nx]).all()) for x in got_fields))
+        flag = torch.tensor([1 if good else 0], device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        proven = bool(flag.item())
+        ctx.set_option(abi.OPT_HALO_IN_SOLVER_LAUNCH, 1 if proven else 0)
+        return proven
+
     # ---- --selftest: first contact with an N-GPU node, stage by stage -----------------------------------------------
     if a.selftest:
         report = dict(selftest="running", n_gpus=world, rank_rows=ny, halo_verified=halo_verified if world > 1 else None,
@@ -684,6 +732,8 @@ def main():
             if max(worst.values()) > tol:
                 raise RuntimeError(f"gathered surface differs from the single-domain oracle: {worst}")
         stage("compare_with_oracle", compare)
+        proven = prove_halo_in_launch()      # (reported, never fatal: where the riders do not reproduce the exchange kernel it is simply not used)
+        report["halo_in_solver_launch_proven"] = proven if world > 1 else None
         if rank == 0:
             report["selftest"] = "ok"
             print(json.dumps(report), flush=True)
@@ -693,50 +743,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- the halo rows inside the solver launch: proven on this machine against the exchange kernel before it is timed -------------
-    halo_in_launch = False
-    if world > 1 and "peer" in exchangers and tail_mode and a.config == "ocean" and a.halo_in_launch != "off" and not a.selftest:
-        def six_steps(flag):
-            """(fields, exchanges that rode, ok): every collective sits OUTSIDE the part that can fail, so that a rank whose
-            riders time out (≈ 5 s, surfacing as an error of its next cf_sync) stays in step with the others"""
-            dist.barrier()
-            fields, rode, ok = None, 0, True
-            try:
-                ctx.set_option(abi.OPT_HALO_IN_SOLVER_LAUNCH, flag)
-                for st in states:                        # rows a neighbour must deliver (the synthetic state is a function of the global index)
-                    for k in ("T", "S", "u", "v"):
-                        if rank > 0:
-                            st[k][h - ring_rows:h] = float("nan")
-                        if rank < world - 1:
-                            st[k][h + ny:h + ny + ring_rows] = float("nan")
-                torch.cuda.synchronize()
-                before = ctx.peer_halo_stats()
-                run_steps("peer", schedule_for("peer"), 0, 6)
-                ctx.sync()
-                torch.cuda.synchronize()
-                ctx.discard_prefetched_atmosphere_state()
-                rode = ctx.peer_halo_stats()[1] - before[1]
-                fields = [fl[k].clone() for k in FLUX_NAMES] + [net[k].clone() for k in net]
-            except Exception as exc:  # noqa: BLE001 — a form that fails on this machine is a form that is not used
-                print(f"[bench] rank {rank}: six steps with CF_OPT_HALO_IN_SOLVER_LAUNCH = {flag} failed: {exc}", file=sys.stderr)
-                ok = False
-                try:
-                    ctx.discard_prefetched_atmosphere_state()
-                    ctx.sync()
-                except Exception:  # noqa: BLE001
-                    pass
-            dist.barrier()
-            return fields, rode, ok
-        ref_fields, _, ok0 = six_steps(0)
-        got_fields, rode, ok1 = six_steps(1)
-        good = (ok0 and ok1 and rode > 0 and all(torch.equal(x, y) for x, y in zip(ref_fields, got_fields)) and
-                all(bool(torch.isfinite(x[h:h + ny, h:h + nx]).all()) for x in got_fields))
-        flag = torch.tensor([1 if good else 0], device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        halo_in_launch = bool(flag.item())
-        if a.halo_in_launch == "on" and not halo_in_launch:
-            raise SystemExit("bench.py --halo-in-launch on: the riders do not reproduce the exchange kernel's steps on this machine")
-        ctx.set_option(abi.OPT_HALO_IN_SOLVER_LAUNCH, 1 if halo_in_launch else 0)
+    halo_in_launch = prove_halo_in_launch()
+    if a.halo_in_launch == "on" and world > 1 and not halo_in_launch:
+        raise SystemExit("bench.py --halo-in-launch on: the riders do not reproduce the exchange kernel's steps on this machine")
 
     settle, per_rank = {}, {}
 

@@ -383,6 +383,7 @@ def test_bench_selftest_two_ranks_sharing_the_device(grid):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["selftest"] == "ok" and line["stages"][0] == "halo_backends" and line["stages"][-1] == "compare_with_oracle"
     assert max(line["worst_scaled_error_vs_oracle"].values()) <= 1e-9
+    assert line["halo_in_solver_launch_proven"] is True      # (the riders reproduce the exchange kernel's steps here: reported, never fatal)
 
 
 @pytest.mark.gpu
