@@ -3,7 +3,7 @@ chunk plans, fusion and pipelining options — against the C oracle's exact path
 (six fields and net fluxes <= 1e-6, exact-path cells 1e-9 with the reference's trip counts, land exact), and bitwise
 against the same case under another chunk plan."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "climaocean.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np
 import util

@@ -3,7 +3,7 @@ stripes, all land, all ocean, a single wet cell), mask kinds and chunk plans —
 C oracle, identical trip counts, exact zeros on land.  Exercises the start phase's range/list/fingerprint logic on
 ragged geometries."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "climaocean.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np
 import util

@@ -6,7 +6,7 @@ neighbour whose kernels sit behind it in the same queue times out — a limit of
 process per rank, as on a node and in tests/test_halo_in_launch.py, has no such coupling: 4 ranks pass there.)
 usage: fuzz_halo_in_launch.py [seed] [cases]"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "climaocean.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 os.environ.setdefault("COFLUX_EXPERIMENTS", "1")
 import numpy as np, torch

@@ -1,7 +1,7 @@
 """GPU fuzz, part 4: the sea-ice interface solve in both workgroup geometries and several chunk plans — bitwise equal
 to the default plan — and against the oracle, on random sizes and both skin schemes."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "climaocean.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np
 import util

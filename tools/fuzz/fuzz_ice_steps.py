@@ -2,7 +2,7 @@
 interpolation as workgroups of the interface solve's launch, net sea-ice fluxes in its epilogue) against the plain sequence —
 bitwise in every output — on random sizes, both ice formulations, every ocean formulation, with and without requests."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "climaocean.jl_amd")]
 import numpy as np, torch
 from coflux import abi, synthetic as syn, interface_computations as ic

@@ -2,7 +2,7 @@
 variant reachable through the size and the tile cap, against the oracle at 1e-12; (b) the sea-ice interface solve with
 the orbit shortcut on and off — bitwise — on random sizes, both skin schemes."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "climaocean.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np
 import util, oracle as orc

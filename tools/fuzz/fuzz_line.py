@@ -4,7 +4,7 @@ allocation by csrc/tools/gcn_sched.py) forced on (CF_OPT_LATENCY_LAYOUT = 2) aga
 similarity profiles, random roughness / gustiness / stop rules) with and without the fused net fluxes and sea-ice fields;
 every fourth case also against the C oracle.  usage: fuzz_line.py [seed] [cases]"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "climaocean.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np
 import util

@@ -1,7 +1,7 @@
 """GPU fuzz, part 3: the wet mask rewritten IN PLACE between calls (same pointer: the static lists are stale) on random
 sizes, patterns and chunk plans; every call must give the oracle's answer for the mask as it is now."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "climaocean.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import util, oracle as orc

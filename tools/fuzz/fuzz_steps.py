@@ -2,7 +2,7 @@
 without the pipelined interpolation) against the host-driven cf_update_state loop — bitwise — on random sizes, window
 lengths, clock increments and step counts."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "climaocean.jl_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np, torch
 from coflux import abi, synthetic as syn, interface_computations as ic
