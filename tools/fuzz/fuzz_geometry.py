@@ -29,7 +29,7 @@ for n in range(ncases):
     kind = rng.choice(["u8", "bottom", "none"])
     params = ic.flux_params(mask_kind={"u8": abi.MASK_U8, "bottom": abi.MASK_BOTTOM_HEIGHT, "none": abi.MASK_NONE}[kind])
     if kind == "bottom": case["ocean"]["mask"] = np.where(m != 0, -3000.0, 10.0)
-    opts = [(), ((abi.OPT_AO_CHUNK, 256),), ((abi.OPT_AO_CHUNK, 1280),), ((abi.OPT_AO_CHUNK, 3072),), ((abi.OPT_TRIP_HINTS, 0),)][int(rng.integers(0, 5))]
+    opts = [(), ((abi.OPT_AO_CHUNK, 256),), ((abi.OPT_AO_CHUNK, 1280),), ((abi.OPT_AO_CHUNK, 768),), ((abi.OPT_TRIP_HINTS, 0),)][int(rng.integers(0, 5))]
     try:
         got = run_gpu(case, params, ring=ring, options=opts, ice=with_ice, fused=fused)
         ref = run_oracle(case, params, ring=ring, ice=with_ice)

@@ -20,7 +20,7 @@ for n in range(ncases):
             util.compare_ice_fluxes(ref_gpu, ref, TOL_ICE)
         except AssertionError as exc:
             print("  note: oracle comparison outside the test bars for", dict(nx=nx, ny=ny, cfg=cfg, scheme=scheme), repr(exc)[:120], flush=True)
-        for plan in (3072, 256, 1280):
+        for plan in (768, 256, 1280):
             got, _ = run_ice(case, cfg, scheme=scheme, options=((abi.OPT_AO_CHUNK, plan),))
             for k in got: np.testing.assert_array_equal(got[k], ref_gpu[k], err_msg=f"plan {plan} {k}")
     except Exception as exc:

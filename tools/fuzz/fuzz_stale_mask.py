@@ -24,7 +24,7 @@ for n in range(ncases):
     params = ic.flux_params()
     case = util.build_case(nx, ny, h, h)
     ctx = FluxContext(nx, ny, h, h, params)
-    opt = [None, 256, 1280, 3072][int(rng.integers(0, 4))]
+    opt = [None, 256, 1280, 768][int(rng.integers(0, 4))]
     if opt: ctx.set_option(abi.OPT_AO_CHUNK, opt)
     dev = ctx.to_device
     src = {k: dev(v) for k, v in case["src"].items()}

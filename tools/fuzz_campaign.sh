@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-end fuzz campaign: the GPU fuzzers of tools/fuzz/ on fresh seeds ($1 = first seed, $2 = output log).
+export COFLUX_EXPERIMENTS=1   # (the fuzzers draw chunk plans: CF_OPT_AO_CHUNK is an experiment option)
 seed=${1:-61}
 log=${2:-gpurun_out/r06_fuzz.log}
 mkdir -p $(dirname $log)
