@@ -6,7 +6,7 @@ log=${2:-gpurun_out/r06_fuzz.log}
 mkdir -p $(dirname $log)
 : > $log
 run() { echo "== $*" >> $log; timeout 900 python "$@" >> $log 2>&1; echo "rc=$?" >> $log; }
-run tools/fuzz/fuzz_geometry.py $seed 60
+run tools/fuzz/fuzz_geometry.py $seed ${CASES:-60}
 run tools/fuzz/fuzz_interp_ice.py $((seed+1)) 40
 run tools/fuzz/fuzz_stale_mask.py $((seed+2)) 30
 run tools/fuzz/fuzz_ice_geometry.py $((seed+3)) 20
