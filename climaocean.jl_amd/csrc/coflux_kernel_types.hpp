@@ -167,16 +167,23 @@ inline FluxOut make_fluxes(const cf_interface_fluxes* f) {
                    f->temperature,   f->friction_velocity, f->temperature_scale, f->humidity_scale, f->iterations};
 }
 
+// FINAL: the launch assembles the net fluxes itself, so nothing in the step reads these fields again (ρτ excepted: the face-stress
+// launch does) — streaming stores (coflux_solver_shared.hpp::gstore_final has the measurements)
+template <bool FINAL = false>
 __device__ __forceinline__ void store_fluxes(const FluxOut& F, size_t k, const CellFluxes& R) {
-    F.Qc[k] = R.Qc;
-    F.Qv[k] = R.Qv;
-    F.Fv[k] = R.Fv;
+    auto put = [](double* p, double v) {
+        if constexpr (FINAL) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    };
+    put(&F.Qc[k], R.Qc);
+    put(&F.Qv[k], R.Qv);
+    put(&F.Fv[k], R.Fv);
     F.tx[k] = R.rho_tau_x;
     F.ty[k] = R.rho_tau_y;
-    F.Ts[k] = R.Ts_ocean;
-    if (F.ustar) F.ustar[k] = R.ustar;
-    if (F.tstar) F.tstar[k] = R.tstar;
-    if (F.qstar) F.qstar[k] = R.qstar;
+    put(&F.Ts[k], R.Ts_ocean);
+    if (F.ustar) put(&F.ustar[k], R.ustar);
+    if (F.tstar) put(&F.tstar[k], R.tstar);
+    if (F.qstar) put(&F.qstar[k], R.qstar);
     if (F.iters) F.iters[k] = R.iterations;
 }
 
@@ -251,13 +258,18 @@ __device__ __forceinline__ void net_sea_ice_cell(double albedo, double emissivit
     bottom = Qf + Qi;
 }
 
+template <bool FINAL = false>
 __device__ __forceinline__ void store_net_cell(const NetOut& N, size_t k, const NetCell& C) {
-    N.T[k] = C.JT;
-    N.S[k] = C.JS;
-    if (N.sw) N.sw[k] = C.sw;
-    if (N.lw_up) N.lw_up[k] = C.lw_up;
-    if (N.lw_down) N.lw_down[k] = C.lw_down;
-    if (N.sw_down) N.sw_down[k] = C.sw_down;
+    auto put = [](double* p, double v) {
+        if constexpr (FINAL) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    };
+    put(&N.T[k], C.JT);
+    put(&N.S[k], C.JS);
+    if (N.sw) put(&N.sw[k], C.sw);
+    if (N.lw_up) put(&N.lw_up[k], C.lw_up);
+    if (N.lw_down) put(&N.lw_down[k], C.lw_down);
+    if (N.sw_down) put(&N.sw_down[k], C.sw_down);
 }
 
 }  // namespace coflux

@@ -396,6 +396,11 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
         // ---- waves pull 64 wet cells at a time; the NEXT batch's inputs are requested before this batch iterates ------
         // (a batch's eleven loads take ≈ 2 µs to come back and its ≈ 2000 FP64 instructions ≈ 6 µs to issue: requested
         // one batch ahead, the loads cost 23 registers across the iteration and no wait)
+        // (results the step's other launches do not read: streamed when this launch assembles the net fluxes itself — gstore_final)
+        auto store_result = [&](double* base, unsigned byte_off, double v) {
+            if constexpr (FUSE) gstore_final(base, byte_off, v);
+            else gstore(base, byte_off, v);
+        };
         auto claim = [&]() {
             int st = 0;
             if (lane == 0) st = atomicAdd(&counters[0], 64);
@@ -489,7 +494,7 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
             const LeanCell c = lean_prologue(P, L.kappa, tab, raw.ua, raw.va, raw.Ta, raw.pa, raw.qa, 0.5 * (raw.u0 + raw.u1),
                                              0.5 * (raw.v0 + raw.v1), raw.To, raw.So);
             // the interface temperature does not depend on the iteration: written now, not carried across it
-            if (in_range) gstore(opaque(K)->F.Ts, (unsigned)cell_of(start) * 8u, c.Ts - T_offset);
+            if (in_range) store_result(opaque(K)->F.Ts, (unsigned)cell_of(start) * 8u, c.Ts - T_offset);
             CertNetSalt net_salt;
             if constexpr (CERT && CF_CERT_NET_SALT) {
                 // J_S is assembled from the vapour flux (by this launch's epilogue or by net_cell_kernel): the certificate is
@@ -565,14 +570,14 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                 const CellFluxes R = lean_epilogue(c, T_offset, s);
                 const FluxOut F = kread(&Ke->F);
                 const unsigned k8 = (unsigned)k * 8u;
-                gstore(F.Qc, k8, R.Qc);
-                gstore(F.Qv, k8, R.Qv);
-                gstore(F.Fv, k8, R.Fv);
+                store_result(F.Qc, k8, R.Qc);
+                store_result(F.Qv, k8, R.Qv);
+                store_result(F.Fv, k8, R.Fv);
                 gstore(F.tx, k8, R.rho_tau_x);
                 gstore(F.ty, k8, R.rho_tau_y);
-                if (F.ustar) gstore(F.ustar, k8, R.ustar);
-                if (F.tstar) gstore(F.tstar, k8, R.tstar);
-                if (F.qstar) gstore(F.qstar, k8, R.qstar);
+                if (F.ustar) gstore_final(F.ustar, k8, R.ustar);
+                if (F.tstar) gstore_final(F.tstar, k8, R.tstar);
+                if (F.qstar) gstore_final(F.qstar, k8, R.qstar);
                 if (F.iters) gstore_i32(F.iters, (unsigned)k * 4u, R.iterations);
                 if constexpr (FUSE) {
                     // compute_net_ocean_fluxes!, the part that needs no neighbour: interior cells only
@@ -587,12 +592,12 @@ __device__ __forceinline__ void ao_lean_body(LeanArgsPtr K_in, int chunk_in) {
                                                          gload(Ke->E.Mp, k8), gload(Ke->E.Qs, k8), gload(Ke->E.Ql, k8), R.Qc, R.Qv, R.Fv,
                                                          I.Qio ? gload(I.Qio, k8) : 0.0, I.Jsio ? gload(I.Jsio, k8) : 0.0,
                                                          I.land ? gload(I.land, k8) : 0.0);
-                        gstore(N.T, k8, C.JT);  // (store_net_cell's fields, by offset)
-                        gstore(N.S, k8, C.JS);
-                        if (N.sw) gstore(N.sw, k8, C.sw);
-                        if (N.lw_up) gstore(N.lw_up, k8, C.lw_up);
-                        if (N.lw_down) gstore(N.lw_down, k8, C.lw_down);
-                        if (N.sw_down) gstore(N.sw_down, k8, C.sw_down);
+                        gstore_final(N.T, k8, C.JT);  // (store_net_cell's fields, by offset)
+                        gstore_final(N.S, k8, C.JS);
+                        if (N.sw) gstore_final(N.sw, k8, C.sw);
+                        if (N.lw_up) gstore_final(N.lw_up, k8, C.lw_up);
+                        if (N.lw_down) gstore_final(N.lw_down, k8, C.lw_down);
+                        if (N.sw_down) gstore_final(N.sw_down, k8, C.sw_down);
                     }
                 }
                 if (sorting && have_list) {

@@ -802,7 +802,7 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
                 const CellFluxes R = cell_epilogue(c, P.T_offset, s);
                 {
                     const FluxOut F = kread(&Ke->F);
-                    store_fluxes(F, k, R);
+                    store_fluxes<FUSE_NET>(F, k, R);
                 }
                 if (use_static && W.trip) W.trip[(size_t)chunk * CHUNK + (list[qc] >> AO_LIST_OFFSET_BITS)] = (uint8_t)min(s.work, 255);
                 if constexpr (FUSE_NET) {
@@ -810,7 +810,7 @@ __device__ __forceinline__ void ao_flux_fast_body(SolverArgsPtr K_in, const int 
                     if (ci >= 0 && ci < G.nx && cj >= 0 && cj < G.ny) {
                         const IceIn I = kread(&Ke->I);
                         const NetOut N = kread(&Ke->N);
-                        store_net_cell(N, k, net_cell_local(P, P.albedo, I.conc ? I.conc[k] : 0.0, So, R.Ts_ocean + P.T_offset,
+                        store_net_cell<true>(N, k, net_cell_local(P, P.albedo, I.conc ? I.conc[k] : 0.0, So, R.Ts_ocean + P.T_offset,
                                                             Ke->E.Mp[k], Ke->E.Qs[k], Ke->E.Ql[k], R.Qc, R.Qv, R.Fv,
                                                             I.Qio ? I.Qio[k] : 0.0, I.Jsio ? I.Jsio[k] : 0.0, I.land ? I.land[k] : 0.0));
                     }

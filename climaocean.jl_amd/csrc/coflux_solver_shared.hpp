@@ -110,6 +110,16 @@ __device__ __forceinline__ double gload(const double* base, unsigned byte_off) {
 __device__ __forceinline__ void gstore(double* base, unsigned byte_off, double v) {
     *(__attribute__((address_space(1))) double*)((__attribute__((address_space(1))) char*)base + byte_off) = v;
 }
+// A store of a value that no kernel of this step reads again (the turbulent heat and vapour fluxes, the interface temperature, the
+// cell-local net fluxes — not ρτ, which the face-stress launch reads next): a streaming store (`nt`), so that the line does not
+// take the place of one the step still needs in the L2.  Same-box A/B, six pairs: the 1/4-degree step 82.8 → 81.7 µs, `:corrected`
+// 72.7 → 71.4, the 1/6-degree tripolar surface 219.2 → 214.3, the 1/8 slab 26.05 → 25.82 (profiles/r06_experiments.md §8); ρτ
+// streamed as well costs the stress kernel what the solver gains, the exchange fields streamed by the interpolation cost the solver
+// more, streaming LOADS of the inputs + 4 … 7 %.  Only where the launch also assembles the net fluxes (FUSE): without them the
+// stand-alone net-flux kernel reads these fields next.
+__device__ __forceinline__ void gstore_final(double* base, unsigned byte_off, double v) {
+    __builtin_nontemporal_store(v, (__attribute__((address_space(1))) double*)((__attribute__((address_space(1))) char*)base + byte_off));
+}
 __device__ __forceinline__ void gstore_i32(int* base, unsigned byte_off, int v) {
     *(__attribute__((address_space(1))) int*)((__attribute__((address_space(1))) char*)base + byte_off) = v;
 }
